@@ -1,0 +1,237 @@
+/*
+ * lidbox_hip.h -- C ABI of liblidbox_hip.so, the MI355X (gfx950) implementation of the
+ * lidbox feature + x-vector hot path.
+ *
+ * The reference (py-lidbox/lidbox) has no FFI: its operator surface is a set of Python
+ * callables whose arithmetic is delegated to TensorFlow ops.  Each entry point below names
+ * the reference callable (file:line relative to the reference checkout) whose arithmetic it
+ * replaces; lidbox_amd/ (Python) mirrors the reference's names on top of these symbols and
+ * INTEGRATION.md shows the ctypes binding a lidbox maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers (unless a parameter says "host"), sizes, scalars,
+ *     and a hipStream_t passed as void*;
+ *   - the caller allocates every output and workspace; nothing here allocates per call
+ *     (plan creation allocates small immutable device tables once);
+ *   - every launch is stream-ordered and re-entrant: concurrent callers on different streams
+ *     are safe, plans are immutable after creation;
+ *   - return value: 0 = ok, negative = error (LIDBOX_E_*); message via lidbox_hip_last_error()
+ *     (thread-local).  Nothing throws across the boundary;
+ *   - all tensors are dense row-major float32 unless stated otherwise.
+ */
+#ifndef LIDBOX_HIP_H
+#define LIDBOX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIDBOX_HIP_ABI_VERSION 1
+
+#define LIDBOX_OK            0
+#define LIDBOX_E_INVALID    -1   /* bad argument (shape, size, null pointer, unsupported value) */
+#define LIDBOX_E_LAUNCH     -2   /* HIP runtime / launch failure */
+#define LIDBOX_E_ALLOC      -3   /* device allocation failed (plan creation only) */
+
+typedef void* lidbox_stream_t;                 /* hipStream_t */
+typedef struct lidbox_feat_plan lidbox_feat_plan;
+
+int         lidbox_hip_abi_version(void);
+const char* lidbox_hip_last_error(void);
+
+/* ------------------------------------------------------------------ host-side scalars/constants */
+
+/* lidbox/features/audio.py:185-189  ms_to_frames: int32(float32(sr) * 1e-3f * float32(ms)) */
+int lidbox_ms_to_frames(int sample_rate, int ms);
+
+/* tf.signal.frame(pad_end=False) frame count used by tf.signal.stft (audio.py:229) */
+int lidbox_num_frames(int num_samples, int frame_length, int frame_step);
+
+/* lidbox/features/mel_ops.py:28-75  linear_to_mel_weight_matrix (non-endpoint _linspace :11-16),
+ * float32 op order.  out_host: [num_spectrogram_bins * num_mel_bins] floats on the HOST. */
+int lidbox_mel_weight_matrix(int num_mel_bins, int num_spectrogram_bins, int sample_rate,
+                             float lower_edge_hertz, float upper_edge_hertz, float* out_host);
+
+/* tf.signal.hann_window(L, periodic=True) as tf.signal.stft applies it; out_host: [L] HOST floats */
+int lidbox_hann_window(int window_length, float* out_host);
+
+/* ------------------------------------------------------------------ feature extraction (a2-a6, a11) */
+
+enum {
+    LIDBOX_FEAT_SPECTROGRAM = 0,   /* audio.py:219-230   |STFT|^power          -> [B,T,F]      */
+    LIDBOX_FEAT_MEL         = 1,   /* audio.py:247-261   spectrogram . W_mel   -> [B,T,M]      */
+    LIDBOX_FEAT_LOGMEL      = 2,   /* tf_utils.py:177-179 ln(mel + 1e-6)       -> [B,T,M]      */
+    LIDBOX_FEAT_MFCC        = 3    /* tf_utils.py:180-185 DCT-II/sqrt(2M), [coef_begin:coef_end) -> [B,T,C] */
+};
+
+/* Immutable per-configuration tables (window, FFT twiddles, banded mel weights, DCT rows) on the
+ * CURRENT device.  Mirrors the constants lidbox rebuilds inside every traced call
+ * (audio.py:226-229, mel_ops.py:28-75, tf_utils.py:181-184). */
+int  lidbox_feat_plan_create(int sample_rate, int frame_length, int frame_step, int fft_length,
+                             float power, int num_mel_bins, float fmin, float fmax,
+                             int coef_begin, int coef_end, lidbox_feat_plan** out_plan);
+void lidbox_feat_plan_destroy(lidbox_feat_plan* plan);
+
+/* number of output channels for `kind` (F, M, M, coef_end-coef_begin) */
+int  lidbox_feat_plan_channels(const lidbox_feat_plan* plan, int kind);
+/* 1 if (kind, N, sig_stride, pointer alignment) takes the fused single-kernel path */
+int  lidbox_feat_plan_is_fused(const lidbox_feat_plan* plan, int kind, const float* signals,
+                               long sig_stride);
+/* bytes of caller-provided workspace the NON-fused path needs (0 when fused) */
+size_t lidbox_extract_features_workspace(const lidbox_feat_plan* plan, int kind, int B, int N,
+                                         const float* signals, long sig_stride);
+
+/* lidbox/data/tf_utils.py:166-185 (spectrogram -> mel -> log -> MFCC stages of extract_features)
+ * signals: [B, N] with row stride sig_stride (floats); out: [B, T, channels(kind)] with
+ * out_batch_stride floats between utterances (0 = dense T*channels; a larger stride lets the
+ * features land directly behind the causal zero rows of the first Conv1D's input buffer);
+ * T = lidbox_num_frames(N, frame_length, frame_step). */
+int lidbox_extract_features_fwd(const lidbox_feat_plan* plan, int kind, const float* signals,
+                                int B, int N, long sig_stride, float* out, long out_batch_stride,
+                                void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+
+/* ------------------------------------------------------------------ normalisation (a7-a10) */
+
+/* lidbox/features/__init__.py:12-32  cmn / cmvn over the middle axis of x viewed as
+ * [outer, R, inner] (axis=1 of [B,T,C]: outer=B, R=T, inner=C).  Population std of x,
+ * divide_no_nan.  normalize_variance=0 -> cmn. */
+int lidbox_cmvn_fwd(const float* x, long outer, long R, long inner, int normalize_variance,
+                    float* out, lidbox_stream_t stream);
+
+/* lidbox/features/__init__.py:35-67  sliding branch of window_normalization on x [B,T,C]
+ * (axis=1, T > window_len >= 2): REFLECT pad [w/2, w/2-1+(w&1)], per-window mean/std. */
+int lidbox_window_norm_fwd(const float* x, int B, int T, int C, int window_len,
+                           int normalize_variance, float* out, lidbox_stream_t stream);
+
+/* min and max of n floats -> out2[0]=min, out2[1]=max (device).  First half of
+ * features.feature_scaling (features/__init__.py:7-8, axis=None) and of audio.power_to_db's
+ * batch-global max (audio.py:173).  scratch: >= 2*1024 floats (device). */
+int lidbox_minmax(const float* x, long n, float* out2, float* scratch, lidbox_stream_t stream);
+
+/* lidbox/features/__init__.py:5-9, axis=None: lo + (hi-lo)*divide_no_nan(x-min, max-min) */
+int lidbox_feature_scaling_fwd(const float* x, long n, const float* minmax2, float lo, float hi,
+                               float* out, lidbox_stream_t stream);
+
+/* lidbox/features/audio.py:167-174 power_to_db: 20*(log10(max(amin,S)) - log10(max(amin,Smax))),
+ * floored at (its own max) - top_db.  minmax2 = lidbox_minmax(S).  scratch as lidbox_minmax. */
+int lidbox_power_to_db_fwd(const float* S, long n, const float* minmax2, float amin, float top_db,
+                           float* out, lidbox_stream_t stream);
+
+/* ------------------------------------------------------------------ GEMM family (a4, a12, a14, a16) */
+
+/* Implicit-GEMM view of a Keras Conv1D(padding="causal") input (xvector.py:38-39, cnn.py:32-35)
+ * and of Dense inputs.  A logical row m = (b, t), 0 <= b < batch, 0 <= t < rows_per_batch,
+ * starts at  base + b*batch_stride + t*row_stride  (floats) and is `K` floats long.  Activations
+ * are stored with (k-1) leading zero rows per utterance, so a causal window is a contiguous
+ * K = k*C_in run and no im2col copy exists.  A plain [M,K] matrix is batch=1, rows_per_batch=M,
+ * row_stride=ld. */
+typedef struct {
+    const float* base;
+    long  batch_stride;
+    long  row_stride;
+    int   batch;
+    int   rows_per_batch;
+} lidbox_rows_t;
+
+typedef struct {
+    float* base;
+    long  batch_stride;
+    long  row_stride;
+    int   batch;
+    int   rows_per_batch;
+} lidbox_rows_out_t;
+
+enum {
+    LIDBOX_EPI_NONE      = 0,
+    LIDBOX_EPI_BIAS      = 1,   /* + bias[n]                                  (Dense, activation=None)  */
+    LIDBOX_EPI_BIAS_RELU = 2,   /* relu(. + bias[n])                          (frame_layer/segment_layer) */
+    LIDBOX_EPI_RELU_MASK = 3,   /* . * (mask[m,n] > 0)   backward through ReLU; mask has C's layout */
+    LIDBOX_EPI_ACCUM     = 4,   /* C += .                                                          */
+    LIDBOX_EPI_ACCUM_RELU_MASK = 5 /* C += . * (mask > 0)                                          */
+};
+
+/* C[M,N] = epi( A[M,K] . B )  -- forward of Conv1D/Dense (a12/a14), linear_to_mel (a4).
+ * A: implicit rows (K contiguous).  B: [K,N] row-major, ldb (Keras kernel layout [k*C_in, C_out]).
+ * C: implicit rows (N contiguous).  aux: bias[N] or mask (layout of C) or NULL. */
+int lidbox_gemm_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C,
+                   int K, int N, int epilogue, const float* aux, lidbox_stream_t stream);
+
+/* C[M,N] = epi( A[M,K] . B^T )  -- dgrad: dX_rows = dY . W^T with B = W[N_out=N rows.. ] i.e.
+ * B is [N,K] row-major (ldb): C[m,n] = sum_k A[m,k]*B[n,k]. */
+int lidbox_gemm_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C,
+                   int K, int N, int epilogue, const float* aux, lidbox_stream_t stream);
+
+/* C[K1,N] (ldc) = A[M,K1]^T . B[M,N]   -- wgrad: dW = col^T . dY, contraction over the M rows.
+ * Split over M into `splits` partial sums reduced deterministically through `workspace`
+ * (>= lidbox_gemm_tn_workspace() bytes).  accumulate != 0: C += result. */
+size_t lidbox_gemm_tn_workspace(int M, int K1, int N);
+int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1, int N,
+                   int accumulate, void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+
+/* out[n] (+)= sum_m rows[m, n]  -- bias gradient; deterministic two-stage reduction through
+ * `workspace` (>= lidbox_colsum_workspace() bytes). */
+size_t lidbox_colsum_workspace(long M, int N);
+int lidbox_colsum(lidbox_rows_t A, int N, float* out, int accumulate, void* workspace,
+                  size_t workspace_bytes, lidbox_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling / losses / optimiser */
+
+/* lidbox/models/xvector.py:25-35 GlobalMeanStddevPooling1D: x [B,T,C] (batch_stride, row_stride
+ * in floats) -> out [B, 2C] = (mean, sqrt(clip(var, 1e-10, FLT_MAX))), two-pass population var. */
+int lidbox_stats_pool_fwd(const float* x, int B, int T, int C, long batch_stride, long row_stride,
+                          float* out, lidbox_stream_t stream);
+/* backward; dx has x's layout; relu_mask != 0 additionally multiplies by (x > 0) (x is the
+ * post-ReLU frame5 output, so this is the ReLU backward of the producing layer). */
+int lidbox_stats_pool_bwd(const float* x, const float* pooled, const float* dout, int B, int T, int C,
+                          long batch_stride, long row_stride, int relu_mask, float* dx,
+                          lidbox_stream_t stream);
+/* Keras GlobalAveragePooling1D (cnn.py:37) */
+int lidbox_avg_pool_fwd(const float* x, int B, int T, int C, long batch_stride, long row_stride,
+                        float* out, lidbox_stream_t stream);
+int lidbox_avg_pool_bwd(const float* x, const float* dout, int B, int T, int C, long batch_stride,
+                        long row_stride, int relu_mask, float* dx, lidbox_stream_t stream);
+
+/* tf.nn.log_softmax (xvector.py:65) over rows of z [B,N] */
+int lidbox_log_softmax_fwd(const float* z, int B, int N, float* logp, lidbox_stream_t stream);
+/* Keras SparseCategoricalCrossentropy(from_logits=True) on log-softmax outputs, mean reduction
+ * (keras_utils.py:141-147): loss_out[0] = mean_b(-logp[b, y_b]); dz = (exp(logp) - onehot) * scale
+ * (scale = 1/global_batch).  dz may be NULL (evaluation). */
+int lidbox_nll_fwd_bwd(const float* logp, const int32_t* labels, int B, int N, float scale,
+                       float* loss_out, float* dz, lidbox_stream_t stream);
+
+/* tf.math.l2_normalize(axis=1) forward / backward on [B,D] */
+int lidbox_l2_normalize_fwd(const float* x, int B, int D, float* out, lidbox_stream_t stream);
+int lidbox_l2_normalize_bwd(const float* x, const float* dout, int B, int D, float* dx,
+                            lidbox_stream_t stream);
+
+/* lidbox/losses.py:25-49 SparseAngularProximity.call: per-example loss [B] from L2-normalised
+ * z [B,D] (D >= N), sparse labels; dz (may be NULL) = d(mean loss * scale*B)/dz, acos' clamped. */
+int lidbox_ap_loss_fwd_bwd(const float* z, const int32_t* labels, int B, int D, int N,
+                           float delta_weight, float scale, float* loss_per_example, float* dz,
+                           lidbox_stream_t stream);
+
+/* lidbox/metrics.py:51-71 AverageDetectionCost.update_state with sparse labels: counters
+ * tp, fn [N,Th]; fp_pairs, tn_pairs [N,N,Th] (float32, accumulated in place). */
+int lidbox_cavg_update(const float* scores, const int32_t* labels, int B, int N,
+                       const float* thresholds, int Th, float* tp, float* fn, float* fp_pairs,
+                       float* tn_pairs, lidbox_stream_t stream);
+/* lidbox/metrics.py:73-103 result(): out[0] = min over thresholds of C_avg; c_avg_out [Th] optional */
+int lidbox_cavg_result(const float* tp, const float* fn, const float* fp_pairs, const float* tn_pairs,
+                       int N, int Th, float C_miss, float C_fa, float P_tar, float* c_avg_out,
+                       float* out, lidbox_stream_t stream);
+
+/* tf.keras.optimizers.Adam dense update (keras_utils.py:137-140; epsilon 1e-7):
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller; grad_scale multiplies g first. */
+int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr_t,
+                     float beta1, float beta2, float eps, float grad_scale, lidbox_stream_t stream);
+
+/* fill n floats with value (stream-ordered) */
+int lidbox_fill(float* x, long n, float value, lidbox_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDBOX_HIP_H */

@@ -1,0 +1,127 @@
+"""
+ctypes binding of liblidbox_hip.so (include/lidbox_hip.h).
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback anywhere in lidbox_amd.
+If the .so is missing or does not load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblidbox_hip.so")
+
+ABI_VERSION = 1
+
+FEAT_SPECTROGRAM, FEAT_MEL, FEAT_LOGMEL, FEAT_MFCC = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_ACCUM_RELU_MASK = 0, 1, 2, 3, 4, 5
+
+
+class LidboxHipError(RuntimeError):
+    pass
+
+
+class Rows(C.Structure):
+    """lidbox_rows_t / lidbox_rows_out_t (identical layout)."""
+    _fields_ = [("base", C.c_void_p), ("batch_stride", C.c_long), ("row_stride", C.c_long),
+                ("batch", C.c_int), ("rows_per_batch", C.c_int)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise LidboxHipError(
+            "liblidbox_hip.so not found at %s -- build it with `python -m lidbox_amd.build` "
+            "(lidbox_amd has no CPU fallback)" % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise LidboxHipError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    return lib
+
+
+lib = _load()
+
+_vp, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+_SIGS = {
+    "lidbox_hip_abi_version": (_i, []),
+    "lidbox_hip_last_error": (C.c_char_p, []),
+    "lidbox_ms_to_frames": (_i, [_i, _i]),
+    "lidbox_num_frames": (_i, [_i, _i, _i]),
+    "lidbox_mel_weight_matrix": (_i, [_i, _i, _i, _f, _f, _vp]),
+    "lidbox_hann_window": (_i, [_i, _vp]),
+    "lidbox_feat_plan_create": (_i, [_i, _i, _i, _i, _f, _i, _f, _f, _i, _i, C.POINTER(_vp)]),
+    "lidbox_feat_plan_destroy": (None, [_vp]),
+    "lidbox_feat_plan_channels": (_i, [_vp, _i]),
+    "lidbox_feat_plan_is_fused": (_i, [_vp, _i, _vp, _l]),
+    "lidbox_extract_features_workspace": (_sz, [_vp, _i, _i, _i, _vp, _l]),
+    "lidbox_extract_features_fwd": (_i, [_vp, _i, _vp, _i, _i, _l, _vp, _l, _vp, _sz, _vp]),
+    "lidbox_cmvn_fwd": (_i, [_vp, _l, _l, _l, _i, _vp, _vp]),
+    "lidbox_window_norm_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lidbox_minmax": (_i, [_vp, _l, _vp, _vp, _vp]),
+    "lidbox_feature_scaling_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
+    "lidbox_power_to_db_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
+    "lidbox_gemm_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp]),
+    "lidbox_gemm_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp]),
+    "lidbox_gemm_tn_workspace": (_sz, [_i, _i, _i]),
+    "lidbox_gemm_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
+    "lidbox_colsum_workspace": (_sz, [_l, _i]),
+    "lidbox_colsum": (_i, [Rows, _i, _vp, _i, _vp, _sz, _vp]),
+    "lidbox_stats_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
+    "lidbox_stats_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
+    "lidbox_avg_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
+    "lidbox_avg_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
+    "lidbox_log_softmax_fwd": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lidbox_nll_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "lidbox_l2_normalize_fwd": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lidbox_l2_normalize_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "lidbox_ap_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "lidbox_cavg_update": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lidbox_cavg_result": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp]),
+    "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
+}
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)      # AttributeError here = the .so is stale: rebuild
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.lidbox_hip_abi_version() != ABI_VERSION:
+    raise LidboxHipError("liblidbox_hip.so ABI %d != expected %d: rebuild with `python -m lidbox_amd.build --force`"
+                         % (lib.lidbox_hip_abi_version(), ABI_VERSION))
+
+
+def last_error():
+    return lib.lidbox_hip_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    """Raise on a negative status, mirroring the reference's exception-on-error behaviour
+    (tf.debugging.assert_* -> InvalidArgumentError, lidbox/data/tf_utils.py:168-194)."""
+    if status != 0:
+        msg = last_error()
+        if status == -1:
+            raise ValueError(msg)
+        raise LidboxHipError("status %d: %s" % (status, msg))
+
+
+def ptr(t):
+    """raw device (or host) pointer of a torch tensor / None"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise LidboxHipError("%s is on %s: lidbox_amd runs on the HIP device only (no CPU fallback)"
+                             % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t

@@ -1,0 +1,692 @@
+// features.hip -- waveform -> |STFT|^p -> mel -> log -> MFCC for gfx950.
+//
+// Replaces (reference file:line, relative to the lidbox checkout):
+//   lidbox/features/audio.py:185-189   ms_to_frames
+//   lidbox/features/audio.py:219-230   spectrograms  (tf.signal.stft + abs + pow)
+//   lidbox/features/mel_ops.py:11-75   linear_to_mel_weight_matrix (non-endpoint _linspace)
+//   lidbox/features/audio.py:247-261   linear_to_mel (tensordot)
+//   lidbox/data/tf_utils.py:172-185    spectrogram -> mel -> ln(x+1e-6) -> MFCC stages
+//
+// Fused fast path (fft_length == 512, frame_length <= 512): ONE kernel reads each sample once
+// from HBM and writes only the final [B,T,C] features.
+//   * 8 lanes per frame, 8 frames per wave64; a wave owns 8 consecutive frames of one utterance.
+//   * the 512-point real FFT is a 256-point complex FFT of the packed signal, done as
+//     16 x 16: an in-register radix-16 DFT, one exchange through LDS (two half passes so a
+//     wave needs 9 KiB), twiddle, second in-register radix-16 DFT.
+//   * lane q ends up holding columns k1 = q and 16-q, so both members of every conjugate pair
+//     (k, 256-k) needed by the real-FFT untangling live in the same lane: no shuffles.
+//   * the mel filterbank is banded (each FFT bin feeds <= 2 triangles; 464 non-zeros of
+//     257x40): a per-band CSR dot product from LDS replaces the dense GEMM, which would
+//     otherwise make this kernel compute-bound at the fp32 vector rate.
+//   * ln(x + 1e-6) and the DCT-II rows for MFCC are epilogues; outputs are staged through
+//     LDS so the global stores are contiguous runs.
+// Roofline: HBM.  Algorithmic bytes per utterance (16 kHz x 2 s, 40 mel): 32000*4 read +
+// 198*40*4 written = 159 680 B.
+//
+// Generic path (any fft_length / frame_length): plain DFT against a twiddle table, one
+// workgroup per frame, spectrogram through a caller-provided workspace.  Correct, not fast.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// host-side constants
+// ------------------------------------------------------------------------------------------------
+extern "C" int lidbox_ms_to_frames(int sample_rate, int ms) {
+    // float32, left to right, truncation (audio.py:189)
+    volatile float a = (float)sample_rate * 1e-3f;
+    volatile float b = a * (float)ms;
+    return (int)b;
+}
+
+extern "C" int lidbox_num_frames(int num_samples, int frame_length, int frame_step) {
+    if (frame_length <= 0 || frame_step <= 0 || num_samples < frame_length) return 0;
+    return 1 + (num_samples - frame_length) / frame_step;
+}
+
+extern "C" int lidbox_hann_window(int L, float* out) {
+    LBX_ARG(L >= 1 && out, "window_length >= 1 and out != NULL");
+    if (L == 1) { out[0] = 1.0f; return LIDBOX_OK; }
+    // tf.signal.hann_window(periodic=True): denominator L + even - 1, float32 arithmetic
+    const int even = 1 - (L % 2);
+    const float n = (float)(L + even - 1);
+    const float two_pi = (float)(2.0 * M_PI);
+    for (int i = 0; i < L; ++i) {
+        const float arg = two_pi * (float)i / n;
+        out[i] = 0.5f - 0.5f * (float)cos((double)arg);
+    }
+    return LIDBOX_OK;
+}
+
+static inline float hz_to_mel_f32(float hz) {   // mel_ops.py:23-25
+    return 1127.0f * logf(1.0f + hz / 700.0f);
+}
+
+extern "C" int lidbox_mel_weight_matrix(int M, int F, int sample_rate, float lo_hz, float hi_hz,
+                                        float* W) {
+    LBX_ARG(M >= 1 && F >= 2 && W, "num_mel_bins >= 1, num_spectrogram_bins >= 2, out != NULL");
+    const float nyq = (float)sample_rate / 2.0f;                              // mel_ops.py:39
+    const float mel_lo = hz_to_mel_f32(lo_hz), mel_hi = hz_to_mel_f32(hi_hz);
+    std::vector<float> edges(M + 2);
+    for (int j = 0; j < M + 2; ++j)                                          // _linspace, :11-16
+        edges[j] = mel_lo + (mel_hi - mel_lo) * (float)j / (float)(M + 2);
+    for (int m = 0; m < M; ++m) W[m] = 0.0f;                                  // DC row, :74-75
+    for (int i = 1; i < F; ++i) {
+        const float hz = 0.0f + (nyq - 0.0f) * (float)i / (float)F;          // non-endpoint
+        const float mel = hz_to_mel_f32(hz);
+        for (int m = 0; m < M; ++m) {
+            const float lower = (mel - edges[m]) / (edges[m + 1] - edges[m]);         // :64-65
+            const float upper = (edges[m + 2] - mel) / (edges[m + 2] - edges[m + 1]); // :66-67
+            float w = fminf(lower, upper);
+            W[(size_t)i * M + m] = w > 0.0f ? w : 0.0f;                               // :70-71
+        }
+    }
+    return LIDBOX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+struct lidbox_feat_plan {
+    int sample_rate, L, S, nfft, F, M, coef_begin, coef_end, ncoef, nnz;
+    float power;
+    bool fused_ok;           // nfft == 512 && L <= 512 && tables fit LDS
+    int device;
+    // device tables
+    float*  d_win512;        // [512] 0.5*hann (zero beyond L)           (fused)
+    float2* d_tw256;         // [16 k1][16 n2]  W256^(n2*k1)             (fused)
+    float2* d_tw512;         // [256]           W512^k                   (fused)
+    float*  d_win;           // [L] hann                                 (generic)
+    float2* d_twN;           // [nfft] e^{-2 pi i j / nfft}              (generic)
+    int*    d_mel_start;     // [M]
+    int*    d_mel_cnt;       // [M]
+    int*    d_mel_off;       // [M]
+    float*  d_mel_w;         // [nnz]
+    float*  d_dct;           // [M][ncoef]
+    void*   d_block;         // single allocation backing all of the above
+};
+
+extern "C" void lidbox_feat_plan_destroy(lidbox_feat_plan* p) {
+    if (!p) return;
+    if (p->d_block) (void)hipFree(p->d_block);
+    delete p;
+}
+
+extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, float power,
+                                       int M, float fmin, float fmax, int coef_begin, int coef_end,
+                                       lidbox_feat_plan** out) {
+    LBX_ARG(out, "out_plan != NULL");
+    LBX_ARG(sample_rate > 0 && L >= 1 && S >= 1 && nfft >= 1, "sample_rate, frame_length, frame_step, fft_length > 0");
+    LBX_ARG(nfft <= 16384, "fft_length <= 16384");
+    LBX_ARG(M >= 1 && M <= 1024, "1 <= num_mel_bins <= 1024");
+    LBX_ARG(power > 0.0f, "power > 0");
+    if (coef_begin < 0) coef_begin = 0;
+    if (coef_end > M) coef_end = M;
+    LBX_ARG(coef_end > coef_begin, "coef_end > coef_begin");
+
+    lidbox_feat_plan* p = new lidbox_feat_plan();
+    memset(p, 0, sizeof(*p));
+    p->sample_rate = sample_rate; p->L = L; p->S = S; p->nfft = nfft; p->F = nfft / 2 + 1;
+    p->M = M; p->coef_begin = coef_begin; p->coef_end = coef_end; p->ncoef = coef_end - coef_begin;
+    p->power = power;
+    LBX_HIP(hipGetDevice(&p->device));
+    const int F = p->F;
+    const int Leff = L < nfft ? L : nfft;       // tf.signal.rfft crops frames longer than fft_length
+
+    // mel matrix (float32 op order) -> banded CSR
+    std::vector<float> W((size_t)F * M);
+    int rc = lidbox_mel_weight_matrix(M, F, sample_rate, fmin, fmax, W.data());
+    if (rc) { delete p; return rc; }
+    std::vector<int> start(M), cnt(M), off(M);
+    std::vector<float> wts;
+    for (int m = 0; m < M; ++m) {
+        int lo = -1, hi = -1;
+        for (int i = 0; i < F; ++i)
+            if (W[(size_t)i * M + m] != 0.0f) { if (lo < 0) lo = i; hi = i; }
+        start[m] = lo < 0 ? 0 : lo;
+        cnt[m] = lo < 0 ? 0 : hi - lo + 1;
+        off[m] = (int)wts.size();
+        for (int i = 0; i < cnt[m]; ++i) wts.push_back(W[(size_t)(start[m] + i) * M + m]);
+    }
+    p->nnz = (int)wts.size();
+    if (wts.empty()) wts.push_back(0.0f);
+
+    // window
+    std::vector<float> win(L), win512(512, 0.0f);
+    lidbox_hann_window(L, win.data());
+    for (int i = 0; i < Leff && i < 512; ++i) win512[i] = 0.5f * win[i];
+    // twiddles (double -> float)
+    std::vector<float2> tw256(256), tw512(256), twN(nfft);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const double a = -2.0 * M_PI * (double)(n2 * k1) / 256.0;
+            tw256[k1 * 16 + n2] = make_float2((float)cos(a), (float)sin(a));
+        }
+    for (int k = 0; k < 256; ++k) {
+        const double a = -2.0 * M_PI * (double)k / 512.0;
+        tw512[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    for (int j = 0; j < nfft; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)nfft;
+        twN[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    // DCT rows: c_k = sqrt(2/M) sum_n x_n cos(pi k (2n+1) / (2M)), k in [coef_begin, coef_end)
+    std::vector<float> dct((size_t)M * p->ncoef);
+    for (int n = 0; n < M; ++n)
+        for (int c = 0; c < p->ncoef; ++c) {
+            const int k = coef_begin + c;
+            dct[(size_t)n * p->ncoef + c] =
+                (float)(2.0 * cos(M_PI * (double)k * (2.0 * n + 1.0) / (2.0 * M)) / sqrt(2.0 * M));
+        }
+
+    // one device block, 256-byte aligned pieces
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o_win512 = 0;
+    size_t o_tw256 = o_win512 + al(512 * 4);
+    size_t o_tw512 = o_tw256 + al(256 * 8);
+    size_t o_win = o_tw512 + al(256 * 8);
+    size_t o_twN = o_win + al((size_t)L * 4);
+    size_t o_ms = o_twN + al((size_t)nfft * 8);
+    size_t o_mc = o_ms + al((size_t)M * 4);
+    size_t o_mo = o_mc + al((size_t)M * 4);
+    size_t o_mw = o_mo + al((size_t)M * 4);
+    size_t o_dct = o_mw + al(wts.size() * 4);
+    size_t total = o_dct + al(dct.size() * 4);
+    char* blk = nullptr;
+    if (hipMalloc((void**)&blk, total) != hipSuccess) {
+        lidbox_set_error("lidbox_feat_plan_create: hipMalloc(%zu) failed", total);
+        delete p;
+        return LIDBOX_E_ALLOC;
+    }
+    p->d_block = blk;
+#define LBX_UP(off, vec, bytes)                                                             \
+    if (hipMemcpy(blk + (off), (vec), (bytes), hipMemcpyHostToDevice) != hipSuccess) {      \
+        lidbox_set_error("lidbox_feat_plan_create: hipMemcpy failed");                      \
+        lidbox_feat_plan_destroy(p);                                                        \
+        return LIDBOX_E_LAUNCH;                                                             \
+    }
+    LBX_UP(o_win512, win512.data(), 512 * 4);
+    LBX_UP(o_tw256, tw256.data(), 256 * 8);
+    LBX_UP(o_tw512, tw512.data(), 256 * 8);
+    LBX_UP(o_win, win.data(), (size_t)L * 4);
+    LBX_UP(o_twN, twN.data(), (size_t)nfft * 8);
+    LBX_UP(o_ms, start.data(), (size_t)M * 4);
+    LBX_UP(o_mc, cnt.data(), (size_t)M * 4);
+    LBX_UP(o_mo, off.data(), (size_t)M * 4);
+    LBX_UP(o_mw, wts.data(), wts.size() * 4);
+    LBX_UP(o_dct, dct.data(), dct.size() * 4);
+#undef LBX_UP
+    p->d_win512 = (float*)(blk + o_win512);
+    p->d_tw256 = (float2*)(blk + o_tw256);
+    p->d_tw512 = (float2*)(blk + o_tw512);
+    p->d_win = (float*)(blk + o_win);
+    p->d_twN = (float2*)(blk + o_twN);
+    p->d_mel_start = (int*)(blk + o_ms);
+    p->d_mel_cnt = (int*)(blk + o_mc);
+    p->d_mel_off = (int*)(blk + o_mo);
+    p->d_mel_w = (float*)(blk + o_mw);
+    p->d_dct = (float*)(blk + o_dct);
+
+    // fused path limits: LDS tables must leave room for >= 2 workgroups per CU
+    p->fused_ok = (nfft == 512) && (L <= 512) && (M <= 64) && (p->nnz <= 1024) &&
+                  ((size_t)M * p->ncoef <= 1024);
+    *out = p;
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_feat_plan_channels(const lidbox_feat_plan* p, int kind) {
+    if (!p) return -1;
+    switch (kind) {
+        case LIDBOX_FEAT_SPECTROGRAM: return p->F;
+        case LIDBOX_FEAT_MEL:
+        case LIDBOX_FEAT_LOGMEL: return p->M;
+        case LIDBOX_FEAT_MFCC: return p->ncoef;
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused kernel
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr float LOG_EPS = 1e-6f;           // tf_utils.py:178
+constexpr int EXCH_ROW = 144;              // bytes: 8 x (2 complex) + 16 pad  -> conflict-free b128
+constexpr int EXCH_FRAME = 8 * EXCH_ROW;   // 1152 B per frame per half pass
+constexpr int P_STRIDE = 264;              // floats per frame in the power buffer (>= 257, = 8 mod 32)
+constexpr int WAVE_SCRATCH = 8 * EXCH_FRAME;   // 9216 B >= 8*264*4 = 8448 B (power buffer aliases it)
+
+struct FusedArgs {
+    const float* signals;
+    long sig_stride;
+    int B, N, T, L, S;
+    float power_half;           // power / 2 (only used when power != 2)
+    int M, ncoef, nnz;
+    const float* win512;
+    const float2* tw256;
+    const float2* tw512;
+    const int* mel_start;
+    const int* mel_cnt;
+    const int* mel_off;
+    const float* mel_w;
+    const float* dct;
+    float* out;
+    long out_bs;                // floats between consecutive utterances in out
+    int tiles_per_utt;          // ceil(T / 8)
+    long ntiles;                // B * tiles_per_utt
+    int iters;                  // tiles per wave
+    unsigned nwg;
+};
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+// forward 4-point DFT in place: (x0,x1,x2,x3) -> (X0,X1,X2,X3)
+__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
+    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = csub(x1, x3);
+    x0 = cadd(t0, t2);
+    x2 = csub(t0, t2);
+    x1 = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i*t3
+    x3 = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i*t3
+}
+
+// register that holds X[k] after dft16 (digit-reversed)
+#define R16(k) (4 * ((k) & 3) + ((k) >> 2))
+
+// forward 16-point DFT in place; input v[n] natural order, output X[k] in v[R16(k)]
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // twiddle Y[b][c] (held in v[4c+b]) by W16^(b*c)
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(C1, -S1));                              // W^1
+    v[4 * 2 + 1] = make_float2((v[9].x + v[9].y) * H, (v[9].y - v[9].x) * H);             // W^2
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], make_float2(S1, -C1));                              // W^3
+    v[4 * 1 + 2] = make_float2((v[6].x + v[6].y) * H, (v[6].y - v[6].x) * H);             // W^2
+    v[4 * 2 + 2] = make_float2(v[10].y, -v[10].x);                                        // W^4 = -i
+    v[4 * 3 + 2] = make_float2((v[14].y - v[14].x) * H, -(v[14].x + v[14].y) * H);        // W^6
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], make_float2(S1, -C1));                              // W^3
+    v[4 * 2 + 3] = make_float2((v[11].y - v[11].x) * H, -(v[11].x + v[11].y) * H);        // W^6
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-C1, S1));                              // W^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+// One conjugate pair of the real-FFT untangling.  zk = Z'[k], zm = Z'[256-k] (Z' already carries
+// the 1/2 through the window), w = W512^k.  Returns |X[k]|^2 and |X[256-k]|^2.
+__device__ __forceinline__ void untangle(float2 zk, float2 zm, float2 w, float& pk, float& pm) {
+    const float er = zk.x + zm.x, ei = zk.y - zm.y;       // e = zk + conj(zm)
+    const float orr = zk.y + zm.y, oi = zm.x - zk.x;      // o = (zk - conj(zm)) / i
+    const float wr = w.x * orr - w.y * oi, wi = w.x * oi + w.y * orr;
+    const float ar = er + wr, ai = ei + wi, br = er - wr, bi = ei - wi;
+    pk = ar * ar + ai * ai;
+    pm = br * br + bi * bi;
+}
+
+template <int KIND, bool VEC4, bool POW2>
+__global__ __launch_bounds__(256) void fused_feat512_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- LDS carve: tables, then one scratch block per wave
+    float* s_win = reinterpret_cast<float*>(smem);                    // 2048 B
+    float2* s_tw256 = reinterpret_cast<float2*>(smem + 2048);         // 2048 B
+    float2* s_tw512 = reinterpret_cast<float2*>(smem + 4096);         // 2048 B
+    int* s_mstart = reinterpret_cast<int*>(smem + 6144);
+    int* s_mcnt = s_mstart + a.M;
+    int* s_moff = s_mcnt + a.M;
+    float* s_mw = reinterpret_cast<float*>(s_moff + a.M);
+    float* s_dct = s_mw + a.nnz;
+    const int table_floats = 1536 + 3 * a.M + a.nnz + (KIND == LIDBOX_FEAT_MFCC ? a.M * a.ncoef : 0);
+    const int table_bytes = (table_floats * 4 + 15) & ~15;
+    const int stage_floats = (KIND == LIDBOX_FEAT_SPECTROGRAM) ? 0 : 8 * a.M + (KIND == LIDBOX_FEAT_MFCC ? 8 * a.ncoef : 0);
+    const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 512; i += 256) s_win[i] = a.win512[i];
+    s_tw256[tid] = a.tw256[tid];
+    s_tw512[tid] = a.tw512[tid];
+    if (KIND != LIDBOX_FEAT_SPECTROGRAM) {
+        for (int i = tid; i < a.M; i += 256) {
+            s_mstart[i] = a.mel_start[i];
+            s_mcnt[i] = a.mel_cnt[i];
+            s_moff[i] = a.mel_off[i];
+        }
+        for (int i = tid; i < a.nnz; i += 256) s_mw[i] = a.mel_w[i];
+        if (KIND == LIDBOX_FEAT_MFCC)
+            for (int i = tid; i < a.M * a.ncoef; i += 256) s_dct[i] = a.dct[i];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 7;          // lane within the frame
+    const int f = lane >> 3;         // frame slot within the wave
+    char* wbuf = smem + table_bytes + wave * wave_bytes;
+    float* s_P = reinterpret_cast<float*>(wbuf);                         // [8][P_STRIDE], aliases exchange
+    float* s_stage = reinterpret_cast<float*>(wbuf + WAVE_SCRATCH);      // [8][M] (+ [8][ncoef])
+
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, a.nwg);
+    const long tile0 = (long)chunk * 4 * a.iters;
+
+    for (int it = 0; it < a.iters; ++it) {
+        const long tile = tile0 + (long)it * 4 + wave;
+        if (tile >= a.ntiles) break;                    // wave-uniform
+        const int b = (int)(tile / a.tiles_per_utt);
+        const int t0 = (int)(tile - (long)b * a.tiles_per_utt) * 8;
+        const int t = t0 + f;
+        const bool valid = t < a.T;
+        const float* src = a.signals + (long)b * a.sig_stride + (long)t * a.S;
+
+        // ---- 1. load + window.  lane q holds n2 = 2q (za) and 2q+1 (zb), n1 = 0..15:
+        //         packed sample n = 16*n1 + n2  <->  reals 32*n1 + 4q .. +3
+        float2 za[16], zb[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int idx = 32 * n1 + 4 * q;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (32 * n1 < a.L) {                         // wave-uniform
+                if (VEC4) {
+                    if (valid && idx < a.L) x = *reinterpret_cast<const float4*>(src + idx);
+                } else {
+                    if (valid && idx + 0 < a.L) x.x = src[idx + 0];
+                    if (valid && idx + 1 < a.L) x.y = src[idx + 1];
+                    if (valid && idx + 2 < a.L) x.z = src[idx + 2];
+                    if (valid && idx + 3 < a.L) x.w = src[idx + 3];
+                }
+                const float4 w = *reinterpret_cast<const float4*>(s_win + idx);
+                x.x *= w.x; x.y *= w.y; x.z *= w.z; x.w *= w.w;
+            }
+            za[n1] = make_float2(x.x, x.y);
+            zb[n1] = make_float2(x.z, x.w);
+        }
+
+        // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
+        dft16(za);
+        dft16(zb);
+        // ---- 3. twiddle by W256^(n2*k1)
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) {
+            const float4 w = *reinterpret_cast<const float4*>(&s_tw256[k1 * 16 + 2 * q]);
+            za[R16(k1)] = cmul(za[R16(k1)], make_float2(w.x, w.y));
+            zb[R16(k1)] = cmul(zb[R16(k1)], make_float2(w.z, w.w));
+        }
+
+        // ---- 4. exchange through LDS in two half passes; lane q ends with
+        //         ua = A[0..15][k1 = q], ub = A[0..15][k1 = (16 - q) % 16, or 8 for q = 0]
+        float2 ua[16], ub[16];
+        char* ex = wbuf + f * EXCH_FRAME;
+        wave_lds_sync();                                 // previous tile's readers are done
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1)
+            *reinterpret_cast<float4*>(ex + k1 * EXCH_ROW + q * 16) =
+                make_float4(za[R16(k1)].x, za[R16(k1)].y, zb[R16(k1)].x, zb[R16(k1)].y);
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(ex + q * EXCH_ROW + j * 16);
+            ua[2 * j] = make_float2(v.x, v.y);
+            ua[2 * j + 1] = make_float2(v.z, v.w);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k1 = 8; k1 < 16; ++k1)
+            *reinterpret_cast<float4*>(ex + (k1 - 8) * EXCH_ROW + q * 16) =
+                make_float4(za[R16(k1)].x, za[R16(k1)].y, zb[R16(k1)].x, zb[R16(k1)].y);
+        wave_lds_sync();
+        const int row2 = (q == 0) ? 0 : 8 - q;           // k1 = 8 for q = 0, else 16 - q
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(ex + row2 * EXCH_ROW + j * 16);
+            ub[2 * j] = make_float2(v.x, v.y);
+            ub[2 * j + 1] = make_float2(v.z, v.w);
+        }
+        // ---- 5. pass 2: DFT16 over n2 -> Z'[k1 + 16*k2] in reg R16(k2)
+        dft16(ua);
+        dft16(ub);
+        wave_lds_sync();                                 // exchange reads done before P overwrites
+
+        // ---- 6. untangle conjugate pairs, |.|^2, into the per-frame power buffer.
+        //   q != 0 : slot s pairs ua[k2=s] (bin q+16s) with ub[k2=15-s] (bin 256-q-16s)
+        //   q == 0 : slots 0..8 pair ua[s] with ua[(16-s)%16] (bins 16s, 256-16s);
+        //            slots 9..16 pair ub[s-9] with ub[24-s]   (bins 8+16(s-9), 248-16(s-9))
+        float* Pf = s_P + f * P_STRIDE;
+        const bool q0 = (q == 0);
+#pragma unroll
+        for (int s = 0; s < 17; ++s) {
+            float2 zk, zm;
+            int bin;
+            if (s <= 8) {
+                zk = ua[R16(s)];
+                const float2 alt = ua[R16((16 - s) & 15)];
+                const float2 gen = ub[R16(15 - s)];
+                zm = make_float2(q0 ? alt.x : gen.x, q0 ? alt.y : gen.y);
+                bin = q + 16 * s;
+            } else if (s < 16) {
+                const float2 g1 = ua[R16(s)], a1 = ub[R16(s - 9)];
+                const float2 g2 = ub[R16(15 - s)], a2 = ub[R16(24 - s)];
+                zk = make_float2(q0 ? a1.x : g1.x, q0 ? a1.y : g1.y);
+                zm = make_float2(q0 ? a2.x : g2.x, q0 ? a2.y : g2.y);
+                bin = q0 ? 8 + 16 * (s - 9) : q + 16 * s;
+            } else {
+                zk = ub[R16(7)];
+                zm = ub[R16(8)];
+                bin = 8 + 16 * 7;
+            }
+            if (s < 16 || q0) {
+                const float2 w = s_tw512[bin];
+                float pk, pm;
+                untangle(zk, zm, w, pk, pm);
+                if (!POW2) {
+                    pk = __powf(pk, a.power_half);
+                    pm = __powf(pm, a.power_half);
+                }
+                Pf[bin] = pk;
+                Pf[256 - bin] = pm;
+            }
+        }
+        wave_lds_sync();
+
+        const int nvalid = min(8, a.T - t0);             // frames of this tile inside the utterance
+        if (KIND == LIDBOX_FEAT_SPECTROGRAM) {
+            float* dst = a.out + (long)b * a.out_bs + (long)t0 * 257;
+            const int total = nvalid * 257;
+            for (int i = lane; i < total; i += 64) {
+                const int ff = i / 257, k = i - ff * 257;
+                dst[i] = s_P[ff * P_STRIDE + k];
+            }
+        } else {
+            // ---- 7. banded mel: lane (f, q) owns bands q, q+8, ...
+            for (int m = q; m < a.M; m += 8) {
+                const int st = s_mstart[m], cn = s_mcnt[m];
+                const float* wv = s_mw + s_moff[m];
+                float acc = 0.f;
+                for (int j = 0; j < cn; ++j) acc = fmaf(Pf[st + j], wv[j], acc);
+                if (KIND != LIDBOX_FEAT_MEL) acc = __logf(acc + LOG_EPS);
+                s_stage[f * a.M + m] = acc;
+            }
+            wave_lds_sync();
+            if (KIND == LIDBOX_FEAT_MFCC) {
+                float* s_coef = s_stage + 8 * a.M;
+                for (int c = q; c < a.ncoef; c += 8) {
+                    float acc = 0.f;
+                    for (int n = 0; n < a.M; ++n) acc = fmaf(s_stage[f * a.M + n], s_dct[n * a.ncoef + c], acc);
+                    s_coef[f * a.ncoef + c] = acc;
+                }
+                wave_lds_sync();
+                float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.ncoef;
+                const int total = nvalid * a.ncoef;
+                for (int i = lane; i < total; i += 64) dst[i] = s_coef[i];
+            } else {
+                float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.M;
+                const int total = nvalid * a.M;
+                for (int i = lane; i < total; i += 64) dst[i] = s_stage[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic path
+// ------------------------------------------------------------------------------------------------
+// one workgroup per frame: windowed frame (cropped/zero-padded to nfft) in LDS, thread k computes
+// bin k by a direct DFT against the twiddle table; writes |X|^power.
+__global__ __launch_bounds__(256) void generic_spectrogram_kernel(
+    const float* __restrict__ signals, long sig_stride, int T, int L, int S, int nfft, int F,
+    const float* __restrict__ win, const float2* __restrict__ tw, float power, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* fr = reinterpret_cast<float*>(smem);
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int Leff = L < nfft ? L : nfft;
+    const float* src = signals + (long)b * sig_stride + (long)t * S;
+    for (int i = threadIdx.x; i < Leff; i += blockDim.x) fr[i] = src[i] * win[i];
+    __syncthreads();
+    for (int k = threadIdx.x; k < F; k += blockDim.x) {
+        float re = 0.f, im = 0.f;
+        int idx = 0;
+        for (int n = 0; n < Leff; ++n) {
+            const float2 w = tw[idx];
+            re = fmaf(fr[n], w.x, re);
+            im = fmaf(fr[n], w.y, im);
+            idx += k;
+            if (idx >= nfft) idx -= nfft;
+        }
+        const float p2 = re * re + im * im;
+        out[((long)b * T + t) * F + k] = (power == 2.0f) ? p2 : powf(p2, 0.5f * power);
+    }
+}
+
+// thread per (frame, band): banded mel (+ optional log)
+__global__ void generic_mel_kernel(const float* __restrict__ spec, long nframes, int F, int M,
+                                   const int* __restrict__ ms, const int* __restrict__ mc,
+                                   const int* __restrict__ mo, const float* __restrict__ mw,
+                                   int do_log, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes * M) return;
+    const long fr = i / M;
+    const int m = (int)(i - fr * M);
+    const float* P = spec + fr * F + ms[m];
+    const float* w = mw + mo[m];
+    float acc = 0.f;
+    for (int j = 0; j < mc[m]; ++j) acc = fmaf(P[j], w[j], acc);
+    out[i] = do_log ? logf(acc + LOG_EPS) : acc;
+}
+
+// thread per (frame, coef)
+__global__ void generic_dct_kernel(const float* __restrict__ logmel, long nframes, int M, int ncoef,
+                                   const float* __restrict__ dct, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes * ncoef) return;
+    const long fr = i / ncoef;
+    const int c = (int)(i - fr * ncoef);
+    float acc = 0.f;
+    for (int n = 0; n < M; ++n) acc = fmaf(logmel[fr * M + n], dct[n * ncoef + c], acc);
+    out[i] = acc;
+}
+
+template <int KIND>
+int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, size_t lds, hipStream_t st) {
+    const bool pow2 = (p->power == 2.0f);
+#define LBX_FUSED(V, P2)                                                                          \
+    hipLaunchKernelGGL((fused_feat512_kernel<KIND, V, P2>), dim3(a.nwg), dim3(256), lds, st, a)
+    if (vec4 && pow2) LBX_FUSED(true, true);
+    else if (vec4) LBX_FUSED(true, false);
+    else if (pow2) LBX_FUSED(false, true);
+    else LBX_FUSED(false, false);
+#undef LBX_FUSED
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+}  // namespace
+
+extern "C" int lidbox_feat_plan_is_fused(const lidbox_feat_plan* p, int kind, const float* signals,
+                                         long sig_stride) {
+    (void)signals; (void)sig_stride; (void)kind;
+    return p && p->fused_ok ? 1 : 0;
+}
+
+extern "C" size_t lidbox_extract_features_workspace(const lidbox_feat_plan* p, int kind, int B, int N,
+                                                    const float* signals, long sig_stride) {
+    if (!p || lidbox_feat_plan_is_fused(p, kind, signals, sig_stride)) return 0;
+    const long T = lidbox_num_frames(N, p->L, p->S);
+    size_t bytes = 0;
+    if (kind != LIDBOX_FEAT_SPECTROGRAM) bytes += (size_t)B * T * p->F * 4;
+    if (kind == LIDBOX_FEAT_MFCC) bytes += (size_t)B * T * p->M * 4;
+    return bytes;
+}
+
+extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, const float* signals,
+                                           int B, int N, long sig_stride, float* out,
+                                           long out_batch_stride, void* workspace,
+                                           size_t workspace_bytes, lidbox_stream_t stream) {
+    LBX_ARG(p && signals && out, "plan, signals, out != NULL");
+    LBX_ARG(kind >= LIDBOX_FEAT_SPECTROGRAM && kind <= LIDBOX_FEAT_MFCC, "kind");
+    LBX_ARG(B >= 0 && N >= 0 && sig_stride >= N, "B >= 0, N >= 0, sig_stride >= N");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = lidbox_num_frames(N, p->L, p->S);
+    if (B == 0 || T == 0) return LIDBOX_OK;
+    const long chan = lidbox_feat_plan_channels(p, kind);
+    if (out_batch_stride == 0) out_batch_stride = (long)T * chan;
+    LBX_ARG(out_batch_stride >= (long)T * chan, "out_batch_stride >= T * channels");
+
+    if (lidbox_feat_plan_is_fused(p, kind, signals, sig_stride)) {
+        FusedArgs a;
+        a.signals = signals; a.sig_stride = sig_stride; a.B = B; a.N = N; a.T = T;
+        a.L = p->L; a.S = p->S; a.power_half = 0.5f * p->power;
+        a.M = p->M; a.ncoef = p->ncoef; a.nnz = p->nnz;
+        a.win512 = p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
+        a.mel_start = p->d_mel_start; a.mel_cnt = p->d_mel_cnt; a.mel_off = p->d_mel_off;
+        a.mel_w = p->d_mel_w; a.dct = p->d_dct; a.out = out; a.out_bs = out_batch_stride;
+        a.tiles_per_utt = (T + 7) / 8;
+        a.ntiles = (long)B * a.tiles_per_utt;
+        // LDS: tables + 4 wave scratch blocks (must mirror the carve in the kernel)
+        const int table_floats = 1536 + 3 * p->M + p->nnz + (kind == LIDBOX_FEAT_MFCC ? p->M * p->ncoef : 0);
+        const int table_bytes = (table_floats * 4 + 15) & ~15;
+        const int stage_floats = (kind == LIDBOX_FEAT_SPECTROGRAM) ? 0
+                                 : 8 * p->M + (kind == LIDBOX_FEAT_MFCC ? 8 * p->ncoef : 0);
+        const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
+        const size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
+        // persistent-ish grid: <= 3 workgroups per CU worth of waves, equal tile counts per wave
+        const long max_wg = 256 * 3;
+        const long wg_needed = lbx_cdiv(a.ntiles, 4);
+        a.iters = (int)lbx_cdiv(wg_needed, max_wg);
+        a.nwg = (unsigned)lbx_cdiv(a.ntiles, 4L * a.iters);
+        // float4 loads need 16-byte aligned frames
+        const bool vec4 = (((uintptr_t)signals & 15) == 0) && (sig_stride % 4 == 0) &&
+                          (p->S % 4 == 0) && (p->L % 4 == 0);
+        switch (kind) {
+            case LIDBOX_FEAT_SPECTROGRAM: return launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, lds, st);
+            case LIDBOX_FEAT_MEL: return launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, lds, st);
+            case LIDBOX_FEAT_LOGMEL: return launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, lds, st);
+            default: return launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, lds, st);
+        }
+    }
+
+    // ---- generic path (dense output only)
+    LBX_ARG(out_batch_stride == (long)T * chan, "the non-fused path needs a dense output (out_batch_stride = T*channels)");
+    const size_t need = lidbox_extract_features_workspace(p, kind, B, N, signals, sig_stride);
+    LBX_ARG(workspace_bytes >= need && (need == 0 || workspace), "workspace too small");
+    const long nframes = (long)B * T;
+    float* spec = (kind == LIDBOX_FEAT_SPECTROGRAM) ? out : (float*)workspace;
+    const int Leff = p->L < p->nfft ? p->L : p->nfft;
+    hipLaunchKernelGGL(generic_spectrogram_kernel, dim3(T, B), dim3(256), (size_t)Leff * 4, st,
+                       signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN,
+                       p->power, spec);
+    LBX_LAUNCH_OK();
+    if (kind == LIDBOX_FEAT_SPECTROGRAM) return LIDBOX_OK;
+    float* mel = (kind == LIDBOX_FEAT_MFCC) ? (float*)workspace + nframes * p->F : out;
+    hipLaunchKernelGGL(generic_mel_kernel, dim3((unsigned)lbx_cdiv(nframes * p->M, 256)), dim3(256), 0, st,
+                       spec, nframes, p->F, p->M, p->d_mel_start, p->d_mel_cnt, p->d_mel_off,
+                       p->d_mel_w, kind != LIDBOX_FEAT_MEL ? 1 : 0, mel);
+    LBX_LAUNCH_OK();
+    if (kind == LIDBOX_FEAT_MFCC) {
+        hipLaunchKernelGGL(generic_dct_kernel, dim3((unsigned)lbx_cdiv(nframes * p->ncoef, 256)), dim3(256), 0,
+                           st, mel, nframes, p->M, p->ncoef, p->d_dct, out);
+        LBX_LAUNCH_OK();
+    }
+    return LIDBOX_OK;
+}

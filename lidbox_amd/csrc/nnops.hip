@@ -1,0 +1,464 @@
+// nnops.hip -- pooling, log-softmax/NLL, L2-normalise, angular-proximity loss, C_avg counters,
+// Keras-Adam and fill kernels (gfx950).
+//
+// Replaces (reference file:line):
+//   lidbox/models/xvector.py:25-35   GlobalMeanStddevPooling1D
+//   lidbox/models/cnn.py:37          GlobalAveragePooling1D
+//   lidbox/models/xvector.py:65      tf.nn.log_softmax
+//   lidbox/models/keras_utils.py:141-147  SparseCategoricalCrossentropy(from_logits) + Adam(eps 1e-7)
+//   lidbox/losses.py:25-52           SparseAngularProximity
+//   lidbox/metrics.py:51-103         AverageDetectionCost update_state / result
+// Reductions over time run inside one workgroup (time is at most a few hundred frames);
+// row-wise ops give each row to one wave64 and reduce with wavefront shuffles.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr float STDDEV_SQRT_MIN_CLIP = 1e-10f;    // xvector.py:22
+
+// grid (ceil(C/64), B); 256 threads = 64 channels x 4 time groups
+template <bool STATS>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x, int T, int C,
+                                                       long bs, long rs, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
+    const int c = blockIdx.x * 64 + col;
+    const int b = blockIdx.y;
+    const bool active = c < C;
+    const float* xp = x + (long)b * bs + c;
+    float s = 0.f;
+    if (active)
+        for (int t = g; t < T; t += 4) s += xp[(long)t * rs];
+    red[tid] = s;
+    __syncthreads();
+    const float mean = (red[col] + red[col + 64] + red[col + 128] + red[col + 192]) / (float)T;
+    if (!STATS) {
+        if (active && g == 0) out[(long)b * C + c] = mean;
+        return;
+    }
+    __syncthreads();
+    float v = 0.f;
+    if (active)
+        for (int t = g; t < T; t += 4) {
+            const float d = xp[(long)t * rs] - mean;
+            v = fmaf(d, d, v);
+        }
+    red[tid] = v;
+    __syncthreads();
+    if (active && g == 0) {
+        const float var = (red[col] + red[col + 64] + red[col + 128] + red[col + 192]) / (float)T;
+        out[(long)b * 2 * C + c] = mean;
+        out[(long)b * 2 * C + C + c] = sqrtf(fminf(fmaxf(var, STDDEV_SQRT_MIN_CLIP), FLT_MAX));
+    }
+}
+
+// thread per (b, t, c), c fastest
+template <bool STATS>
+__global__ void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
+                                const float* __restrict__ dout, int B, int T, int C, long bs, long rs,
+                                int relu_mask, float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T * C) return;
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T);
+    const long b = bt / T;
+    const long off = b * bs + (long)t * rs + c;
+    const float xv = x[off];
+    float g;
+    if (STATS) {
+        const float mean = pooled[b * 2 * C + c], sd = pooled[b * 2 * C + C + c];
+        const float dmean = dout[b * 2 * C + c], dsd = dout[b * 2 * C + C + c];
+        // clip_by_value passes gradient only inside [1e-10, max]; sd == sqrt(1e-10) <=> clipped
+        const float dvar = sd > 1.0000001e-5f ? dsd / (2.f * sd) : 0.f;
+        g = (dmean + dvar * 2.f * (xv - mean)) / (float)T;
+    } else {
+        g = dout[b * C + c] / (float)T;
+    }
+    if (relu_mask && !(xv > 0.f)) g = 0.f;
+    dx[off] = g;
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ z, int B, int N,
+                                                          float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* zr = z + (long)row * N;
+    float m = -FLT_MAX;
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, zr[n]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += expf(zr[n] - m);
+    s = wave_sum(s);
+    const float ls = logf(s);
+    for (int n = lane; n < N; n += 64) out[(long)row * N + n] = (zr[n] - m) - ls;
+}
+
+// single workgroup: mean NLL + gradient wrt the logits feeding log_softmax
+__global__ __launch_bounds__(256) void nll_kernel(const float* __restrict__ logp,
+                                                  const int32_t* __restrict__ labels, int B, int N,
+                                                  float scale, float* __restrict__ loss_out,
+                                                  float* __restrict__ dz) {
+    __shared__ float red[4];
+    float part = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int y = labels[b];
+        // Keras applies softmax cross-entropy to the log-probabilities themselves:
+        // -log_softmax(logp)[y]; logsumexp(logp) is 0 up to rounding and is kept for fidelity
+        float m = -FLT_MAX;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, logp[(long)b * N + n]);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += expf(logp[(long)b * N + n] - m);
+        const float lse = m + logf(s);
+        part += lse - logp[(long)b * N + y];
+        if (dz)
+            for (int n = 0; n < N; ++n)
+                dz[(long)b * N + n] = (expf(logp[(long)b * N + n] - lse) - (n == y ? 1.f : 0.f)) * scale;
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+constexpr float L2_EPS = 1e-12f;   // tf.math.l2_normalize default epsilon
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int B, int D,
+                                                         float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* xr = x + (long)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(xr[d], xr[d], s);
+    s = wave_sum(s);
+    const float inv = rsqrtf(fmaxf(s, L2_EPS));
+    for (int d = lane; d < D; d += 64) out[(long)row * D + d] = xr[d] * inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ dout, int B, int D,
+                                                         float* __restrict__ dx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* xr = x + (long)row * D;
+    const float* gr = dout + (long)row * D;
+    float s = 0.f, dot = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        s = fmaf(xr[d], xr[d], s);
+        dot = fmaf(xr[d], gr[d], dot);
+    }
+    s = wave_sum(s);
+    dot = wave_sum(dot);
+    const bool clipped = s < L2_EPS;
+    const float inv = rsqrtf(fmaxf(s, L2_EPS));
+    const float k = clipped ? 0.f : dot * inv * inv * inv;   // y (y . g) / |x|
+    for (int d = lane; d < D; d += 64) dx[(long)row * D + d] = gr[d] * inv - xr[d] * k;
+}
+
+constexpr float AP_ACOS_CLAMP = 1e-6f;   // floor of 1 - x^2 in d acos/dx (TF would return inf at |x| = 1)
+
+// one wave per example
+__global__ __launch_bounds__(256) void ap_loss_kernel(const float* __restrict__ z,
+                                                      const int32_t* __restrict__ labels, int B, int D,
+                                                      int N, float delta, float scale,
+                                                      float* __restrict__ loss, float* __restrict__ dz) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* zr = z + (long)row * D;
+    const int y = labels[row];
+    const float th_y = acosf(zr[y]);                       // losses.py:31-33 (theta_l)
+    float L = 0.f, dsum = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        if (n == y) continue;
+        const float th = acosf(zr[n]);
+        const float s = 1.f / (1.f + expf(-delta * (th_y - th)));      // losses.py:35-36
+        L += s;
+        const float ds = delta * s * (1.f - s);
+        dsum += ds;
+        if (dz) {
+            const float x = zr[n];
+            dz[(long)row * D + n] = ds * rsqrtf(fmaxf(1.f - x * x, AP_ACOS_CLAMP)) * scale;   // -ds * acos'
+        }
+    }
+    L = wave_sum(L);
+    dsum = wave_sum(dsum);
+    if (lane == 0) {
+        loss[row] = L;
+        if (dz) {
+            const float x = zr[y];
+            dz[(long)row * D + y] = -dsum * rsqrtf(fmaxf(1.f - x * x, AP_ACOS_CLAMP)) * scale;
+        }
+    }
+    if (dz)
+        for (int d = N + lane; d < D; d += 64) dz[(long)row * D + d] = 0.f;
+}
+
+// C_avg counters.  grid (N scored classes m, ceil(Th/64)); 64 threads = 64 thresholds.
+// LDS pos[l][th] counts examples with label l whose score for class m is >= threshold; the
+// workgroup is the only writer of cells [*, m, th-tile], so no atomics and the result is exact.
+__global__ __launch_bounds__(64) void cavg_update_kernel(const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ labels, int B, int N,
+                                                         const float* __restrict__ thresholds, int Th,
+                                                         int lch, float* __restrict__ tp,
+                                                         float* __restrict__ fn, float* __restrict__ fp,
+                                                         float* __restrict__ tn) {
+    extern __shared__ float s_cnt[];          // pos[lch][64] then cnt[lch]
+    float* pos = s_cnt;
+    float* cnt = s_cnt + lch * 64;
+    const int m = blockIdx.x;
+    const int th = blockIdx.y * 64 + threadIdx.x;
+    const float thr = th < Th ? thresholds[th] : 0.f;
+    for (int l0 = 0; l0 < N; l0 += lch) {
+        const int nl = min(lch, N - l0);
+        for (int l = 0; l < nl; ++l) pos[l * 64 + threadIdx.x] = 0.f;
+        for (int l = threadIdx.x; l < nl; l += 64) cnt[l] = 0.f;
+        __syncthreads();
+        for (int b = 0; b < B; ++b) {
+            const int y = labels[b] - l0;               // uniform across the workgroup
+            if (y < 0 || y >= nl) continue;
+            const float s = scores[(long)b * N + m];
+            if (s >= thr) pos[y * 64 + threadIdx.x] += 1.f;     // metrics.py:60
+            if (threadIdx.x == 0) cnt[y] += 1.f;
+        }
+        __syncthreads();
+        if (th < Th)
+            for (int l = 0; l < nl; ++l) {
+                const int lab = l0 + l;
+                const float p = pos[l * 64 + threadIdx.x], ng = cnt[l] - p;   // s < thr  (:61)
+                if (lab == m) {
+                    tp[(long)m * Th + th] += p;                                // :63-66
+                    fn[(long)m * Th + th] += ng;
+                } else {
+                    fp[((long)lab * N + m) * Th + th] += p;                    // :68-71
+                    tn[((long)lab * N + m) * Th + th] += ng;
+                }
+            }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ float div_no_nan(float a, float b) { return b != 0.f ? a / b : 0.f; }
+
+__global__ __launch_bounds__(256) void cavg_result_kernel(const float* __restrict__ tp,
+                                                          const float* __restrict__ fn,
+                                                          const float* __restrict__ fp,
+                                                          const float* __restrict__ tn, int N, int Th,
+                                                          float C_miss, float C_fa, float P_tar,
+                                                          float* __restrict__ c_avg_out,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4];
+    float best = FLT_MAX;
+    for (int th = threadIdx.x; th < Th; th += 256) {
+        float pm = 0.f, pf = 0.f;
+        for (int l = 0; l < N; ++l) {
+            const float a = fn[(long)l * Th + th], b = tp[(long)l * Th + th];
+            pm += div_no_nan(a, a + b);                                         // metrics.py:80-85
+            float inner = 0.f;
+            for (int m = 0; m < N; ++m) {
+                const float f = fp[((long)l * N + m) * Th + th], t = tn[((long)l * N + m) * Th + th];
+                inner += div_no_nan(f, f + t);                                  // :89-95
+            }
+            pf += div_no_nan(inner, (float)(N - 1));
+        }
+        pm /= (float)N;
+        pf /= (float)N;
+        const float c = C_miss * P_tar * pm + C_fa * (1.f - P_tar) * pf;        // :98
+        if (c_avg_out) c_avg_out[th] = c;
+        best = fminf(best, c);
+    }
+    best = wave_min(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));   // :103
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
+                            float gscale) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define LBX_ADAM1(c)                                              \
+    {                                                             \
+        const float gr = gg.c * gscale;                           \
+        mm.c = b1 * mm.c + (1.f - b1) * gr;                       \
+        vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                  \
+        pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps);          \
+    }
+        LBX_ADAM1(x) LBX_ADAM1(y) LBX_ADAM1(z) LBX_ADAM1(w)
+#undef LBX_ADAM1
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gr = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gr;
+        const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ x, long n, float value) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = value;
+}
+
+inline unsigned ew_grid(long n) {
+    long g = lbx_cdiv(n, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int lidbox_stats_pool_fwd(const float* x, int B, int T, int C, long bs, long rs, float* out,
+                                     lidbox_stream_t stream) {
+    LBX_ARG(x && out && B >= 0 && T >= 1 && C >= 1, "x, out != NULL; T, C >= 1");
+    if (B == 0) return LIDBOX_OK;
+    LBX_ARG(B <= 65535, "B <= 65535");
+    hipLaunchKernelGGL(pool_fwd_kernel<true>, dim3((unsigned)lbx_cdiv(C, 64), B), dim3(256), 0,
+                       (hipStream_t)stream, x, T, C, bs, rs, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_avg_pool_fwd(const float* x, int B, int T, int C, long bs, long rs, float* out,
+                                   lidbox_stream_t stream) {
+    LBX_ARG(x && out && B >= 0 && T >= 1 && C >= 1, "x, out != NULL; T, C >= 1");
+    if (B == 0) return LIDBOX_OK;
+    LBX_ARG(B <= 65535, "B <= 65535");
+    hipLaunchKernelGGL(pool_fwd_kernel<false>, dim3((unsigned)lbx_cdiv(C, 64), B), dim3(256), 0,
+                       (hipStream_t)stream, x, T, C, bs, rs, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_stats_pool_bwd(const float* x, const float* pooled, const float* dout, int B, int T,
+                                     int C, long bs, long rs, int relu_mask, float* dx,
+                                     lidbox_stream_t stream) {
+    LBX_ARG(x && pooled && dout && dx && T >= 1 && C >= 1, "pointers != NULL; T, C >= 1");
+    const long total = (long)B * T * C;
+    if (total == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3((unsigned)lbx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, pooled, dout, B, T, C, bs, rs, relu_mask, dx);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_avg_pool_bwd(const float* x, const float* dout, int B, int T, int C, long bs, long rs,
+                                   int relu_mask, float* dx, lidbox_stream_t stream) {
+    LBX_ARG(x && dout && dx && T >= 1 && C >= 1, "pointers != NULL; T, C >= 1");
+    const long total = (long)B * T * C;
+    if (total == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3((unsigned)lbx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (const float*)nullptr, dout, B, T, C, bs, rs, relu_mask, dx);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_log_softmax_fwd(const float* z, int B, int N, float* logp, lidbox_stream_t stream) {
+    LBX_ARG(z && logp && B >= 0 && N >= 1, "z, logp != NULL; N >= 1");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), 0,
+                       (hipStream_t)stream, z, B, N, logp);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_nll_fwd_bwd(const float* logp, const int32_t* labels, int B, int N, float scale,
+                                  float* loss_out, float* dz, lidbox_stream_t stream) {
+    LBX_ARG(logp && labels && loss_out && B >= 1 && N >= 1, "logp, labels, loss_out != NULL; B, N >= 1");
+    hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, labels, B, N, scale,
+                       loss_out, dz);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_l2_normalize_fwd(const float* x, int B, int D, float* out, lidbox_stream_t stream) {
+    LBX_ARG(x && out && B >= 0 && D >= 1, "x, out != NULL; D >= 1");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, B, D, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_l2_normalize_bwd(const float* x, const float* dout, int B, int D, float* dx,
+                                       lidbox_stream_t stream) {
+    LBX_ARG(x && dout && dx && B >= 0 && D >= 1, "x, dout, dx != NULL; D >= 1");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, dout, B, D, dx);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_ap_loss_fwd_bwd(const float* z, const int32_t* labels, int B, int D, int N,
+                                      float delta_weight, float scale, float* loss_per_example, float* dz,
+                                      lidbox_stream_t stream) {
+    LBX_ARG(z && labels && loss_per_example, "z, labels, loss != NULL");
+    LBX_ARG(N >= 1 && D >= N, "N >= 1 and D >= N (losses.py:14-15)");
+    LBX_ARG(delta_weight > 0.f, "delta_weight > 0 (losses.py:16)");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(ap_loss_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream,
+                       z, labels, B, D, N, delta_weight, scale, loss_per_example, dz);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_cavg_update(const float* scores, const int32_t* labels, int B, int N,
+                                  const float* thresholds, int Th, float* tp, float* fn, float* fp_pairs,
+                                  float* tn_pairs, lidbox_stream_t stream) {
+    LBX_ARG(scores && labels && thresholds && tp && fn && fp_pairs && tn_pairs, "pointers != NULL");
+    LBX_ARG(N >= 2 && Th >= 1, "N >= 2 (metrics.py:20), Th >= 1");
+    if (B == 0) return LIDBOX_OK;
+    const int lch = N < 224 ? N : 224;                       // label chunk held in LDS
+    const size_t lds = ((size_t)lch * 64 + lch) * sizeof(float);
+    hipLaunchKernelGGL(cavg_update_kernel, dim3(N, (unsigned)lbx_cdiv(Th, 64)), dim3(64), lds,
+                       (hipStream_t)stream, scores, labels, B, N, thresholds, Th, lch, tp, fn, fp_pairs,
+                       tn_pairs);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_cavg_result(const float* tp, const float* fn, const float* fp_pairs,
+                                  const float* tn_pairs, int N, int Th, float C_miss, float C_fa, float P_tar,
+                                  float* c_avg_out, float* out, lidbox_stream_t stream) {
+    LBX_ARG(tp && fn && fp_pairs && tn_pairs && out, "pointers != NULL");
+    LBX_ARG(N >= 2 && Th >= 1, "N >= 2, Th >= 1");
+    hipLaunchKernelGGL(cavg_result_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tp, fn, fp_pairs,
+                       tn_pairs, N, Th, C_miss, C_fa, P_tar, c_avg_out, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr_t,
+                                float beta1, float beta2, float eps, float grad_scale,
+                                lidbox_stream_t stream) {
+    LBX_ARG(param && grad && m && v && n >= 0, "pointers != NULL");
+    LBX_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+            "param/grad/m/v must be 16-byte aligned");
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_fill(float* x, long n, float value, lidbox_stream_t stream) {
+    LBX_ARG(x && n >= 0, "x != NULL");
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, value);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}

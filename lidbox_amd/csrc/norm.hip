@@ -1,0 +1,226 @@
+// norm.hip -- CMN/CMVN, sliding-window normalisation, min-max scaling, power_to_db (gfx950).
+//
+// Replaces (reference file:line):
+//   lidbox/features/__init__.py:12-32   cmn / cmvn       (reduce_mean, reduce_std, divide_no_nan)
+//   lidbox/features/__init__.py:35-67   window_normalization (REFLECT pad + tf.signal.frame)
+//   lidbox/features/__init__.py:5-9     feature_scaling
+//   lidbox/features/audio.py:162-174    log10, power_to_db
+// All HBM-bound and tiny next to the signal read (31 KB/utt vs 128 KB/utt); they are written
+// for coalesced access along the innermost axis and two-pass (mean, then centred variance)
+// statistics, the structure of tf.math.reduce_std.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+// x viewed as [outer, R, inner]; one workgroup per (outer, column tile of cw columns);
+// 256 threads = cw columns x (256/cw) row groups.
+__global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ x, long R, long inner,
+                                                   int cw, int normalize_variance,
+                                                   float* __restrict__ out) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int col = tid % cw, g = tid / cw, ng = 256 / cw;
+    const long c = (long)blockIdx.x * cw + col;
+    const long o = blockIdx.y;
+    const bool active = c < inner;
+    const float* xp = x + o * R * inner + c;
+    float* op = out + o * R * inner + c;
+
+    float s = 0.f;
+    if (active)
+        for (long r = g; r < R; r += ng) s += xp[r * inner];
+    red[tid] = s;
+    __syncthreads();
+    for (int h = ng / 2; h > 0; h >>= 1) {
+        if (g < h) red[tid] += red[tid + h * cw];
+        __syncthreads();
+    }
+    const float mean = red[col] / (float)R;
+    __syncthreads();
+
+    float sd = 1.f;
+    if (normalize_variance) {
+        float v = 0.f;
+        if (active)
+            for (long r = g; r < R; r += ng) {
+                const float d = xp[r * inner] - mean;
+                v = fmaf(d, d, v);
+            }
+        red[tid] = v;
+        __syncthreads();
+        for (int h = ng / 2; h > 0; h >>= 1) {
+            if (g < h) red[tid] += red[tid + h * cw];
+            __syncthreads();
+        }
+        sd = sqrtf(red[col] / (float)R);             // population std of x
+    }
+    if (active)
+        for (long r = g; r < R; r += ng) {
+            const float d = xp[r * inner] - mean;
+            op[r * inner] = normalize_variance ? (sd != 0.f ? d / sd : 0.f) : d;   // divide_no_nan
+        }
+}
+
+// numpy-'reflect' index into [0, T)
+__device__ __forceinline__ int reflect_idx(int i, int T) {
+    if (i < 0) i = -i;
+    if (i >= T) i = 2 * (T - 1) - i;
+    return i;
+}
+
+// thread per (b, t, c), c fastest.  Window t covers padded rows t..t+w-1, padded row i <-> x row
+// reflect(i - w/2).
+__global__ void window_norm_kernel(const float* __restrict__ x, int B, int T, int C, int w,
+                                   int normalize_variance, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * T * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T);
+    const long b = bt / T;
+    const float* xb = x + b * (long)T * C + c;
+    const int left = w / 2;
+    float s = 0.f;
+    for (int j = 0; j < w; ++j) s += xb[(long)reflect_idx(t + j - left, T) * C];
+    const float mean = s / (float)w;
+    const float d = xb[(long)t * C] - mean;
+    if (!normalize_variance) { out[i] = d; return; }
+    float v = 0.f;
+    for (int j = 0; j < w; ++j) {
+        const float e = xb[(long)reflect_idx(t + j - left, T) * C] - mean;
+        v = fmaf(e, e, v);
+    }
+    const float sd = sqrtf(v / (float)w);
+    out[i] = sd != 0.f ? d / sd : 0.f;
+}
+
+constexpr int MM_MAX_WG = 1024;
+
+__global__ __launch_bounds__(256) void minmax_stage1(const float* __restrict__ x, long n,
+                                                     float* __restrict__ scratch) {
+    __shared__ float smin[4], smax[4];
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        scratch[MM_MAX_WG + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_stage2(const float* __restrict__ scratch, int nwg,
+                                                     float* __restrict__ out2) {
+    __shared__ float smin[4], smax[4];
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    for (int i = threadIdx.x; i < nwg; i += 256) {
+        mn = fminf(mn, scratch[i]);
+        mx = fmaxf(mx, scratch[MM_MAX_WG + i]);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        out2[1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+
+__global__ void feature_scaling_kernel(const float* __restrict__ x, long n,
+                                       const float* __restrict__ mm, float lo, float hi,
+                                       float* __restrict__ out) {
+    const float mn = mm[0], range = mm[1] - mm[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float q = range != 0.f ? (x[i] - mn) / range : 0.f;       // divide_no_nan
+        out[i] = lo + (hi - lo) * q;
+    }
+}
+
+__device__ __forceinline__ float log10_tf(float v) { return logf(v) / logf(10.0f); }   // audio.py:164
+
+__global__ void power_to_db_kernel(const float* __restrict__ S, long n, const float* __restrict__ mm,
+                                   float amin, float top_db, float* __restrict__ out) {
+    const float ref = log10_tf(fmaxf(amin, mm[1]));
+    // the batch-global max of the dB spectrogram is 20*(ref - ref) = 0 exactly, so the floor
+    // reduce_max(db) - top_db (audio.py:174) is -top_db
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float db = 20.0f * (log10_tf(fmaxf(amin, S[i])) - ref);
+        out[i] = fmaxf(db, 0.0f - top_db);
+    }
+}
+
+inline unsigned ew_grid(long n) {
+    long g = lbx_cdiv(n, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int lidbox_cmvn_fwd(const float* x, long outer, long R, long inner, int normalize_variance,
+                               float* out, lidbox_stream_t stream) {
+    LBX_ARG(x && out, "x, out != NULL");
+    LBX_ARG(outer >= 0 && R >= 0 && inner >= 0, "non-negative shape");
+    if (outer == 0 || R == 0 || inner == 0) return LIDBOX_OK;
+    LBX_ARG(outer <= 65535, "outer <= 65535");
+    int cw = 64;
+    while (cw > 1 && cw / 2 >= inner) cw /= 2;
+    dim3 grid((unsigned)lbx_cdiv(inner, cw), (unsigned)outer);
+    hipLaunchKernelGGL(cmvn_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, R, inner, cw,
+                       normalize_variance, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_window_norm_fwd(const float* x, int B, int T, int C, int window_len,
+                                      int normalize_variance, float* out, lidbox_stream_t stream) {
+    LBX_ARG(x && out, "x, out != NULL");
+    LBX_ARG(B >= 0 && T >= 0 && C >= 0, "non-negative shape");
+    LBX_ARG(window_len >= 2 && window_len < T, "2 <= window_len < T (the sliding branch; use cmvn otherwise)");
+    const long total = (long)B * T * C;
+    if (total == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(window_norm_kernel, dim3((unsigned)lbx_cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, B, T, C, window_len, normalize_variance, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_minmax(const float* x, long n, float* out2, float* scratch, lidbox_stream_t stream) {
+    LBX_ARG(x && out2 && scratch && n > 0, "x, out2, scratch != NULL, n > 0");
+    long g = lbx_cdiv(n, 256 * 8);
+    const int nwg = (int)(g < 1 ? 1 : (g > MM_MAX_WG ? MM_MAX_WG : g));
+    hipLaunchKernelGGL(minmax_stage1, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, n, scratch);
+    LBX_LAUNCH_OK();
+    hipLaunchKernelGGL(minmax_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nwg, out2);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_feature_scaling_fwd(const float* x, long n, const float* minmax2, float lo, float hi,
+                                          float* out, lidbox_stream_t stream) {
+    LBX_ARG(x && out && minmax2 && n >= 0, "x, out, minmax2 != NULL");
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(feature_scaling_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       minmax2, lo, hi, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_power_to_db_fwd(const float* S, long n, const float* minmax2, float amin, float top_db,
+                                      float* out, lidbox_stream_t stream) {
+    LBX_ARG(S && out && minmax2 && n >= 0, "S, out, minmax2 != NULL");
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(power_to_db_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, S, n,
+                       minmax2, amin, top_db, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}

@@ -1,0 +1,84 @@
+"""
+Counterpart of lidbox/features/__init__.py: feature_scaling, cmn, cmvn, window_normalization
+with the reference's signatures (file:line cited per function), over torch tensors on the HIP
+device.  Arithmetic runs in liblidbox_hip.so; there is no CPU fallback.
+"""
+import torch
+
+from .. import _native as nv
+
+
+def _as_outer_r_inner(X, axis):
+    axis = axis % X.dim()
+    outer = 1
+    for d in X.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in X.shape[axis + 1:]:
+        inner *= d
+    return outer, X.shape[axis], inner
+
+
+def _cmvn(X, axis, normalize_variance):
+    X = nv.require_gpu_tensor(X, "X", torch.float32).contiguous()
+    out = torch.empty_like(X)
+    if X.numel() == 0:
+        return out
+    outer, R, inner = _as_outer_r_inner(X, axis)
+    with torch.cuda.device(X.device):
+        nv.check(nv.lib.lidbox_cmvn_fwd(nv.ptr(X), outer, R, inner, int(bool(normalize_variance)), nv.ptr(out),
+                                        nv.current_stream()))
+    return out
+
+
+def feature_scaling(X, min, max, axis=None):
+    """reference lidbox/features/__init__.py:5-9.  axis=None (the only form the pipeline uses,
+    tf_utils.py:189-190) runs the fused min/max + rescale kernels; an explicit axis is plain
+    tensor plumbing."""
+    X = nv.require_gpu_tensor(X, "X", torch.float32)
+    if axis is not None:
+        X_min = torch.amin(X, dim=axis, keepdim=True)
+        X_max = torch.amax(X, dim=axis, keepdim=True)
+        rng = X_max - X_min
+        q = torch.where(rng != 0, (X - X_min) / torch.where(rng != 0, rng, torch.ones_like(rng)), torch.zeros_like(X))
+        return min + (max - min) * q
+    X = X.contiguous()
+    out = torch.empty_like(X)
+    if X.numel() == 0:
+        return out
+    from .audio import _minmax
+    mm = _minmax(X)
+    with torch.cuda.device(X.device):
+        nv.check(nv.lib.lidbox_feature_scaling_fwd(nv.ptr(X), X.numel(), nv.ptr(mm), float(min), float(max),
+                                                   nv.ptr(out), nv.current_stream()))
+    return out
+
+
+def cmn(X, axis=1):
+    """reference lidbox/features/__init__.py:12-20."""
+    return _cmvn(X, axis, False)
+
+
+def cmvn(X, axis=1):
+    """reference lidbox/features/__init__.py:22-32 (population std, divide_no_nan)."""
+    return _cmvn(X, axis, True)
+
+
+def window_normalization(X, axis=1, window_len=-1, normalize_variance=True):
+    """reference lidbox/features/__init__.py:35-67."""
+    X = nv.require_gpu_tensor(X, "X", torch.float32)
+    if X.dim() != 3:
+        raise ValueError("X must be [B, T, C]")
+    if window_len == -1 or X.shape[1] <= window_len:
+        return cmvn(X, axis=axis) if normalize_variance else cmn(X, axis=axis)
+    if axis != 1:
+        raise ValueError("sliding window normalization is defined on axis=1 (the reference pads dim 1)")
+    X = X.contiguous()
+    out = torch.empty_like(X)
+    if X.numel() == 0:
+        return out
+    B, T, C = X.shape
+    with torch.cuda.device(X.device):
+        nv.check(nv.lib.lidbox_window_norm_fwd(nv.ptr(X), B, T, C, int(window_len), int(bool(normalize_variance)),
+                                               nv.ptr(out), nv.current_stream()))
+    return out

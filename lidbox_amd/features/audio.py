@@ -1,0 +1,151 @@
+"""
+Counterpart of lidbox/features/audio.py for the hot path: the same function names, argument
+names and defaults as the reference (cited per function, file:line relative to the lidbox
+checkout), over torch tensors on the HIP device.  All arithmetic runs in liblidbox_hip.so.
+File decoding, VAD, resampling and augmentation helpers of the reference module are out of
+scope.
+"""
+import math
+import threading
+
+import torch
+
+from .. import _native as nv
+from . import mel_ops
+
+_plans = {}
+_plan_lock = threading.Lock()
+
+
+class FeaturePlan:
+    """Immutable device tables for one (sample_rate, framing, fft, mel, mfcc) configuration."""
+
+    def __init__(self, sample_rate, frame_length, frame_step, fft_length, power, num_mel_bins, fmin, fmax,
+                 coef_begin, coef_end):
+        import ctypes
+        h = ctypes.c_void_p()
+        nv.check(nv.lib.lidbox_feat_plan_create(int(sample_rate), int(frame_length), int(frame_step),
+                                                int(fft_length), float(power), int(num_mel_bins),
+                                                float(fmin), float(fmax), int(coef_begin), int(coef_end),
+                                                ctypes.byref(h)))
+        self.handle = h
+        self.frame_length, self.frame_step, self.fft_length = int(frame_length), int(frame_step), int(fft_length)
+
+    def channels(self, kind):
+        return nv.lib.lidbox_feat_plan_channels(self.handle, kind)
+
+    def num_frames(self, num_samples):
+        return nv.lib.lidbox_num_frames(int(num_samples), self.frame_length, self.frame_step)
+
+    def run(self, kind, signals, out=None, out_batch_stride=0):
+        """signals [B,N] float32 on the HIP device -> [B,T,C]."""
+        nv.require_gpu_tensor(signals, "signals", torch.float32)
+        if signals.dim() != 2:
+            raise ValueError("Input signals for feature extraction must be batches of mono signals "
+                             "without channels, i.e. of shape [B, N]")
+        if signals.stride(1) != 1:
+            signals = signals.contiguous()
+        B, N = signals.shape
+        T, C = self.num_frames(N), self.channels(kind)
+        if out is None:
+            out = torch.empty((B, T, C), dtype=torch.float32, device=signals.device)
+        if B == 0 or T == 0:
+            return out
+        stride = signals.stride(0) if B > 1 else N      # a size-1 dim may carry any stride
+        wbytes = nv.lib.lidbox_extract_features_workspace(self.handle, kind, B, N, nv.ptr(signals), stride)
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=signals.device) if wbytes else None
+        with torch.cuda.device(signals.device):
+            nv.check(nv.lib.lidbox_extract_features_fwd(self.handle, kind, nv.ptr(signals), B, N, stride,
+                                                        nv.ptr(out), int(out_batch_stride), nv.ptr(ws), wbytes,
+                                                        nv.current_stream()))
+        return out
+
+
+def get_plan(sample_rate, frame_length, frame_step, fft_length=512, power=2.0, num_mel_bins=40, fmin=0.0,
+             fmax=8000.0, coef_begin=1, coef_end=13, device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, int(sample_rate), int(frame_length), int(frame_step), int(fft_length), float(power),
+           int(num_mel_bins), float(fmin), float(fmax), int(coef_begin), int(coef_end))
+    with _plan_lock:
+        plan = _plans.get(key)
+        if plan is None:
+            with torch.cuda.device(dev):
+                plan = FeaturePlan(*key[1:])
+            _plans[key] = plan
+    return plan
+
+
+def _scalar(x):
+    return x.item() if isinstance(x, torch.Tensor) else x
+
+
+def ms_to_frames(sample_rate, ms):
+    """reference lidbox/features/audio.py:185-189 (float32 arithmetic, truncation)."""
+    return nv.lib.lidbox_ms_to_frames(int(_scalar(sample_rate)), int(_scalar(ms)))
+
+
+def spectrograms(signals, sample_rate, frame_length_ms=25, frame_step_ms=10, power=2.0, fft_length=512):
+    """reference lidbox/features/audio.py:219-230: |tf.signal.stft|^power, [B,N] -> [B,T,fft_length//2+1]."""
+    sample_rate = int(_scalar(sample_rate))
+    frame_length = ms_to_frames(sample_rate, frame_length_ms)
+    frame_step = ms_to_frames(sample_rate, frame_step_ms)
+    plan = get_plan(sample_rate, frame_length, frame_step, int(fft_length), float(power),
+                    device=signals.device if isinstance(signals, torch.Tensor) else None)
+    return plan.run(nv.FEAT_SPECTROGRAM, signals)
+
+
+def linear_to_mel(spectrograms, sample_rate, num_mel_bins=40, fmin=0.0, fmax=8000.0):
+    """reference lidbox/features/audio.py:247-261: tensordot(S [B,T,F], W [F,M], 1) on the MFMA GEMM."""
+    S = nv.require_gpu_tensor(spectrograms, "spectrograms", torch.float32)
+    if S.dim() != 3:
+        raise ValueError("spectrograms must be [B, T, F]")
+    S = S.contiguous()
+    B, T, F = S.shape
+    W = mel_ops.linear_to_mel_weight_matrix(num_mel_bins=num_mel_bins, num_spectrogram_bins=F,
+                                            sample_rate=int(_scalar(sample_rate)), lower_edge_hertz=fmin,
+                                            upper_edge_hertz=fmax, device=S.device)
+    out = torch.empty((B, T, int(num_mel_bins)), dtype=torch.float32, device=S.device)
+    if B * T == 0:
+        return out
+    A = nv.Rows(S.data_ptr(), 0, F, 1, B * T)
+    Cd = nv.Rows(out.data_ptr(), 0, int(num_mel_bins), 1, B * T)
+    with torch.cuda.device(S.device):
+        nv.check(nv.lib.lidbox_gemm_nn(A, nv.ptr(W), int(num_mel_bins), Cd, F, int(num_mel_bins), nv.EPI_NONE,
+                                       None, nv.current_stream()))
+    return out
+
+
+def _minmax(x):
+    scratch = torch.empty(2048 + 2, dtype=torch.float32, device=x.device)
+    mm = scratch[2048:]
+    with torch.cuda.device(x.device):
+        nv.check(nv.lib.lidbox_minmax(nv.ptr(x), x.numel(), nv.ptr(mm), nv.ptr(scratch), nv.current_stream()))
+    return mm
+
+
+def log10(x):
+    """reference lidbox/features/audio.py:162-164: ln(x)/ln(10) (plain elementwise; torch holds the tensor)."""
+    return torch.log(x) / math.log(10.0)
+
+
+def power_to_db(S, amin=1e-10, top_db=80.0):
+    """reference lidbox/features/audio.py:167-174 (factor 20, batch-global max)."""
+    S = nv.require_gpu_tensor(S, "S", torch.float32).contiguous()
+    out = torch.empty_like(S)
+    if S.numel() == 0:
+        return out
+    mm = _minmax(S)
+    with torch.cuda.device(S.device):
+        nv.check(nv.lib.lidbox_power_to_db_fwd(nv.ptr(S), S.numel(), nv.ptr(mm), float(amin), float(top_db),
+                                               nv.ptr(out), nv.current_stream()))
+    return out
+
+
+def db_to_power(S):
+    """reference lidbox/features/audio.py:177-181."""
+    return torch.pow(10.0, S / 20.0)
+
+
+def fft_frequencies(sample_rate, n_fft):
+    """reference lidbox/features/audio.py:151-159 (host constant)."""
+    return torch.linspace(0.0, float(int(sample_rate) // 2), 1 + int(n_fft) // 2)

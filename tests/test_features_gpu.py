@@ -1,0 +1,211 @@
+"""
+GPU parity: HIP feature path (through the C ABI) vs the oracle on identical inputs.
+
+Tolerances (fp32 GPU vs float64 oracle), from SURVEY.md section 8(c) / BASELINE.json north_star:
+  log-mel max-abs <= 1e-3 (log domain), MFCC max-abs <= 1e-3, spectrogram/mel relative 2e-5
+  of the per-utterance maximum.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import features_np as fo
+
+pytestmark = pytest.mark.gpu
+
+LOGMEL_TOL = 1e-3
+MFCC_TOL = 1e-3
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from lidbox_amd.testutil import synthetic_batch
+    return synthetic_batch(6, num_labels=4)
+
+
+def test_ms_to_frames_grid():
+    from lidbox_amd.features import audio
+    for sr in range(1000, 60000, 1000):
+        for ms in range(1, 5000, 100):
+            assert audio.ms_to_frames(sr, ms) == (sr // 1000) * ms
+
+
+def test_fused_logmel_matches_oracle(synth):
+    from lidbox_amd.data import tf_utils
+    sig, _ = synth
+    ref = fo.extract_features(sig, [16000] * len(sig), "logmelspectrogram")
+    got = tf_utils.extract_features(_dev(sig), [16000] * len(sig), "logmelspectrogram").cpu().numpy()
+    assert got.shape == ref.shape == (6, 198, 40)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max()
+    assert err <= LOGMEL_TOL, err
+
+
+def test_fused_all_kinds_match_oracle(synth):
+    from lidbox_amd.data import tf_utils
+    sig, _ = synth
+    sr = [16000] * len(sig)
+    x = _dev(sig)
+    for kind, rel in (("spectrogram", 2e-5), ("melspectrogram", 2e-5)):
+        ref = fo.extract_features(sig, sr, kind)
+        got = tf_utils.extract_features(x, sr, kind).cpu().numpy()
+        assert got.shape == ref.shape
+        scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+        assert (np.abs(got - ref) / scale).max() <= rel, kind
+    ref = fo.extract_features(sig, sr, "mfcc")
+    got = tf_utils.extract_features(x, sr, "mfcc").cpu().numpy()
+    assert got.shape == ref.shape == (6, 198, 12)
+    assert np.abs(got - ref).max() <= MFCC_TOL
+    ref = fo.extract_features(sig, sr, "mfcc", mfcc_kwargs=dict(coef_begin=0, coef_end=20),
+                              window_norm_kwargs=dict(window_len=-1, normalize_variance=True))
+    got = tf_utils.extract_features(x, sr, "mfcc", mfcc_kwargs=dict(coef_begin=0, coef_end=20),
+                                    window_norm_kwargs=dict(window_len=-1, normalize_variance=True)).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-3
+
+
+def test_reference_wav_fixtures(wav_paths):
+    """the reference's own 16 kHz fixtures (3 s -> T = 298), log-mel and MFCC+CMVN"""
+    from lidbox_amd.data import tf_utils
+    sigs = np.stack([fo.read_wav_pcm16(p)[0] for p in wav_paths])
+    sr = [16000] * len(sigs)
+    ref = fo.extract_features(sigs, sr, "logmelspectrogram")
+    got = tf_utils.extract_features(_dev(sigs), sr, "logmelspectrogram").cpu().numpy()
+    assert got.shape == (5, 298, 40)
+    assert np.abs(got - ref).max() <= LOGMEL_TOL
+    golden = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "features_wav.npz"))
+    assert np.abs(got - golden["logmel"]).max() <= LOGMEL_TOL
+
+
+def test_ragged_and_edge_shapes():
+    """T not a multiple of 8, a single frame, N < frame_length (T = 0), B = 1, unaligned rows"""
+    from lidbox_amd.data import tf_utils
+    rng = np.random.default_rng(0)
+    for n in (400, 559, 560, 1000, 4001, 16000 + 3):
+        sig = rng.standard_normal((3, n)).astype(np.float32) * 0.1
+        ref = fo.extract_features(sig, [16000] * 3, "logmelspectrogram")
+        got = tf_utils.extract_features(_dev(sig), [16000] * 3, "logmelspectrogram").cpu().numpy()
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= LOGMEL_TOL, n
+    sig = rng.standard_normal((2, 399)).astype(np.float32)
+    assert tf_utils.extract_features(_dev(sig), [16000] * 2, "logmelspectrogram").shape == (2, 0, 40)
+    # strided (non-dense) batch rows exercise sig_stride
+    big = _dev(rng.standard_normal((4, 5000)).astype(np.float32))
+    view = big[:, :4000]
+    ref = fo.extract_features(view.cpu().numpy(), [16000] * 4, "logmelspectrogram")
+    got = tf_utils.extract_features(view, [16000] * 4, "logmelspectrogram").cpu().numpy()
+    assert np.abs(got - ref).max() <= LOGMEL_TOL
+
+
+def test_generic_path_other_fft_lengths(wav_paths):
+    """reference test_spectrograms grid (tests/test_features_audio.py:131-145): shape law + values"""
+    from lidbox_amd.features import audio
+    s, r = fo.read_wav_pcm16(wav_paths[0])
+    s = s[:16000]
+    x = _dev(s[None])
+    for len_ms in (20, 60, 100):
+        for n_fft in (256, 512, 1024, 2048):
+            if n_fft < audio.ms_to_frames(r, len_ms):
+                continue
+            step_ms = len_ms // 2
+            got = audio.spectrograms(x, r, frame_length_ms=len_ms, frame_step_ms=step_ms, fft_length=n_fft)[0]
+            got = got.cpu().numpy()
+            ref = fo.spectrograms(s[None], r, frame_length_ms=len_ms, frame_step_ms=step_ms, fft_length=n_fft)[0]
+            assert not np.isnan(got).any()
+            assert got.shape[0] == s.shape[0] // audio.ms_to_frames(r, step_ms) - 1
+            assert got.shape[1] == n_fft // 2 + 1
+            assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (len_ms, n_fft)
+    # power != 2 and a different sample rate
+    got = audio.spectrograms(x, r, power=1.0).cpu().numpy()
+    ref = fo.spectrograms(s[None], r, power=1.0)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    got = audio.spectrograms(x, 8000).cpu().numpy()
+    ref = fo.spectrograms(s[None], 8000)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_linear_to_mel_standalone(wav_paths):
+    from lidbox_amd.features import audio
+    s, r = fo.read_wav_pcm16(wav_paths[1])
+    P = fo.spectrograms(s[None], r)
+    for m in range(10, 100, 15):
+        got = audio.linear_to_mel(_dev(P.astype(np.float32)), r, num_mel_bins=m).cpu().numpy()
+        ref = fo.linear_to_mel(P, r, num_mel_bins=m)
+        assert got.shape == (1, P.shape[1], m) and not np.isnan(got).any()
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), m
+
+
+def test_pure_tone_peak_bin():
+    from lidbox_amd.features import audio
+    sr, k = 16000, 32
+    n = np.arange(32000)
+    x = np.sin(2 * np.pi * (k * sr / 512) * n / sr).astype(np.float32)[None]
+    P = audio.spectrograms(_dev(x), sr).cpu().numpy()
+    assert P.shape == (1, 198, 257)
+    assert (P[0].argmax(axis=1) == k).all()
+
+
+def test_cmvn_all_axes_and_properties():
+    import lidbox_amd.features as F
+    rng = np.random.default_rng(4)
+    for mag in range(2, 7, 2):
+        for _ in range(5):
+            delta = rng.uniform(1, 10 ** mag)
+            x = rng.uniform(-delta, delta, size=rng.integers(1, 20, size=3)).astype(np.float32)
+            for axis in range(3):
+                ym = F.cmn(_dev(x), axis=axis).cpu().numpy()
+                yv = F.cmvn(_dev(x), axis=axis).cpu().numpy()
+                assert not np.isnan(ym).any() and not np.isnan(yv).any()
+                assert np.abs(ym.mean(axis=axis)).max() < 1
+                assert np.abs(yv.mean(axis=axis)).max() < 0.1 and yv.var(axis=axis).max() < 10
+                ref = fo.cmvn(x, axis=axis)
+                assert np.abs(yv - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    assert (F.cmvn(torch.ones(2, 5, 3, device="cuda")) == 0).all()          # divide_no_nan
+    x = rng.standard_normal((7, 198, 40)).astype(np.float32) * 3 + 1
+    assert np.abs(F.cmvn(_dev(x)).cpu().numpy() - fo.cmvn(x)).max() <= 1e-4
+
+
+def test_window_normalization():
+    import lidbox_amd.features as F
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 50, 12)).astype(np.float32)
+    for w in (-1, 2, 3, 4, 7, 10, 49, 50, 300):
+        for nv_ in (True, False):
+            got = F.window_normalization(_dev(x), window_len=w, normalize_variance=nv_).cpu().numpy()
+            ref = fo.window_normalization(x, window_len=w, normalize_variance=nv_)
+            assert got.shape == x.shape and not np.isnan(got).any()
+            assert np.abs(got - ref).max() <= 1e-4, (w, nv_)
+
+
+def test_feature_scaling_and_power_to_db():
+    import lidbox_amd.features as F
+    from lidbox_amd.features import audio
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 50, size=(4, 30, 17)).astype(np.float32)
+    y = F.feature_scaling(_dev(x), -1.0, 1.0).cpu().numpy()
+    assert abs(y.min() + 1) < 1e-6 and abs(y.max() - 1) < 1e-6
+    assert np.abs(y - fo.feature_scaling(x, -1.0, 1.0)).max() < 1e-5
+    for axis in (0, 1, 2):
+        y = F.feature_scaling(_dev(x), 0.0, 5.0, axis=axis).cpu().numpy()
+        assert np.abs(y.min(axis=axis)).max() < 1e-5 and np.abs(y.max(axis=axis) - 5).max() < 1e-5
+    S = np.abs(rng.standard_normal((2, 20, 33)).astype(np.float32)) ** 2
+    for top_db in (10.0, 80.0):
+        db = audio.power_to_db(_dev(S), top_db=top_db).cpu().numpy()
+        assert db.max() <= 0 and db.min() >= -top_db - 1e-4
+        assert np.abs(db - fo.power_to_db(S, top_db=top_db)).max() < 1e-3
+
+
+def test_errors_raise():
+    from lidbox_amd.data import tf_utils
+    x = torch.zeros(2, 1000, device="cuda")
+    with pytest.raises(ValueError):
+        tf_utils.extract_features(x, [16000, 8000], "spectrogram")
+    with pytest.raises(ValueError):
+        tf_utils.extract_features(x[0], [16000], "spectrogram")
+    with pytest.raises(Exception):
+        tf_utils.extract_features(torch.zeros(2, 1000), [16000, 16000], "spectrogram")    # CPU tensor: no fallback
+    with pytest.raises(FloatingPointError):
+        tf_utils.extract_features(torch.full((1, 1000), float("nan"), device="cuda"), [16000], "spectrogram")
