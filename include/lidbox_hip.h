@@ -224,9 +224,13 @@ int lidbox_cavg_result(const float* tp, const float* fn, const float* fp_pairs, 
                        float* out, lidbox_stream_t stream);
 
 /* tf.keras.optimizers.Adam dense update (keras_utils.py:137-140; epsilon 1e-7):
- * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller; grad_scale multiplies g first. */
-int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr_t,
-                     float beta1, float beta2, float eps, float grad_scale, lidbox_stream_t stream);
+ *   t = ++state[0];  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps)
+ * `state` is a 16-byte device block {int64 step; float lr_t; float pad} owned by the caller and
+ * advanced ON THE DEVICE, so a captured hipGraph replays with the right bias correction.
+ * grad_scale multiplies g first (1/world_size after an all-reduce(sum)). */
+int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
+                     float beta1, float beta2, float eps, float grad_scale, void* state,
+                     lidbox_stream_t stream);
 
 /* fill n floats with value (stream-ordered) */
 int lidbox_fill(float* x, long n, float value, lidbox_stream_t stream);

@@ -275,9 +275,23 @@ __global__ __launch_bounds__(256) void cavg_result_kernel(const float* __restric
     if (threadIdx.x == 0) out[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));   // :103
 }
 
+struct AdamState {
+    long long step;
+    float lr_t;
+    float pad;
+};
+
+// one thread: advance the step and publish the bias-corrected learning rate for this step
+__global__ void adam_prepare_kernel(AdamState* st, float lr, float b1, float b2) {
+    const long long t = ++st->step;
+    const double c = sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+    st->lr_t = (float)((double)lr * c);
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
-                            float gscale) {
+                            float* __restrict__ v, long n, const AdamState* __restrict__ st, float b1,
+                            float b2, float eps, float gscale) {
+    const float lr_t = st->lr_t;
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -442,15 +456,18 @@ extern "C" int lidbox_cavg_result(const float* tp, const float* fn, const float*
     return LIDBOX_OK;
 }
 
-extern "C" int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr_t,
-                                float beta1, float beta2, float eps, float grad_scale,
+extern "C" int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
+                                float beta1, float beta2, float eps, float grad_scale, void* state,
                                 lidbox_stream_t stream) {
-    LBX_ARG(param && grad && m && v && n >= 0, "pointers != NULL");
-    LBX_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
-            "param/grad/m/v must be 16-byte aligned");
+    LBX_ARG(param && grad && m && v && state && n >= 0, "pointers != NULL");
+    LBX_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v | (uintptr_t)state) & 15) == 0,
+            "param/grad/m/v/state must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (AdamState*)state, lr,
+                       beta1, beta2);
+    LBX_LAUNCH_OK();
     if (n == 0) return LIDBOX_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       m, v, n, lr_t, beta1, beta2, eps, grad_scale);
+                       m, v, n, (const AdamState*)state, beta1, beta2, eps, grad_scale);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

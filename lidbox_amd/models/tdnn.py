@@ -1,0 +1,352 @@
+"""
+Sequential TDNN engine: the host-side orchestration shared by `lidbox_amd.models.xvector` and
+`lidbox_amd.models.cnn`.
+
+A model is  Conv1D(causal, strided)+ReLU x n  ->  global pooling over time  ->  Dense x m  ->
+log_softmax -- the structure of reference lidbox/models/xvector.py:46-67 and
+lidbox/models/cnn.py:25-45.  Everything numeric is a liblidbox_hip.so call on preallocated
+device buffers (no allocation, no host sync inside a step), so a whole train step can be
+captured into a hipGraph.
+
+HBM layout
+  * parameters, gradients and Adam moments: ONE flat fp32 buffer each, per-layer views in
+    Keras layouts (Conv1D kernel [k, C_in, C_out], Dense [in, out], bias [C_out]); every view
+    starts on a 16-byte boundary.  The flat gradient buffer is what RCCL all-reduces.
+  * activations: act[i] = [B, pad_i + T_i, C_i], pad_i = (k-1) leading zero rows of the layer
+    that READS it.  A causal window is then k*C_i contiguous floats (row stride s*C_i): Conv1D
+    forward / wgrad are GEMMs over implicit rows and no im2col buffer exists.  Gradient buffers
+    d_act[i] share the layout (the pad rows just absorb unused dgrad output).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .. import _native as nv
+
+
+class ConvSpec:
+    def __init__(self, name, filters, kernel_size, strides, relu=True):
+        self.name, self.filters, self.k, self.s, self.relu = name, int(filters), int(kernel_size), int(strides), relu
+
+
+class DenseSpec:
+    def __init__(self, name, units, relu=True):
+        self.name, self.units, self.relu = name, int(units), relu
+
+
+def conv_out_len(T, s):
+    """Keras Conv1D(padding="causal"): left-pad k-1, VALID, stride s."""
+    return (T - 1) // s + 1 if T > 0 else 0
+
+
+def _align4(n):
+    return (n + 3) & ~3
+
+
+def _rows(t_ptr, batch_stride, row_stride, batch, rpb):
+    return nv.Rows(t_ptr, int(batch_stride), int(row_stride), int(batch), int(rpb))
+
+
+class _Workspace:
+    """All per-(B, T) device buffers of one model."""
+
+    def __init__(self, model, B, T):
+        dev = model.device
+        self.B, self.T = B, T
+        f32 = dict(dtype=torch.float32, device=dev)
+        convs = model.convs
+        self.Ts = [T]
+        for c in convs:
+            self.Ts.append(conv_out_len(self.Ts[-1], c.s))
+        chans = [model.input_dim] + [c.filters for c in convs]
+        self.pads = [c.k - 1 for c in convs] + [0]
+        # activations (zero-initialised once: the pad rows stay zero forever)
+        self.act = [torch.zeros((B, self.pads[i] + self.Ts[i], chans[i]), **f32) for i in range(len(chans))]
+        self.dact = [None] + [torch.zeros_like(a) for a in self.act[1:]]
+        C_last = chans[-1]
+        P = 2 * C_last if model.pool == "stats" else C_last
+        self.pooled = torch.zeros((B, P), **f32)
+        self.dpooled = torch.zeros((B, P), **f32)
+        self.h = [torch.zeros((B, d.units), **f32) for d in model.denses]          # last = logits z
+        self.dh = [torch.zeros((B, d.units), **f32) for d in model.denses]
+        self.logp = torch.zeros((B, model.denses[-1].units), **f32)
+        self.emb = torch.zeros((B, model.denses[0].units), **f32)
+        self.loss = torch.zeros(4, **f32)
+        # GEMM / reduction workspaces sized for the largest layer
+        tn_bytes, cs_bytes = 16, 16
+        cin = model.input_dim
+        for i, c in enumerate(convs):
+            M = B * self.Ts[i + 1]
+            if M > 0:
+                tn_bytes = max(tn_bytes, nv.lib.lidbox_gemm_tn_workspace(M, c.k * cin, c.filters))
+                cs_bytes = max(cs_bytes, nv.lib.lidbox_colsum_workspace(M, c.filters))
+            cin = c.filters
+        din = P
+        for d in model.denses:
+            tn_bytes = max(tn_bytes, nv.lib.lidbox_gemm_tn_workspace(B, din, d.units))
+            cs_bytes = max(cs_bytes, nv.lib.lidbox_colsum_workspace(B, d.units))
+            din = d.units
+        self.tn_ws = torch.empty(tn_bytes, dtype=torch.uint8, device=dev)
+        self.cs_ws = torch.empty(cs_bytes, dtype=torch.uint8, device=dev)
+
+    def input_view(self):
+        """[B, T, C0] view of act[0] behind its causal zero rows."""
+        return self.act[0][:, self.pads[0]:, :]
+
+
+class SequentialTDNN:
+    """convs -> pool -> denses -> log_softmax, parameters in one flat buffer."""
+
+    def __init__(self, input_shape, convs, pool, denses, name="tdnn", output_activation="log_softmax",
+                 channel_dropout_rate=0.0, seed=None, device=None):
+        if not torch.cuda.is_available():
+            raise nv.LidboxHipError("lidbox_amd models need a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.name = name
+        self.input_shape = tuple(input_shape)
+        self.input_dim = int(input_shape[-1])
+        self.convs, self.pool, self.denses = list(convs), pool, list(denses)
+        assert pool in ("stats", "avg")
+        if output_activation not in ("log_softmax", None):
+            raise ValueError("output_activation must be 'log_softmax' or None")
+        self.output_activation = output_activation
+        self.channel_dropout_rate = float(channel_dropout_rate)
+        self.embedding_layer = self.denses[0].name
+        # ---- flat parameter layout
+        self.layout = {}           # name -> (offset, shape)
+        off = 0
+        cin = self.input_dim
+        for c in self.convs:
+            self.layout[c.name + ".W"] = (off, (c.k, cin, c.filters)); off = _align4(off + c.k * cin * c.filters)
+            self.layout[c.name + ".b"] = (off, (c.filters,)); off = _align4(off + c.filters)
+            cin = c.filters
+        din = 2 * cin if pool == "stats" else cin
+        for d in self.denses:
+            self.layout[d.name + ".W"] = (off, (din, d.units)); off = _align4(off + din * d.units)
+            self.layout[d.name + ".b"] = (off, (d.units,)); off = _align4(off + d.units)
+            din = d.units
+        self.num_flat = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self._init_weights(seed)
+        self._ws = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _init_weights(self, seed):
+        """Keras defaults: glorot_uniform kernels, zero biases."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.num_flat, np.float32)
+        for name, (off, shape) in self.layout.items():
+            if name.endswith(".W"):
+                if len(shape) == 3:
+                    k, ci, co = shape
+                    fan_in, fan_out = k * ci, k * co
+                else:
+                    fan_in, fan_out = shape
+                limit = math.sqrt(6.0 / (fan_in + fan_out))
+                n = int(np.prod(shape))
+                host[off:off + n] = rng.uniform(-limit, limit, size=n).astype(np.float32)
+        self.flat.copy_(torch.from_numpy(host))
+
+    def param(self, name, grad=False):
+        off, shape = self.layout[name]
+        buf = self.flat_grad if grad else self.flat
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def named_parameters(self):
+        return [(n, self.param(n)) for n in self.layout]
+
+    def count_params(self):
+        return sum(int(np.prod(s)) for _, s in self.layout.values())
+
+    def get_weights(self):
+        """dict name -> numpy array in Keras layouts."""
+        return {n: self.param(n).detach().cpu().numpy().copy() for n in self.layout}
+
+    def set_weights(self, weights):
+        for n, w in weights.items():
+            self.param(n).copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device))
+
+    def _p(self, name, grad=False):
+        off, _ = self.layout[name]
+        base = (self.flat_grad if grad else self.flat).data_ptr()
+        return ctypes.c_void_p(base + 4 * off)
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B, T):
+        key = (int(B), int(T))
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) >= 4:                     # keep the cache small
+                self._ws.pop(next(iter(self._ws)))
+            ws = _Workspace(self, *key)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def _conv_rows_in(self, ws, i):
+        a = ws.act[i]
+        c = self.convs[i]
+        Tp, C = a.shape[1], a.shape[2]
+        return _rows(a.data_ptr(), Tp * C, c.s * C, ws.B, ws.Ts[i + 1])
+
+    def _rows_out(self, buf, ws, i):
+        """rows of act[i] / dact[i] behind the pad (what the producing layer writes)."""
+        Tp, C = buf.shape[1], buf.shape[2]
+        return _rows(buf.data_ptr() + 4 * ws.pads[i] * C, Tp * C, C, ws.B, ws.Ts[i])
+
+    def forward_ws(self, ws, upto_embedding=False):
+        """act[0] must already hold the input.  Returns logp (or the embedding)."""
+        st = nv.current_stream()
+        lib = nv.lib
+        cin = self.input_dim
+        for i, c in enumerate(self.convs):
+            if ws.B * ws.Ts[i + 1] > 0:
+                nv.check(lib.lidbox_gemm_nn(self._conv_rows_in(ws, i), self._p(c.name + ".W"), c.filters,
+                                            self._rows_out(ws.act[i + 1], ws, i + 1), c.k * cin, c.filters,
+                                            nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"), st))
+            cin = c.filters
+        last = ws.act[-1]
+        T, C = last.shape[1], last.shape[2]
+        fn = lib.lidbox_stats_pool_fwd if self.pool == "stats" else lib.lidbox_avg_pool_fwd
+        nv.check(fn(nv.ptr(last), ws.B, T, C, T * C, C, nv.ptr(ws.pooled), st))
+        x, din = ws.pooled, ws.pooled.shape[1]
+        for j, d in enumerate(self.denses):
+            emb = upto_embedding and j == 0
+            out = ws.emb if emb else ws.h[j]
+            epi = nv.EPI_BIAS_RELU if (d.relu and not emb) else nv.EPI_BIAS
+            nv.check(lib.lidbox_gemm_nn(_rows(x.data_ptr(), 0, din, 1, ws.B), self._p(d.name + ".W"), d.units,
+                                        _rows(out.data_ptr(), 0, d.units, 1, ws.B), din, d.units, epi,
+                                        self._p(d.name + ".b"), st))
+            if emb:
+                return ws.emb
+            x, din = out, d.units
+        if self.output_activation is None:
+            return ws.h[-1]
+        nv.check(lib.lidbox_log_softmax_fwd(nv.ptr(ws.h[-1]), ws.B, din, nv.ptr(ws.logp), st))
+        return ws.logp
+
+    # ------------------------------------------------------------------ backward
+    def backward_ws(self, ws):
+        """dh[-1] must hold d loss / d logits.  Fills flat_grad (overwrites)."""
+        self.backward_head_ws(ws)
+        for i in range(len(self.convs) - 1, -1, -1):
+            self.backward_conv_ws(ws, i)
+
+    def backward_head_ws(self, ws):
+        """dense chain + pooling backward: fills the dense gradients and dact[-1]."""
+        st = nv.current_stream()
+        lib = nv.lib
+        B = ws.B
+        tn_ws, tn_n = nv.ptr(ws.tn_ws), ws.tn_ws.numel()
+        cs_ws, cs_n = nv.ptr(ws.cs_ws), ws.cs_ws.numel()
+        # ---- dense chain
+        for j in range(len(self.denses) - 1, -1, -1):
+            d = self.denses[j]
+            x = ws.pooled if j == 0 else ws.h[j - 1]
+            din = x.shape[1]
+            dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
+            nv.check(lib.lidbox_gemm_tn(_rows(x.data_ptr(), 0, din, 1, B), dy, self._p(d.name + ".W", True),
+                                        d.units, din, d.units, 0, tn_ws, tn_n, st))
+            nv.check(lib.lidbox_colsum(dy, d.units, self._p(d.name + ".b", True), 0, cs_ws, cs_n, st))
+            dst = ws.dpooled if j == 0 else ws.dh[j - 1]
+            relu_prev = j > 0 and self.denses[j - 1].relu
+            nv.check(lib.lidbox_gemm_nt(dy, self._p(d.name + ".W"), d.units,
+                                        _rows(dst.data_ptr(), 0, din, 1, B), d.units, din,
+                                        nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE,
+                                        nv.ptr(x) if relu_prev else None, st))
+        # ---- pooling (fused with the ReLU backward of the last conv)
+        last = ws.act[-1]
+        T, C = last.shape[1], last.shape[2]
+        relu_last = 1 if self.convs[-1].relu else 0
+        if self.pool == "stats":
+            nv.check(lib.lidbox_stats_pool_bwd(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
+                                               relu_last, nv.ptr(ws.dact[-1]), st))
+        else:
+            nv.check(lib.lidbox_avg_pool_bwd(nv.ptr(last), nv.ptr(ws.dpooled), B, T, C, T * C, C, relu_last,
+                                             nv.ptr(ws.dact[-1]), st))
+
+    def backward_conv_ws(self, ws, i):
+        """wgrad / bias grad of conv i and (i > 0) dgrad into dact[i]; dact[i+1] must be final."""
+        st = nv.current_stream()
+        lib = nv.lib
+        B = ws.B
+        tn_ws, tn_n = nv.ptr(ws.tn_ws), ws.tn_ws.numel()
+        cs_ws, cs_n = nv.ptr(ws.cs_ws), ws.cs_ws.numel()
+        c = self.convs[i]
+        cin = self.input_dim if i == 0 else self.convs[i - 1].filters
+        K = c.k * cin
+        To = ws.Ts[i + 1]
+        if B * To == 0:
+            self.param(c.name + ".W", True).zero_()
+            self.param(c.name + ".b", True).zero_()
+            return
+        dy = self._rows_out(ws.dact[i + 1], ws, i + 1)
+        nv.check(lib.lidbox_gemm_tn(self._conv_rows_in(ws, i), dy, self._p(c.name + ".W", True), c.filters,
+                                    K, c.filters, 0, tn_ws, tn_n, st))
+        nv.check(lib.lidbox_colsum(dy, c.filters, self._p(c.name + ".b", True), 0, cs_ws, cs_n, st))
+        if i == 0:
+            return
+        # dgrad into dact[i].  Window t touches padded rows [t*s, t*s+k).  Group g = taps
+        # [g*s, g*s+ntaps) writes rows (t+g)*s + [0, ntaps): disjoint across t, so each group is one
+        # GEMM; group 0 overwrites, later groups accumulate.  Rows no tap produces must read as zero.
+        dprev, aprev = ws.dact[i], ws.act[i]
+        Tp = dprev.shape[1]
+        relu_prev = self.convs[i - 1].relu
+        if c.k < c.s:
+            dprev.zero_()                                   # holes inside every stride period
+        elif To * c.s < Tp:
+            dprev[:, To * c.s:, :].zero_()                  # tail rows beyond group 0's coverage
+        ngroups = (c.k + c.s - 1) // c.s
+        for g in range(ngroups):
+            ntaps = min(c.s, c.k - g * c.s)
+            base_off = 4 * g * c.s * cin                    # bytes
+            Cd = _rows(dprev.data_ptr() + base_off, Tp * cin, c.s * cin, B, To)
+            Wg = ctypes.c_void_p(self._p(c.name + ".W").value + 4 * g * c.s * cin * c.filters)
+            mask = ctypes.c_void_p(aprev.data_ptr() + base_off) if relu_prev else None
+            if g == 0:
+                epi = nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE
+            else:
+                epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
+            nv.check(lib.lidbox_gemm_nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, st))
+
+    # ------------------------------------------------------------------ public call
+    def _load_input(self, ws, x, training):
+        x = nv.require_gpu_tensor(x, "x", torch.float32)
+        if x.dim() != 3 or x.shape[2] != self.input_dim:
+            raise ValueError("expected input [B, T, %d], got %s" % (self.input_dim, tuple(x.shape)))
+        if training and self.channel_dropout_rate > 0:
+            # Keras SpatialDropout1D (xvector.py:50-51): whole channels dropped per utterance
+            keep = 1.0 - self.channel_dropout_rate
+            mask = (torch.rand((x.shape[0], 1, x.shape[2]), device=x.device) < keep).to(x.dtype) / keep
+            x = x * mask
+        ws.input_view().copy_(x)
+
+    def __call__(self, x, training=False):
+        """x [B,T,C] on the HIP device -> log-probs [B, num_outputs] (a fresh tensor)."""
+        with torch.cuda.device(self.device):
+            ws = self.workspace(x.shape[0], x.shape[1])
+            self._load_input(ws, x, training)
+            return self.forward_ws(ws).clone()
+
+    def embed(self, x):
+        """as_embedding_extractor output: first dense layer's affine output (activation removed)."""
+        with torch.cuda.device(self.device):
+            ws = self.workspace(x.shape[0], x.shape[1])
+            self._load_input(ws, x, False)
+            return self.forward_ws(ws, upto_embedding=True).clone()
+
+    predict = __call__
+
+
+class EmbeddingExtractor:
+    """Result of `as_embedding_extractor(model)` (reference xvector.py:70-73 / cnn.py:19-22)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.name = model.name + ":" + model.embedding_layer
+
+    def __call__(self, x, training=False):
+        return self.model.embed(x)

@@ -1,0 +1,54 @@
+"""
+Counterpart of lidbox/models/xvector.py: x-vector TDNN -- five causal strided Conv1D+ReLU frame
+layers, mean+stddev pooling over time, two Dense+ReLU segment layers, Dense, log_softmax
+(reference xvector.py:46-67).  NOTE: the reference passes its third
+`frame_layer` argument to Keras as STRIDES, not dilation, and uses no BatchNorm; this build
+follows the reference.
+"""
+from .tdnn import ConvSpec, DenseSpec, EmbeddingExtractor, SequentialTDNN
+
+TIME_AXIS = 1
+STDDEV_SQRT_MIN_CLIP = 1e-10     # reference xvector.py:22 (applied inside lidbox_stats_pool_fwd)
+
+
+def frame_layer(filters, kernel_size, strides, padding="causal", activation="relu", name="frame"):
+    """reference xvector.py:38-39"""
+    if padding != "causal":
+        raise ValueError("only padding='causal' is supported")
+    if activation not in ("relu", None):
+        raise ValueError("activation must be 'relu' or None")
+    return ConvSpec(name, filters, kernel_size, strides, relu=(activation == "relu"))
+
+
+def segment_layer(units, activation="relu", name="segment"):
+    """reference xvector.py:42-43"""
+    if activation not in ("relu", None):
+        raise ValueError("activation must be 'relu' or None")
+    return DenseSpec(name, units, relu=(activation == "relu"))
+
+
+def create(input_shape, num_outputs, channel_dropout_rate=0, name="x-vector", seed=None, device=None):
+    """reference xvector.py:46-67.  input_shape = (T or None, C); returns a callable model:
+    model(x [B,T,C], training=bool) -> log-probs [B, num_outputs]."""
+    convs = [
+        frame_layer(512, 5, 1, name="frame1"),
+        frame_layer(512, 3, 2, name="frame2"),
+        frame_layer(512, 3, 3, name="frame3"),
+        frame_layer(512, 1, 1, name="frame4"),
+        frame_layer(1500, 1, 1, name="frame5"),
+    ]
+    denses = [
+        segment_layer(512, name="segment1"),
+        segment_layer(512, name="segment2"),
+        DenseSpec("outputs", num_outputs, relu=False),
+    ]
+    return SequentialTDNN(input_shape, convs, "stats", denses, name=name, output_activation="log_softmax",
+                          channel_dropout_rate=channel_dropout_rate, seed=seed, device=device)
+
+
+loader = create      # lidbox/models/keras_utils.py:134 calls `model_module.loader(...)`
+
+
+def as_embedding_extractor(m):
+    """reference xvector.py:70-73: output of `segment1` with its activation removed, [B, 512]."""
+    return EmbeddingExtractor(m)

@@ -1,0 +1,325 @@
+"""
+Train step for the hot path: counterpart of what `KerasWrapper.from_config` + `fit` make Keras do
+per batch (reference lidbox/models/keras_utils.py:124-149, 191-203): forward(training=True) ->
+loss (mean over the batch) -> gradients -> Adam(lr 1e-3, betas 0.9/0.999, epsilon 1e-7) ->
+optional streaming metrics.  Here the step optionally starts from raw waveforms (the fused
+log-mel / MFCC kernel writes straight into the first Conv1D's input buffer) and the whole step
+is captured into hipGraphs.
+
+Data parallelism (new in this build; the reference is single-device): one process per GPU,
+utterances sharded contiguously across ranks, weights replicated, ONE exchange per step: an
+all-reduce(sum) of the flat gradient buffer over RCCL (torch.distributed backend "nccl"),
+then Adam scales by 1/world.  The gradient buffer is reduced in two contiguous buckets; the
+first (everything from the split conv layer upwards) is issued on a side HIP stream as soon
+as its last wgrad has been enqueued and overlaps the remaining backward GEMMs.
+"""
+import os
+
+import torch
+
+from . import _native as nv
+from .losses import SparseAngularProximity
+
+
+# ------------------------------------------------------------------ distributed helpers
+def init_distributed(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, world, local_rank
+
+
+def shard_bounds(global_batch, rank, world):
+    """Contiguous utterance shard [lo, hi) of rank `rank`; remainders go to the first ranks."""
+    q, r = divmod(int(global_batch), int(world))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class GradSync:
+    """Bucketed all-reduce(sum) of one flat gradient tensor.
+
+    `bucket_bounds` are element offsets [0 = b0 < b1 < ... < bn = numel]; bucket i is
+    flat[b_i:b_{i+1}].  Buckets are reduced in the order they are `launch`ed (backward fills the
+    HIGH offsets first).  On HIP the collective runs on `side_stream` after an event recorded on
+    the compute stream, so it overlaps the rest of backward; `wait()` joins.  On CPU (gloo, used
+    by the CPU tests) the same calls run synchronously.
+    """
+
+    def __init__(self, flat, bucket_bounds, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.flat, self.bounds, self.group = flat, list(bucket_bounds), group
+        assert self.bounds[0] == 0 and self.bounds[-1] == flat.numel()
+        assert all(a < b for a, b in zip(self.bounds, self.bounds[1:]))
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.cuda = flat.is_cuda
+        self.side = torch.cuda.Stream(device=flat.device) if (self.cuda and self.active) else None
+        self._pending = []
+
+    @property
+    def num_buckets(self):
+        return len(self.bounds) - 1
+
+    def launch(self, i):
+        """all-reduce bucket i; everything enqueued on the current stream so far is visible to it."""
+        if not self.active:
+            return
+        view = self.flat[self.bounds[i]:self.bounds[i + 1]]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def wait(self):
+        """make the reduced gradients visible to the compute stream"""
+        if self.active and self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    @property
+    def grad_scale(self):
+        """what the optimizer multiplies the summed gradient by (mean over the global batch)"""
+        return 1.0 / self.world
+
+
+def plan_buckets(model, num_buckets=2):
+    """Split the flat gradient into `num_buckets` contiguous buckets at conv-layer boundaries so
+    that the high bucket (reduced first, overlapped with the rest of backward) holds roughly the
+    upper half of the parameters.  Returns (bounds, split_conv_index): bucket 1 is complete once
+    backward_conv_ws(split_conv_index) has been enqueued."""
+    if num_buckets < 2 or len(model.convs) < 2:
+        return [0, model.num_flat], None
+    total = model.num_flat
+    best, best_i = None, None
+    for i in range(1, len(model.convs)):
+        off = model.layout[model.convs[i].name + ".W"][0]
+        score = abs(off - total * 0.25)          # lower layers finish last: keep the tail bucket small
+        if best is None or score < best:
+            best, best_i = score, i
+    return [0, model.layout[model.convs[best_i].name + ".W"][0], total], best_i
+
+
+# ------------------------------------------------------------------ trainer
+class Trainer:
+    """One compiled train step.
+
+    model      : lidbox_amd.models.tdnn.SequentialTDNN (xvector.create / cnn.create)
+    loss       : "sparse_categorical_crossentropy" (Keras SparseCategoricalCrossentropy(from_logits=True)
+                 on the log-softmax outputs, keras_utils.py:141-142) or a SparseAngularProximity
+                 instance (applied to the L2-normalised model output; the model must then end in an
+                 affine layer with output_activation=None)
+    optimizer  : dict(lr, beta_1, beta_2, epsilon) -- tf.keras.optimizers.Adam defaults
+    feature    : None (inputs are features [B,T,C]) or dict(plan=FeaturePlan, kind=nv.FEAT_*)
+                 (inputs are waveforms [B,N]; features are computed inside the step)
+    """
+
+    def __init__(self, model, loss="sparse_categorical_crossentropy", optimizer=None, feature=None,
+                 use_graph=True, num_buckets=2, group=None, metric=None):
+        self.model = model
+        self.device = model.device
+        opt = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
+        opt.update(optimizer or {})
+        self.opt = opt
+        self.feature = feature
+        self.metric = metric
+        if isinstance(loss, SparseAngularProximity):
+            if model.output_activation is not None:
+                raise ValueError("angular proximity loss needs a model without output activation")
+            self.loss_kind, self.ap = "ap", loss
+        elif loss == "sparse_categorical_crossentropy":
+            if model.output_activation != "log_softmax":
+                raise ValueError("sparse_categorical_crossentropy expects log_softmax outputs")
+            self.loss_kind, self.ap = "nll", None
+        else:
+            raise ValueError("unknown loss %r" % (loss,))
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.m = torch.zeros(model.num_flat, **f32)
+        self.v = torch.zeros(model.num_flat, **f32)
+        self.adam_state = torch.zeros(16, dtype=torch.uint8, device=self.device)     # {int64 step, float lr_t}
+        bounds, self.split_conv = plan_buckets(model, num_buckets)
+        self.sync = GradSync(model.flat_grad, bounds, group)
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
+        self._static = {}
+
+    # ---------------------------------------------------------------- pieces of a step
+    def _forward_loss(self, ws, inputs, labels):
+        lib, st = nv.lib, nv.current_stream()
+        model = self.model
+        if self.feature is not None:
+            plan, kind = self.feature["plan"], self.feature["kind"]
+            a0 = ws.act[0]
+            Tp, C = a0.shape[1], a0.shape[2]
+            Bn, N = inputs.shape
+            stride = inputs.stride(0) if Bn > 1 else N
+            if self.feature.get("cmvn"):
+                # MFCC/log-mel -> per-utterance CMVN over time (features/__init__.py:22-32) -> input buffer
+                if not hasattr(ws, "feat_tmp"):
+                    ws.feat_tmp = torch.empty((Bn, ws.T, C), dtype=torch.float32, device=self.device)
+                    ws.feat_norm = torch.empty_like(ws.feat_tmp)
+                nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride,
+                                                         nv.ptr(ws.feat_tmp), 0, None, 0, st))
+                nv.check(lib.lidbox_cmvn_fwd(nv.ptr(ws.feat_tmp), Bn, ws.T, C, 1, nv.ptr(ws.feat_norm), st))
+                ws.input_view().copy_(ws.feat_norm)
+            else:
+                # features land directly behind the causal zero rows of the first Conv1D's input
+                out_ptr = nv.C.c_void_p(a0.data_ptr() + 4 * ws.pads[0] * C)
+                nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride, out_ptr,
+                                                         Tp * C, None, 0, st))
+        else:
+            ws.input_view().copy_(inputs)
+        out = model.forward_ws(ws)
+        B = ws.B
+        if self.loss_kind == "nll":
+            nv.check(lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, out.shape[1], 1.0 / B,
+                                            nv.ptr(ws.loss), nv.ptr(ws.dh[-1]), st))
+        else:
+            D = out.shape[1]
+            zn, dzn, per = self._ap_buffers(ws, D)
+            nv.check(lib.lidbox_l2_normalize_fwd(nv.ptr(out), B, D, nv.ptr(zn), st))
+            nv.check(lib.lidbox_ap_loss_fwd_bwd(nv.ptr(zn), nv.ptr(labels), B, D, self.ap.N, self.ap.delta_weight,
+                                                1.0 / B, nv.ptr(per), nv.ptr(dzn), st))
+            nv.check(lib.lidbox_l2_normalize_bwd(nv.ptr(out), nv.ptr(dzn), B, D, nv.ptr(ws.dh[-1]), st))
+            ws.loss[0:1].copy_(per.mean(dim=0, keepdim=True))
+            if self.metric is not None:
+                self.metric._update_sparse(labels, -torch.acos(zn[:, :self.ap.N]))
+        if self.loss_kind == "nll" and self.metric is not None:
+            self.metric._update_sparse(labels, out)
+
+    def _ap_buffers(self, ws, D):
+        if not hasattr(ws, "ap_zn"):
+            ws.ap_zn = torch.zeros((ws.B, D), dtype=torch.float32, device=self.device)
+            ws.ap_dzn = torch.zeros_like(ws.ap_zn)
+            ws.ap_per = torch.zeros(ws.B, dtype=torch.float32, device=self.device)
+        return ws.ap_zn, ws.ap_dzn, ws.ap_per
+
+    def _backward_hi(self, ws):
+        """backward down to (and including) the split conv layer: bucket 1 is then complete"""
+        self.model.backward_head_ws(ws)
+        lo = self.split_conv if self.split_conv is not None else 0
+        for i in range(len(self.model.convs) - 1, lo - 1, -1):
+            self.model.backward_conv_ws(ws, i)
+
+    def _backward_lo(self, ws):
+        if self.split_conv is None:
+            return
+        for i in range(self.split_conv - 1, -1, -1):
+            self.model.backward_conv_ws(ws, i)
+
+    def _adam(self):
+        o = self.opt
+        m = self.model
+        nv.check(nv.lib.lidbox_adam_step(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v),
+                                         m.num_flat, o["lr"], o["beta_1"], o["beta_2"], o["epsilon"],
+                                         self.sync.grad_scale, nv.ptr(self.adam_state), nv.current_stream()))
+
+    # ---------------------------------------------------------------- graph plumbing
+    def _capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool()):
+            fn()
+        return g
+
+    def _pool(self):
+        if not hasattr(self, "_mempool"):
+            self._mempool = torch.cuda.graph_pool_handle()
+        return self._mempool
+
+    def _build(self, inputs, labels):
+        """warm up eagerly (also validates arguments), then capture the step's graph segments"""
+        B = inputs.shape[0]
+        T = self.feature["plan"].num_frames(inputs.shape[1]) if self.feature is not None else inputs.shape[1]
+        ws = self.model.workspace(B, T)
+        seg_a = lambda: (self._forward_loss(ws, inputs, labels), self._backward_hi(ws))     # noqa: E731
+        seg_b = lambda: self._backward_lo(ws)                                               # noqa: E731
+        seg_c = self._adam
+        entry = dict(ws=ws, inputs=inputs, labels=labels, eager=(seg_a, seg_b, seg_c), graphs=None)
+        if self.use_graph:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                # warm-up on a side stream (required before capture); keeps optimizer state untouched
+                seg_a()
+                seg_b()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            if self.sync.active:
+                entry["graphs"] = (self._capture(seg_a), self._capture(seg_b), self._capture(seg_c))
+            else:
+                entry["graphs"] = (self._capture(lambda: (seg_a(), seg_b(), seg_c())),)
+        return entry
+
+    # ---------------------------------------------------------------- public API
+    def train_step(self, inputs, labels):
+        """One optimisation step on this rank's shard.  inputs: waveforms [B,N] (feature != None) or
+        features [B,T,C]; labels int32 [B].  Both must stay alive and at the same address between
+        calls that reuse the captured graph (pass the same tensors, refilled in place).
+        Returns the device scalar holding this rank's mean loss."""
+        inputs = nv.require_gpu_tensor(inputs, "inputs", torch.float32)
+        labels = nv.require_gpu_tensor(labels, "labels", torch.int32)
+        if labels.dim() != 1 or labels.shape[0] != inputs.shape[0]:
+            raise ValueError("labels must be [batch_size]")
+        key = (inputs.data_ptr(), labels.data_ptr(), tuple(inputs.shape), tuple(inputs.stride()))
+        with torch.cuda.device(self.device):
+            entry = self._graphs.get(key)
+            if entry is None:
+                if len(self._graphs) >= 4:
+                    self._graphs.pop(next(iter(self._graphs)))
+                entry = self._build(inputs, labels)
+                self._graphs[key] = entry
+            ws = entry["ws"]
+            if entry["graphs"] is None:
+                a, b, c = entry["eager"]
+                a()
+                self.sync.launch(self.sync.num_buckets - 1)
+                b()
+                if self.sync.num_buckets > 1:
+                    self.sync.launch(0)
+                self.sync.wait()
+                c()
+            elif len(entry["graphs"]) == 1:
+                entry["graphs"][0].replay()
+            else:
+                ga, gb, gc = entry["graphs"]
+                ga.replay()
+                self.sync.launch(self.sync.num_buckets - 1)
+                gb.replay()
+                if self.sync.num_buckets > 1:
+                    self.sync.launch(0)
+                self.sync.wait()
+                gc.replay()
+            return ws.loss[0]
+
+    def loss_and_grads(self, inputs, labels):
+        """forward + backward only (no all-reduce, no optimizer): returns (loss, flat_grad view)."""
+        inputs = nv.require_gpu_tensor(inputs, "inputs", torch.float32)
+        labels = nv.require_gpu_tensor(labels, "labels", torch.int32)
+        with torch.cuda.device(self.device):
+            B = inputs.shape[0]
+            T = self.feature["plan"].num_frames(inputs.shape[1]) if self.feature is not None else inputs.shape[1]
+            ws = self.model.workspace(B, T)
+            self._forward_loss(ws, inputs, labels)
+            self.model.backward_ws(ws)
+            return ws.loss[0], self.model.flat_grad
+
+    @property
+    def step_count(self):
+        return int(self.adam_state[:8].view(torch.int64).item())

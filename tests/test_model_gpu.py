@@ -1,0 +1,225 @@
+"""
+GPU parity of the x-vector / CNN models, embedding extractor and the train step against the
+oracle and the committed golden vectors.
+
+Tolerances: embedding cosine >= 0.9999, loss rel <= 1e-4, log-prob max-abs 1e-3,
+per-layer gradient rel 1e-3 (fp32 MFMA chains over K up to 50k vs float64).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import features_np as fo
+from oracle import model_np as mo
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dev(x, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype))).cuda()
+
+
+def _cos(a, b):
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def _oracle_params(model):
+    return {k: v.astype(np.float64) for k, v in model.get_weights().items()}
+
+
+def test_xvector_param_count_and_layout():
+    from lidbox_amd.models import xvector
+    m = xvector.create((198, 40), 4, seed=0)
+    assert m.count_params() == 4510176
+    assert xvector.create((198, 40), 100, seed=0).count_params() == 4559424
+    w = m.get_weights()
+    assert w["frame1.W"].shape == (5, 40, 512) and w["frame5.W"].shape == (1, 512, 1500)
+    assert w["segment1.W"].shape == (3000, 512) and w["outputs.W"].shape == (512, 4)
+    # same seed as the oracle initialiser -> identical weights (glorot_uniform, zero bias)
+    p = mo.xvector_init(40, 4, seed=0)
+    for k in p:
+        assert np.array_equal(w[k], p[k]), k
+
+
+def test_xvector_forward_matches_golden_and_oracle():
+    from lidbox_amd.models import xvector
+    g = np.load(os.path.join(GOLDEN, "xvector_synth.npz"))
+    m = xvector.create((198, 40), 4, seed=0)
+    x = _dev(g["logmel"])
+    logp = m(x, training=False).cpu().numpy()
+    assert logp.shape == (4, 4)
+    assert np.abs(logp - g["logp"]).max() < 1e-3
+    emb = xvector.as_embedding_extractor(m)(x).cpu().numpy()
+    assert emb.shape == (4, 512)
+    assert _cos(emb, g["embedding"]).min() >= 0.9999
+    assert np.abs(m(x, training=True).cpu().numpy() - logp).max() == 0     # no dropout -> same path
+
+
+def test_waveform_to_embedding_end_to_end():
+    """waveform -> fused log-mel kernel -> x-vector, vs the float64 oracle chain"""
+    from lidbox_amd.data import tf_utils
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    sig, y = synthetic_batch(4, num_labels=4)
+    g = np.load(os.path.join(GOLDEN, "xvector_synth.npz"))
+    assert np.array_equal(y, g["labels"])
+    feats = tf_utils.extract_features(_dev(sig), [16000] * 4, "logmelspectrogram")
+    assert np.abs(feats.cpu().numpy() - g["logmel"]).max() <= 1e-3
+    m = xvector.create((198, 40), 4, seed=0)
+    emb = xvector.as_embedding_extractor(m)(feats).cpu().numpy()
+    assert _cos(emb, g["embedding"]).min() >= 0.9999
+
+
+def test_xvector_loss_and_gradients_match_oracle():
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer
+    g = np.load(os.path.join(GOLDEN, "xvector_synth.npz"))
+    m = xvector.create((198, 40), 4, seed=0)
+    # non-zero biases so every bias path carries signal
+    rng = np.random.default_rng(3)
+    m.set_weights({k: rng.standard_normal(v.shape) * 0.05 for k, v in m.get_weights().items() if k.endswith(".b")})
+    tr = Trainer(m, use_graph=False)
+    x, y = g["logmel"], g["labels"]
+    loss, grads = tr.loss_and_grads(_dev(x), _dev(y, np.int32))
+    ref_loss, ref_g, _ = mo.xvector_loss_and_grads(_oracle_params(m), x.astype(np.float64), y)
+    assert abs(float(loss) - ref_loss) <= 1e-4 * abs(ref_loss)
+    for name in ref_g:
+        got = m.param(name, grad=True).cpu().numpy()
+        scale = np.abs(ref_g[name]).max()
+        assert np.abs(got - ref_g[name]).max() <= 1e-3 * scale, name
+    # golden first-step loss and gradient norms (regression pin; zero-bias weights as in make_golden.py)
+    m0 = xvector.create((198, 40), 4, seed=0)
+    loss0, _ = Trainer(m0, use_graph=False).loss_and_grads(_dev(x), _dev(y, np.int32))
+    assert abs(float(loss0) - float(g["loss"])) <= 1e-4 * float(g["loss"])
+    for name, norm in zip(g["grad_names"], g["grad_norms"]):
+        got = float(m0.param(str(name), grad=True).norm())
+        assert abs(got - norm) <= 1e-3 * max(norm, 1e-6), name
+
+
+def test_train_steps_match_oracle_adam_and_graph_equals_eager():
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((6, 50, 24)).astype(np.float32)
+    y = rng.integers(0, 5, size=6).astype(np.int32)
+    xd, yd = _dev(x), _dev(y, np.int32)
+    m_e = xvector.create((50, 24), 5, seed=7)
+    m_g = xvector.create((50, 24), 5, seed=7)
+    p = _oracle_params(m_e)
+    am = {k: np.zeros_like(v) for k, v in p.items()}
+    av = {k: np.zeros_like(v) for k, v in p.items()}
+    t_e, t_g = Trainer(m_e, use_graph=False), Trainer(m_g, use_graph=True)
+    for step in range(1, 4):
+        le = float(t_e.train_step(xd, yd))
+        lg = float(t_g.train_step(xd, yd))
+        lo, go, _ = mo.xvector_loss_and_grads(p, x.astype(np.float64), y)
+        mo.adam_step(p, go, am, av, step)
+        assert abs(le - lo) <= 2e-4 * abs(lo), (step, le, lo)
+        assert le == lg, (step, le, lg)                       # graph replay == eager, bit for bit
+    assert torch.equal(m_e.flat, m_g.flat)
+    assert t_e.step_count == 3 and t_g.step_count == 3
+    for k, v in m_e.get_weights().items():
+        # Adam normalises the update, so after 3 steps weights moved ~3e-3; compare the movement
+        assert np.abs(v - p[k]).max() <= 3e-4, k
+    # the loss goes down on a fixed batch
+    l0 = float(t_e.train_step(xd, yd))
+    for _ in range(10):
+        l1 = float(t_e.train_step(xd, yd))
+    assert l1 < l0
+
+
+def test_train_step_from_waveforms_writes_features_in_place():
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    sig, y = synthetic_batch(8, num_labels=4)
+    m1, m2 = xvector.create((198, 40), 4, seed=0), xvector.create((198, 40), 4, seed=0)
+    plan = audio.get_plan(16000, 400, 160)
+    t1 = Trainer(m1, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=True)
+    t2 = Trainer(m2, use_graph=False)
+    sd, yd = _dev(sig), _dev(y, np.int32)
+    feats = plan.run(nv.FEAT_LOGMEL, sd)
+    for _ in range(2):
+        a = float(t1.train_step(sd, yd))
+        b = float(t2.train_step(feats, yd))
+        assert a == b
+    assert torch.equal(m1.flat, m2.flat)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 7), (2, 5, 40), (4, 50, 13), (10, 400, 100), (2, 198, 40)])
+def test_models_valid_output_any_shape(shape):
+    """reference tests/test_models.py:30-35,65-68,104-107: [B,num_outputs], no NaN, training in {F,T}"""
+    from lidbox_amd.models import cnn, xvector
+    rng = np.random.default_rng(8)
+    x = _dev(rng.uniform(-1e3, 1e3, size=shape))
+    for module in (xvector, cnn):
+        for n_out in (1, 100):
+            m = module.create(shape[1:], n_out, seed=1)
+            for t in (False, True):
+                yv = m(x, training=t).cpu().numpy()
+                assert yv.shape == (shape[0], n_out) and not np.isnan(yv).any()
+    m = xvector.create(shape[1:], 3, channel_dropout_rate=0.5, seed=1)
+    assert not torch.isnan(m(x, training=True)).any()
+
+
+def test_cnn_matches_oracle_forward_and_backward():
+    from lidbox_amd.models import cnn
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((3, 61, 12))
+    y = rng.integers(0, 4, size=3).astype(np.int32)
+    m = cnn.create((61, 12), 4, seed=2)
+    p = _oracle_params(m)
+    ref = mo.cnn_fwd(p, x)
+    got = m(_dev(x)).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-3
+    emb = cnn.as_embedding_extractor(m)(_dev(x)).cpu().numpy()
+    assert _cos(emb, mo.cnn_fwd(p, x, embedding=True)).min() >= 0.9999
+    # gradients vs torch autograd on the CPU restatement
+    from oracle import torch_ref as tr
+    pt = tr.to_torch_params(p, True, torch.float64)
+    tr.sparse_ce_from_logits(tr.cnn_fwd(pt, torch.tensor(x)), torch.tensor(y.astype(np.int64))).backward()
+    loss, _ = Trainer(m, use_graph=False).loss_and_grads(_dev(x), _dev(y, np.int32))
+    for k in p:
+        ref_g = pt[k].grad.numpy()
+        got_g = m.param(k, grad=True).cpu().numpy()
+        assert np.abs(got_g - ref_g).max() <= 1e-3 * max(1e-12, np.abs(ref_g).max()), k
+
+
+def test_angular_proximity_head_train_step():
+    """config 5 head: trunk -> segment1 (affine) -> L2 normalise -> SparseAngularProximity + C_avg"""
+    from lidbox_amd.losses import SparseAngularProximity
+    from lidbox_amd.metrics import SparseAverageDetectionCost
+    from lidbox_amd.models import xvector
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    from lidbox_amd.train import Trainer
+    from oracle import torch_ref as tr
+    rng = np.random.default_rng(10)
+    B, T, C, N, D = 8, 40, 16, 5, 32
+    x = rng.standard_normal((B, T, C))
+    y = rng.integers(0, N, size=B).astype(np.int32)
+    convs = [xvector.frame_layer(32, 5, 1, name="frame1"), xvector.frame_layer(32, 3, 2, name="frame2")]
+    m = SequentialTDNN((T, C), convs, "stats", [DenseSpec("segment1", D, relu=False)], output_activation=None, seed=3)
+    metric = SparseAverageDetectionCost(N, np.linspace(-np.pi, 0, 20))
+    t = Trainer(m, loss=SparseAngularProximity(N, D), use_graph=False, metric=metric)
+    loss, _ = t.loss_and_grads(_dev(x), _dev(y, np.int32))
+    # torch autograd reference of the same head
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in m.get_weights().items()}
+    h = torch.tensor(x)
+    h = tr.conv1d_causal(h, p["frame1.W"], p["frame1.b"], 1)
+    h = tr.conv1d_causal(h, p["frame2.W"], p["frame2.b"], 2)
+    z = tr.stats_pool(h) @ p["segment1.W"] + p["segment1.b"]
+    zn = torch.nn.functional.normalize(z, dim=1)
+    ref = tr.ap_loss(torch.tensor(y.astype(np.int64)), zn, N)
+    ref.backward()
+    assert abs(float(loss) - float(ref.detach())) < 1e-5
+    for k in p:
+        rg = p[k].grad.numpy()
+        assert np.abs(m.param(k, grad=True).cpu().numpy() - rg).max() <= 2e-3 * np.abs(rg).max(), k
+    l0 = float(t.train_step(_dev(x), _dev(y, np.int32)))
+    assert np.isfinite(l0) and 0.0 <= float(metric.result()) <= 1.0
