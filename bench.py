@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""
+bench.py -- utterances/s of the log-mel + x-vector train step on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] per GPU: 256 synthetic 16 kHz x 2 s utterances, 4 languages,
+fp32: waveform -> fused log-mel kernel -> x-vector forward -> sparse CE -> backward -> Keras-Adam.
+N > 1 is weak scaling (256 utterances per GPU, configs[2] at N = 8): one all-reduce(sum) of the
+18 MB flat gradient per step over RCCL, two buckets, the first overlapped with backward.
+
+A "step" is one full pass of the hot path over one batch resident in HBM (inputs are uploaded
+before the timed region).  Timed region: barrier + synchronize, K graph-replayed steps,
+synchronize + barrier; max over ranks.  One JSON line is printed by rank 0.
+
+Extra measurements in the same process (rank 0):
+  roofline          fp32-MFMA roofline of the dominant GEMM kernel family: algorithmic flops of
+                    its launches / HIP-event time of those launches, from an instrumented eager
+                    pass over the same steps (events cannot be placed inside a graph replay).
+  roofline_feature  HBM roofline of the fused log-mel kernel (159 680 algorithmic bytes/utterance).
+  cpu_baseline      oracle/torch_ref.py (the CPU restatement; TensorFlow cannot run here) timed on
+                    the host cores on a bounded sample of the same workload -- N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 256
+NUM_LANGS = 4
+SAMPLE_RATE, DURATION_S = 16000, 2.0
+BYTES_PER_UTT_FEATURE = 32000 * 4 + 198 * 40 * 4           # 159 680 B
+FLOPS_PER_UTT_TRAIN = 918.7e6
+PEAK_FP32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """Brackets every launch of the GEMM family and of the feature kernel with HIP events on the
+    stream they are launched on (torch's current stream) during an instrumented eager pass."""
+
+    FAMILIES = {
+        "lidbox_gemm_nn": "gemm_rows_kernel<NN>",
+        "lidbox_gemm_nt": "gemm_rows_kernel<NT>",
+        "lidbox_gemm_tn": "gemm_tn_kernel",
+        "lidbox_extract_features_fwd": "fused_feat512_kernel",
+    }
+
+    def __init__(self, nv):
+        self.nv = nv
+        self.records = {k: [] for k in self.FAMILIES}
+        self._orig = {}
+
+    def _work(self, name, args):
+        if name in ("lidbox_gemm_nn", "lidbox_gemm_nt"):
+            A, K, N = args[0], args[4], args[5]
+            return 2.0 * A.batch * A.rows_per_batch * K * N
+        if name == "lidbox_gemm_tn":
+            A, K1, N = args[0], args[4], args[5]
+            return 2.0 * A.batch * A.rows_per_batch * K1 * N
+        return float(args[3]) * BYTES_PER_UTT_FEATURE            # feature kernel: algorithmic bytes
+
+    def __enter__(self):
+        for name in self.FAMILIES:
+            orig = getattr(self.nv.lib, name)
+            self._orig[name] = orig
+
+            def wrapper(*args, _n=name, _o=orig):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _o(*args)
+                e1.record()
+                self.records[_n].append((e0, e1, self._work(_n, args)))
+                return rc
+            setattr(self.nv.lib, name, wrapper)
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self._orig.items():
+            setattr(self.nv.lib, name, orig)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            if not recs:
+                continue
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+            work = sum(w for _, _, w in recs)
+            out[self.FAMILIES[name]] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs),
+                                            work_per_launch=work / len(recs), rate=work / (ms * 1e-3))
+        return out
+
+
+def cpu_baseline(seconds, batch=32):
+    """oracle/torch_ref.py train step on the host cores, bounded sample."""
+    from oracle.torch_ref import TrainStepCPU
+    from lidbox_amd.testutil import synthetic_batch
+    threads = os.cpu_count() or 1
+    step = TrainStepCPU(num_outputs=NUM_LANGS, seed=0, threads=threads)
+    sig, y = synthetic_batch(batch, NUM_LANGS, SAMPLE_RATE, DURATION_S)
+    sig_t, y_t = torch.from_numpy(sig), torch.from_numpy(y.astype(np.int64))
+    step.step(sig_t, y_t)                                            # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step.step(sig_t, y_t)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return dict(value=round(n * batch / dt, 2), unit="utterances/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d train steps of %d utterances (log-mel + x-vector fwd/bwd + Adam, fp32, torch-CPU "
+                       "restatement oracle/torch_ref.py; TensorFlow unavailable) in %.1f s" % (n, batch, dt))
+
+
+def main():
+    args = parse_args()
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer, init_distributed, shard_bounds
+    import torch.distributed as dist
+
+    rank, world, local_rank = init_distributed()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # ---- synthetic global batch (SURVEY 8d recipe), this rank's contiguous shard resident in HBM
+    B = args.batch
+    global_B = B * world
+    sig, labels = synthetic_batch(global_B, NUM_LANGS, SAMPLE_RATE, DURATION_S, seed=1234)
+    lo, hi = shard_bounds(global_B, rank, world)
+    sig_d = torch.from_numpy(sig[lo:hi]).to(dev)
+    lab_d = torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)
+    del sig
+
+    model = xvector.create((198, 40), NUM_LANGS, seed=0, device=dev)
+    plan = audio.get_plan(SAMPLE_RATE, 400, 160, device=dev)
+    trainer = Trainer(model, loss="sparse_categorical_crossentropy", feature=dict(plan=plan, kind=nv.FEAT_LOGMEL),
+                      use_graph=not args.no_graph)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.train_step(sig_d, lab_d)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(sig_d, lab_d)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+    if not np.isfinite(final_loss):
+        raise SystemExit("non-finite loss %r" % final_loss)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = global_B * args.steps / elapsed
+
+    result = {
+        "metric": "utterances/sec (16kHz x 2s) log-mel + x-vector train step",
+        "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "log-mel + x-vector 4-lang train step, bs=%d per GPU, fp32 (BASELINE configs[%d])"
+                               % (B, 1 if world == 1 else 2),
+                   "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
+                   "languages": NUM_LANGS, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world,
+                   "hip_graph": not args.no_graph, "final_loss": round(final_loss, 6)},
+    }
+
+    if rank == 0:
+        # ---- per-kernel HIP-event timing: instrumented eager pass over the same steps
+        if not args.no_kernel_timing and world == 1:
+            eager = Trainer(model, loss="sparse_categorical_crossentropy",
+                            feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=False)
+            eager.m, eager.v, eager.adam_state = trainer.m, trainer.v, trainer.adam_state
+            eager.train_step(sig_d, lab_d)
+            torch.cuda.synchronize()
+            nsteps = min(args.steps, 10)
+            with KernelTimer(nv) as kt:
+                for _ in range(nsteps):
+                    eager.train_step(sig_d, lab_d)
+                ks = kt.summary()
+            gemms = {k: v for k, v in ks.items() if k != "fused_feat512_kernel"}
+            dom = max(gemms, key=lambda k: gemms[k]["total_ms"])
+            d = gemms[dom]
+            ach = d["rate"] / 1e12
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
+                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                  "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
+                                  "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3)}
+            gemm_ms = sum(v["total_ms"] for v in gemms.values()) / nsteps
+            gemm_flops = sum(v["rate"] * v["total_ms"] * 1e-3 for v in gemms.values()) / nsteps
+            result["kernels"] = {k: {"launches_per_step": v["launches"] // nsteps, "ms_per_step": round(v["total_ms"] / nsteps, 4),
+                                     "rate": round(v["rate"] / (1e9 if k == "fused_feat512_kernel" else 1e12), 2),
+                                     "rate_unit": "GB/s" if k == "fused_feat512_kernel" else "TFLOP/s"}
+                                 for k, v in ks.items()}
+            result["kernels"]["all_gemm"] = {"ms_per_step": round(gemm_ms, 4),
+                                             "rate": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "rate_unit": "TFLOP/s"}
+            f = ks.get("fused_feat512_kernel")
+            if f:
+                gbs = f["rate"] / 1e9
+                result["roofline_feature"] = {"kernel": "fused_feat512_kernel", "bound": "hbm", "achieved": round(gbs, 1),
+                                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                              "traffic": None, "avg_launch_us": round(f["avg_us"], 2),
+                                              "bytes_per_launch": int(f["work_per_launch"])}
+        # whole-step view of the same roofline: algorithmic train flops / step time
+        result["step_tflops"] = round(value / world * FLOPS_PER_UTT_TRAIN / 1e12, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

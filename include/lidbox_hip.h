@@ -153,23 +153,34 @@ enum {
     LIDBOX_EPI_ACCUM_RELU_MASK = 5 /* C += . * (mask > 0)                                          */
 };
 
+/* Split-K workspace (bytes) that lets lidbox_gemm_nn / _nt fill the chip when M*N is small
+ * (Dense layers at M = batch): partial sums are reduced in a fixed order with the epilogue
+ * fused into the reduce.  0 = not needed.  Passing NULL/0 is always legal (no split). */
+size_t lidbox_gemm_rows_workspace(long M, int N, int K);
+
 /* C[M,N] = epi( A[M,K] . B )  -- forward of Conv1D/Dense (a12/a14), linear_to_mel (a4).
  * A: implicit rows (K contiguous).  B: [K,N] row-major, ldb (Keras kernel layout [k*C_in, C_out]).
  * C: implicit rows (N contiguous).  aux: bias[N] or mask (layout of C) or NULL. */
 int lidbox_gemm_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C,
-                   int K, int N, int epilogue, const float* aux, lidbox_stream_t stream);
+                   int K, int N, int epilogue, const float* aux,
+                   void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
 
-/* C[M,N] = epi( A[M,K] . B^T )  -- dgrad: dX_rows = dY . W^T with B = W[N_out=N rows.. ] i.e.
- * B is [N,K] row-major (ldb): C[m,n] = sum_k A[m,k]*B[n,k]. */
+/* C[M,N] = epi( A[M,K] . B^T ), B is [N,K] row-major (ldb): C[m,n] = sum_k A[m,k]*B[n,k].
+ * dgrad of Conv1D/Dense: A = dY rows, B = W rows (Keras kernel [k*C_in, C_out] is exactly
+ * [N = k*C_in][K = C_out]), C = dX rows. */
 int lidbox_gemm_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C,
-                   int K, int N, int epilogue, const float* aux, lidbox_stream_t stream);
+                   int K, int N, int epilogue, const float* aux,
+                   void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
 
 /* C[K1,N] (ldc) = A[M,K1]^T . B[M,N]   -- wgrad: dW = col^T . dY, contraction over the M rows.
- * Split over M into `splits` partial sums reduced deterministically through `workspace`
- * (>= lidbox_gemm_tn_workspace() bytes).  accumulate != 0: C += result. */
+ * Split over M into partial sums reduced deterministically through `workspace`
+ * (>= lidbox_gemm_tn_workspace() bytes).  accumulate != 0: C += result.
+ * bias_grad (may be NULL): [N], receives the column sums of B (db = sum_m dY[m,:]) computed
+ * from the B tiles the kernel already holds in LDS (same accumulate flag). */
 size_t lidbox_gemm_tn_workspace(int M, int K1, int N);
 int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1, int N,
-                   int accumulate, void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+                   int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
+                   lidbox_stream_t stream);
 
 /* out[n] (+)= sum_m rows[m, n]  -- bias gradient; deterministic two-stage reduction through
  * `workspace` (>= lidbox_colsum_workspace() bytes). */

@@ -7,6 +7,10 @@ If the .so is missing or does not load, importing this module raises.
 import ctypes as C
 import os
 
+# torch first: it ships its own libamdhip64.so.7; loading ours before it would put a second HIP
+# runtime in the process (and hipGetDevice in that copy then reports "no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblidbox_hip.so")
 
@@ -60,10 +64,11 @@ _SIGS = {
     "lidbox_minmax": (_i, [_vp, _l, _vp, _vp, _vp]),
     "lidbox_feature_scaling_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
     "lidbox_power_to_db_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
-    "lidbox_gemm_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp]),
-    "lidbox_gemm_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp]),
+    "lidbox_gemm_rows_workspace": (_sz, [_l, _i, _i]),
+    "lidbox_gemm_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_tn_workspace": (_sz, [_i, _i, _i]),
-    "lidbox_gemm_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
+    "lidbox_gemm_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_colsum_workspace": (_sz, [_l, _i]),
     "lidbox_colsum": (_i, [Rows, _i, _vp, _i, _vp, _sz, _vp]),
     "lidbox_stats_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),

@@ -12,27 +12,35 @@
 //     is then a contiguous run of k*C floats, so Conv1D is a GEMM whose A rows are addressed
 //     as base + b*batch_stride + t*row_stride (lidbox_rows_t) -- no im2col buffer, no bounds
 //     logic in the inner loop.  Strided layers simply use row_stride = s*C.
-//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD): 128x128 block tile, 4 waves as
-//     2x2, each wave 64x64 = 2x2 MFMA blocks (64 accumulator VGPRs).
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Block tile BM x BN in
+//     {128,64}^2, 4 waves as 2x2, each wave (BM/2)x(BN/2) = up to 2x2 MFMA blocks.
 //   * LDS tiles are K-outer ([k][row]) for both operands so every MFMA operand fetch is one
 //     conflict-free ds_read_b32 of 32 consecutive floats per half-wave.  Operands whose
 //     contraction index is contiguous in HBM (A of NN/NT, B of NT) are transposed on the way
-//     in (row stride = 128 + 8/(BK/4) keeps those scattered ds_write_b32 conflict-free);
-//     the others are copied with ds_write_b128.
+//     in (row stride = rows + 2 keeps those scattered ds_write_b32 conflict-free); the others
+//     are copied with ds_write_b128.
 //   * global -> register prefetch of tile t+1 is issued before the MFMAs of tile t and
-//     written to the other LDS buffer afterwards: one barrier per K step.
+//     written to the other LDS buffer afterwards: one barrier per K step; 33 KB LDS per
+//     workgroup keeps 4 workgroups per CU resident to cover each other's barriers.
+//   * Work decomposition is chosen per launch by a small cost model (choose_rows / tn_plan):
+//     the chip has 256 CUs and an fp32 MFMA tile is long, so tile COUNT quantisation is the
+//     first-order effect (264 tiles of 128x128 run at 52 %).  Small-M problems (Dense layers,
+//     M = 256) are split along K into partial sums that a reduce kernel sums in a fixed
+//     order and finishes with the fused epilogue (deterministic; no float atomics).
 //   * block id -> tile uses the XCD-chunk remap so the n-tiles that share an A row panel run
 //     on one XCD's L2; the weight matrix (<= 3 MB) is L2-resident everywhere.
-//   * wgrad contracts over M = B*T (up to 50 688): split across workgroups into partial sums in
-//     a workspace and reduced in a fixed order (deterministic; no float atomics).
+//   * wgrad contracts over M = B*T (up to 50 688): always split; the bias gradient (column
+//     sums of dY) is accumulated from the dY tiles already in LDS by the k1-tile-0 workgroups.
 // Roofline: MFMA fp32, 157.3 TFLOP/s.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128;
+constexpr int BK = 16;
 
 struct RowsD {
     const float* base;
@@ -40,194 +48,249 @@ struct RowsD {
     int batch, rpb;
 };
 
-__device__ __forceinline__ long row_offset(const RowsD& r, long m) {
-    if (r.batch == 1) return m * r.rs;
-    const long b = m / r.rpb;
-    return b * r.bs + (m - b * r.rpb) * r.rs;
-}
-
-template <int BK>
-struct Cfg {
-    static constexpr int F4_PER_ROW = BK / 4;                 // K-inner operand: float4 per tile row
-    static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
-    static constexpr int KI_PASSES = 128 / ROWS_PER_PASS;
-    static constexpr int LDT = 128 + 8 / F4_PER_ROW;          // transposed-store row stride (floats)
-    static constexpr int KO_PASSES = BK / 8;                  // K-outer operand: 8 k-rows per pass
-    static constexpr int LDD = 128;                           // direct-copy row stride
-    static constexpr int TILE_FLOATS = BK * LDT;              // per operand per buffer (max of both)
-};
-
-// ---- K-inner operand (contraction index contiguous in HBM): rows r0+p*ROWS_PER_PASS, float4 c4
-template <int BK, bool ALIGNED>
-struct KInnerLoader {
-    using C = Cfg<BK>;
-    float4 v[C::KI_PASSES];
-    long off[C::KI_PASSES];
-    bool rok[C::KI_PASSES];
-    int c4, r0;
-
-    __device__ __forceinline__ void init(const RowsD& rows, long row_base, long nrows, int tid) {
-        c4 = tid % C::F4_PER_ROW;
-        r0 = tid / C::F4_PER_ROW;
-#pragma unroll
-        for (int p = 0; p < C::KI_PASSES; ++p) {
-            const long r = row_base + r0 + p * C::ROWS_PER_PASS;
-            rok[p] = r < nrows;
-            off[p] = rok[p] ? row_offset(rows, r) : 0;
-        }
-    }
-    __device__ __forceinline__ void load(const float* base, int k0, int K) {
-        const int k = k0 + c4 * 4;
-#pragma unroll
-        for (int p = 0; p < C::KI_PASSES; ++p) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rok[p]) {
-                const float* src = base + off[p] + k;
-                if (ALIGNED) {
-                    if (k < K) x = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (k + 0 < K) x.x = src[0];
-                    if (k + 1 < K) x.y = src[1];
-                    if (k + 2 < K) x.z = src[2];
-                    if (k + 3 < K) x.w = src[3];
-                }
-            }
-            v[p] = x;
-        }
-    }
-    __device__ __forceinline__ void store(float* tile) const {
-#pragma unroll
-        for (int p = 0; p < C::KI_PASSES; ++p) {
-            float* d = tile + (c4 * 4) * C::LDT + r0 + p * C::ROWS_PER_PASS;
-            d[0 * C::LDT] = v[p].x;
-            d[1 * C::LDT] = v[p].y;
-            d[2 * C::LDT] = v[p].z;
-            d[3 * C::LDT] = v[p].w;
-        }
-    }
-};
-
-// ---- K-outer operand, plain matrix [Kdim][ld] (weights in NN): k-rows kk0+8p, float4 column c4
-template <int BK, bool ALIGNED>
-struct KOuterLoader {
-    using C = Cfg<BK>;
-    float4 v[C::KO_PASSES];
-    int c4, kk0;
-
-    __device__ __forceinline__ void init(int tid) {
-        c4 = tid & 31;
-        kk0 = tid >> 5;
-    }
-    // generic: per-k-row offsets supplied by the caller through a functor
-    template <typename RowOff>
-    __device__ __forceinline__ void load(const float* base, RowOff row_off, long k0, long Kdim, long col0,
-                                         long ncols) {
-        const long c = col0 + c4 * 4;
-#pragma unroll
-        for (int p = 0; p < C::KO_PASSES; ++p) {
-            const long k = k0 + kk0 + 8 * p;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < Kdim) {
-                const float* src = base + row_off(k) + c;
-                if (ALIGNED) {
-                    if (c < ncols) x = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (c + 0 < ncols) x.x = src[0];
-                    if (c + 1 < ncols) x.y = src[1];
-                    if (c + 2 < ncols) x.z = src[2];
-                    if (c + 3 < ncols) x.w = src[3];
-                }
-            }
-            v[p] = x;
-        }
-    }
-    __device__ __forceinline__ void store(float* tile) const {
-#pragma unroll
-        for (int p = 0; p < C::KO_PASSES; ++p)
-            *reinterpret_cast<float4*>(tile + (kk0 + 8 * p) * C::LDD + c4 * 4) = v[p];
-    }
-};
-
-// 64x64 per wave: 2x2 blocks of v_mfma_f32_32x32x2_f32 over one BK-deep LDS tile pair
-template <int BK, int LDA, int LDB>
-__device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int wm, int wn, int lane,
-                                         f32x16 (&acc)[2][2]) {
-    const int h = lane >> 5, l = lane & 31;
-    const float* ap = As + h * LDA + wm * 64 + l;
-    const float* bp = Bs + h * LDB + wn * 64 + l;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-        const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
-        const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-}
-
 struct RowsOutD {
     float* base;
     long bs, rs;
     int batch, rpb;
 };
 
+// m < 2^31 always (checked on the host): 32-bit unsigned division
+__device__ __forceinline__ long row_offset(const RowsD& r, unsigned m) {
+    if (r.batch == 1) return (long)m * r.rs;
+    const unsigned b = m / (unsigned)r.rpb;
+    return (long)b * r.bs + (long)(m - b * (unsigned)r.rpb) * r.rs;
+}
+__device__ __forceinline__ long row_offset(const RowsOutD& r, unsigned m) {
+    if (r.batch == 1) return (long)m * r.rs;
+    const unsigned b = m / (unsigned)r.rpb;
+    return (long)b * r.bs + (long)(m - b * (unsigned)r.rpb) * r.rs;
+}
+
+// ---- K-inner operand (contraction index contiguous in HBM): ROWS x BK tile, transposed into
+//      LDS [BK][ROWS + 2].  Each thread keeps one source pointer per pass and bumps it by BK.
+template <int ROWS, bool ALIGNED>
+struct KInnerLoader {
+    static constexpr int PASSES = ROWS / 64;          // 256 threads = 64 rows x 4 float4
+    static constexpr int LD = ROWS + 2;
+    float4 v[PASSES];
+    const float* ptr[PASSES];                         // nullptr = row outside the matrix
+    int c4, r0, k;
+
+    __device__ __forceinline__ void init(const RowsD& rows, long row_base, long nrows, int tid, int kbeg) {
+        c4 = tid & 3;
+        r0 = tid >> 2;
+        k = kbeg + c4 * 4;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const long r = row_base + r0 + p * 64;
+            ptr[p] = r < nrows ? rows.base + row_offset(rows, (unsigned)r) + k : nullptr;
+        }
+    }
+    // loads the tile starting at the current k, then advances by BK
+    __device__ __forceinline__ void load(int kend) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ptr[p]) {
+                if (ALIGNED) {
+                    if (k < kend) x = *reinterpret_cast<const float4*>(ptr[p]);
+                } else {
+                    if (k + 0 < kend) x.x = ptr[p][0];
+                    if (k + 1 < kend) x.y = ptr[p][1];
+                    if (k + 2 < kend) x.z = ptr[p][2];
+                    if (k + 3 < kend) x.w = ptr[p][3];
+                }
+                ptr[p] += BK;
+            }
+            v[p] = x;
+        }
+        k += BK;
+    }
+    __device__ __forceinline__ void store(float* tile) const {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            float* d = tile + (c4 * 4) * LD + r0 + p * 64;
+            d[0 * LD] = v[p].x;
+            d[1 * LD] = v[p].y;
+            d[2 * LD] = v[p].z;
+            d[3 * LD] = v[p].w;
+        }
+    }
+};
+
+// ---- K-outer operand: BK x COLS tile copied into LDS [BK][COLS]; rows are the contraction index
+template <int COLS, bool ALIGNED>
+struct KOuterLoader {
+    static constexpr int F4 = COLS / 4;                // float4 per tile row: 32 or 16
+    static constexpr int RPP = 256 / F4;               // tile rows per pass: 8 or 16
+    static constexpr int PASSES = BK / RPP;            // 2 or 1
+    static constexpr int LD = COLS;
+    float4 v[PASSES];
+    const float* ptr[PASSES];                          // plain-matrix mode: bumped by BK*ld per step
+    long step;
+    int c4, kk0, c, kcur, ncols_;
+
+    __device__ __forceinline__ void init(int tid) {
+        c4 = tid % F4;
+        kk0 = tid / F4;
+    }
+    // plain matrix: row k at base + k*ld
+    __device__ __forceinline__ void init_plain(const float* base, long ld, int kbeg, int col0, int ncols, int tid) {
+        init(tid);
+        c = col0 + c4 * 4;
+        ncols_ = ncols;
+        kcur = kbeg + kk0;
+        step = (long)BK * ld;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) ptr[p] = base + (long)(kcur + RPP * p) * ld + c;
+    }
+    __device__ __forceinline__ void load_plain(int kend) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            v[p] = fetch((kcur + RPP * p) < kend ? ptr[p] : nullptr, c, ncols_);
+            ptr[p] += step;
+        }
+        kcur += BK;
+    }
+    // implicit rows: caller supplies the per-pass row offsets (tracked incrementally)
+    __device__ __forceinline__ void load_rows(const float* base, const long (&off)[PASSES],
+                                              const bool (&ok)[PASSES], int col0, int ncols) {
+        const int cc = col0 + c4 * 4;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) v[p] = fetch(ok[p] ? base + off[p] + cc : nullptr, cc, ncols);
+    }
+    __device__ __forceinline__ float4 fetch(const float* src, int cc, int ncols) const {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) {
+            if (ALIGNED) {
+                if (cc < ncols) x = *reinterpret_cast<const float4*>(src);
+            } else {
+                if (cc + 0 < ncols) x.x = src[0];
+                if (cc + 1 < ncols) x.y = src[1];
+                if (cc + 2 < ncols) x.z = src[2];
+                if (cc + 3 < ncols) x.w = src[3];
+            }
+        }
+        return x;
+    }
+    __device__ __forceinline__ void store(float* tile) const {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+            *reinterpret_cast<float4*>(tile + (kk0 + RPP * p) * LD + c4 * 4) = v[p];
+    }
+};
+
+// (BM/2)x(BN/2) per wave: MI x NJ blocks of v_mfma_f32_32x32x2_f32 over one BK-deep LDS tile pair.
+// Operand registers are double-buffered by hand: the ds_reads of k-pair kk+2 are issued before
+// the MFMAs of k-pair kk, so LDS latency hides under 4 x 64 cycles of matrix work instead of
+// serialising read -> wait -> MFMA.
+template <int MI, int NJ, int LDA, int LDB>
+__device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int wm, int wn, int lane,
+                                         f32x16 (&acc)[MI][NJ]) {
+    const int h = lane >> 5, l = lane & 31;
+    const float* ap = As + h * LDA + wm * (32 * MI) + l;
+    const float* bp = Bs + h * LDB + wn * (32 * NJ) + l;
+    float a[2][MI], b[2][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[0][i] = ap[32 * i];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[0][j] = bp[32 * j];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+        const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+        if (kk + 2 < BK) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[nxt][i] = ap[(kk + 2) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[nxt][j] = bp[(kk + 2) * LDB + 32 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this k-pair's MFMAs
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float apply_epi(float v, int epi, float bias, const float* aux, long idx,
+                                           const float* dst) {
+    switch (epi) {
+        case LIDBOX_EPI_BIAS: return v + bias;
+        case LIDBOX_EPI_BIAS_RELU: return fmaxf(v + bias, 0.f);
+        case LIDBOX_EPI_RELU_MASK: return aux[idx] > 0.f ? v : 0.f;
+        case LIDBOX_EPI_ACCUM: return v + *dst;
+        case LIDBOX_EPI_ACCUM_RELU_MASK: return *dst + (aux[idx] > 0.f ? v : 0.f);
+        default: return v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] . B)    B_KINNER = false: B[K][N] (NN)   true: B[N][K] (NT)
+// grid.x = tiles (XCD-chunk remapped), grid.y = K splits.  splits > 1: raw partial sums go to
+// P[split][M][N] and rows_reduce_kernel finishes.
 // ------------------------------------------------------------------------------------------------
-template <int BK, bool B_KINNER, bool ALIGNED>
+template <int BM, int BN, bool B_KINNER, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
-                                                        RowsOutD Cd, long M, int K, int N, int epi,
-                                                        const float* __restrict__ aux, int tiles_n,
-                                                        unsigned nwg) {
-    using C = Cfg<BK>;
-    constexpr int LDB = B_KINNER ? C::LDT : C::LDD;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * C::LDT];
+                                                        RowsOutD Cd, float* __restrict__ P, long M, int K,
+                                                        int N, int epi, const float* __restrict__ aux,
+                                                        int tiles_n, unsigned ntiles, int k_per_split) {
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    using LA = KInnerLoader<BM, ALIGNED>;
+    using LBI = KInnerLoader<BN, ALIGNED>;
+    using LBO = KOuterLoader<BN, ALIGNED>;
+    constexpr int LDA = LA::LD;
+    constexpr int LDB = B_KINNER ? LBI::LD : LBO::LD;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const unsigned chunk = xcd_chunk_id(blockIdx.x, nwg);
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
     const int tn = chunk % tiles_n;
     const long tm = chunk / tiles_n;
     const long m0 = tm * BM;
     const int n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
 
-    KInnerLoader<BK, ALIGNED> la;
-    la.init(A, m0, M, tid);
-    KInnerLoader<BK, ALIGNED> lbi;
-    KOuterLoader<BK, ALIGNED> lbo;
+    LA la;
+    la.init(A, m0, M, tid, kbeg);
+    LBI lbi;
+    LBO lbo;
     RowsD Brows{Bm, 0, ldb, 1, 0};
-    if (B_KINNER) lbi.init(Brows, n0, N, tid);
-    else lbo.init(tid);
-    auto b_off = [&](long k) { return k * ldb; };
+    if (B_KINNER) lbi.init(Brows, n0, N, tid, kbeg);
+    else lbo.init_plain(Bm, ldb, kbeg, n0, N, tid);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (K + BK - 1) / BK;
-    la.load(A.base, 0, K);
-    if (B_KINNER) lbi.load(Bm, 0, K);
-    else lbo.load(Bm, b_off, 0, K, n0, N);
-    la.store(As[0]);
-    if (B_KINNER) lbi.store(Bs[0]);
-    else lbo.store(Bs[0]);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(kend);
+        if (B_KINNER) lbi.load(kend);
+        else lbo.load_plain(kend);
+        la.store(As[0]);
+        if (B_KINNER) lbi.store(Bs[0]);
+        else lbo.store(Bs[0]);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
-            la.load(A.base, (kt + 1) * BK, K);
-            if (B_KINNER) lbi.load(Bm, (kt + 1) * BK, K);
-            else lbo.load(Bm, b_off, (long)(kt + 1) * BK, K, n0, N);
+            la.load(kend);
+            if (B_KINNER) lbi.load(kend);
+            else lbo.load_plain(kend);
         }
-        mma_tile<BK, C::LDT, LDB>(As[cur], Bs[cur], wm, wn, lane, acc);
+        mma_tile<MI, NJ, LDA, LDB>(As[cur], Bs[cur], wm, wn, lane, acc);
         if (more) {
             la.store(As[cur ^ 1]);
             if (B_KINNER) lbi.store(Bs[cur ^ 1]);
@@ -236,52 +299,86 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of each block
+    // ---- epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5) of each block.
+    // Epilogue kind as four uniform flags (no per-element switch); bias and column state hoisted.
     const int h = lane >> 5, l = lane & 31;
+    const bool partial = gridDim.y > 1;
+    const bool has_bias = !partial && (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU);
+    const bool do_relu = !partial && epi == LIDBOX_EPI_BIAS_RELU;
+    const bool has_mask = !partial && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    const bool accum = !partial && (epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    int col[NJ];
+    bool colok[NJ];
+    float bias[NJ];
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-        const int col = n0 + wn * 64 + bj * 32 + l;
-        if (col >= N) continue;
-        const float bias = (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU) ? aux[col] : 0.f;
+    for (int bj = 0; bj < NJ; ++bj) {
+        col[bj] = n0 + wn * (32 * NJ) + bj * 32 + l;
+        colok[bj] = col[bj] < N;
+        bias[bj] = (has_bias && colok[bj]) ? aux[col[bj]] : 0.f;
+    }
+    float* const out_base = partial ? P + (long)split * M * N : Cd.base;
+    const long out_rs = partial ? (long)N : Cd.rs;
+    const bool batched = !partial && Cd.batch != 1;
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi) {
+    for (int bi = 0; bi < MI; ++bi) {
+        const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
+        // (b, t) of the block's first row; the other 15 rows are <= 27 below it
+        unsigned b0 = 0, t0 = (unsigned)rbase;
+        if (batched) { b0 = (unsigned)rbase / (unsigned)Cd.rpb; t0 = (unsigned)rbase - b0 * (unsigned)Cd.rpb; }
+        const long off0 = batched ? (long)b0 * Cd.bs + (long)t0 * Cd.rs : rbase * out_rs;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = m0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= M) continue;
-                long off;
-                if (Cd.batch == 1) off = row * Cd.rs;
-                else { const long b = row / Cd.rpb; off = b * Cd.bs + (row - b * Cd.rpb) * Cd.rs; }
-                float* dst = Cd.base + off + col;
-                float v = acc[bi][bj][r];
-                switch (epi) {
-                    case LIDBOX_EPI_BIAS: v += bias; break;
-                    case LIDBOX_EPI_BIAS_RELU: v = fmaxf(v + bias, 0.f); break;
-                    case LIDBOX_EPI_RELU_MASK: v = aux[off + col] > 0.f ? v : 0.f; break;
-                    case LIDBOX_EPI_ACCUM: v += *dst; break;
-                    case LIDBOX_EPI_ACCUM_RELU_MASK: v = *dst + (aux[off + col] > 0.f ? v : 0.f); break;
-                    default: break;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const long row = rbase + dr;
+            if (row >= M) continue;
+            long off = off0 + dr * out_rs;
+            if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
+#pragma unroll
+            for (int bj = 0; bj < NJ; ++bj) {
+                if (!colok[bj]) continue;
+                float* dst = out_base + off + col[bj];
+                float v = acc[bi][bj][r] + bias[bj];
+                if (has_mask) v = aux[off + col[bj]] > 0.f ? v : 0.f;
+                if (accum) v += *dst;
+                if (do_relu) v = fmaxf(v, 0.f);
                 *dst = v;
             }
         }
     }
 }
 
+// C rows = epi( sum_s P[s][M][N] ), fixed order
+__global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long M, int N, RowsOutD Cd,
+                                   int epi, const float* __restrict__ aux) {
+    const long total = M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += P[(long)k * total + i];
+        const long row = i / N;
+        const int col = (int)(i - row * N);
+        const long off = row_offset(Cd, (unsigned)row);
+        const float bias = (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU) ? aux[col] : 0.f;
+        float* dst = Cd.base + off + col;
+        *dst = apply_epi(s, epi, bias, aux, off + col, dst);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N]
+// wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = column sums of B[Mslice]
 // ------------------------------------------------------------------------------------------------
-template <int BK, bool ALIGNED>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P, long M,
-                                                      int K1, int N, int tiles_n, int ntiles, int splits,
-                                                      long rows_per_split) {
-    using C = Cfg<BK>;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * C::LDD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * C::LDD];
+template <int BM, int BN, bool ALIGNED>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P,
+                                                      float* __restrict__ Pc, long M, int K1, int N,
+                                                      int tiles_n, int ntiles, long rows_per_split) {
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    using LAo = KOuterLoader<BM, ALIGNED>;
+    using LBo = KOuterLoader<BN, ALIGNED>;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LAo::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LBo::LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // consecutive block ids = the splits of one tile pair -> spread over XCDs; tiles share nothing
+    // consecutive block ids = the tiles of one M slice: they read the same A/B rows (L2 reuse)
     const int tile = blockIdx.x % ntiles;
     const int split = blockIdx.x / ntiles;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
@@ -290,24 +387,71 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* 
     long mend = mbeg + rows_per_split;
     if (mend > M) mend = M;
 
-    KOuterLoader<BK, ALIGNED> la, lb;
+    LAo la;
+    LBo lb;
     la.init(tid);
     lb.init(tid);
-    auto a_off = [&](long m) { return row_offset(A, m); };
-    auto b_off = [&](long m) { return row_offset(Bd, m); };
+    // per-pass offset of the contraction row this thread fetches; advanced by BK rows per step with
+    // adds only: off += BK*rs, and "+= bs - rpb*rs" whenever t crosses into the next utterance
+    long am[LAo::PASSES], bm_[LBo::PASSES], aoff[LAo::PASSES], boff[LBo::PASSES];
+    unsigned at[LAo::PASSES], bt[LBo::PASSES];
+    const long a_step = (long)BK * A.rs, b_step = (long)BK * Bd.rs;
+    const long a_wrap = A.batch == 1 ? 0 : A.bs - (long)A.rpb * A.rs;
+    const long b_wrap = Bd.batch == 1 ? 0 : Bd.bs - (long)Bd.rpb * Bd.rs;
+    const unsigned a_rpb = A.batch == 1 ? 0xffffffffu : (unsigned)A.rpb;
+    const unsigned b_rpb = Bd.batch == 1 ? 0xffffffffu : (unsigned)Bd.rpb;
+#pragma unroll
+    for (int p = 0; p < LAo::PASSES; ++p) {
+        am[p] = mbeg + la.kk0 + LAo::RPP * p;
+        const unsigned bq = A.batch == 1 ? 0u : (unsigned)am[p] / a_rpb;
+        at[p] = (unsigned)am[p] - (A.batch == 1 ? 0u : bq * a_rpb);
+        aoff[p] = (long)bq * A.bs + (long)at[p] * A.rs;
+    }
+#pragma unroll
+    for (int p = 0; p < LBo::PASSES; ++p) {
+        bm_[p] = mbeg + lb.kk0 + LBo::RPP * p;
+        const unsigned bq = Bd.batch == 1 ? 0u : (unsigned)bm_[p] / b_rpb;
+        bt[p] = (unsigned)bm_[p] - (Bd.batch == 1 ? 0u : bq * b_rpb);
+        boff[p] = (long)bq * Bd.bs + (long)bt[p] * Bd.rs;
+    }
+    auto fetch = [&]() {
+        bool oka[LAo::PASSES], okb[LBo::PASSES];
+        long offa[LAo::PASSES], offb[LBo::PASSES];
+#pragma unroll
+        for (int p = 0; p < LAo::PASSES; ++p) {
+            oka[p] = am[p] < mend;
+            offa[p] = aoff[p];
+            am[p] += BK;
+            at[p] += BK;
+            aoff[p] += a_step;
+            while (at[p] >= a_rpb) { at[p] -= a_rpb; aoff[p] += a_wrap; }
+        }
+#pragma unroll
+        for (int p = 0; p < LBo::PASSES; ++p) {
+            okb[p] = bm_[p] < mend;
+            offb[p] = boff[p];
+            bm_[p] += BK;
+            bt[p] += BK;
+            boff[p] += b_step;
+            while (bt[p] >= b_rpb) { bt[p] -= b_rpb; boff[p] += b_wrap; }
+        }
+        la.load_rows(A.base, offa, oka, i0, K1);
+        lb.load_rows(Bd.base, offb, okb, n0, N);
+    };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
+    const bool do_csum = (Pc != nullptr) && tk == 0 && tid < BN;
 
     const int nk = (int)((mend - mbeg + BK - 1) / BK);
     if (nk > 0) {
-        la.load(A.base, a_off, mbeg, mend, i0, K1);
-        lb.load(Bd.base, b_off, mbeg, mend, n0, N);
+        fetch();
         la.store(As[0]);
         lb.store(Bs[0]);
     }
@@ -315,11 +459,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more) {
-            la.load(A.base, a_off, mbeg + (long)(kt + 1) * BK, mend, i0, K1);
-            lb.load(Bd.base, b_off, mbeg + (long)(kt + 1) * BK, mend, n0, N);
+        if (more) fetch();
+        mma_tile<MI, NJ, LAo::LD, LBo::LD>(As[cur], Bs[cur], wm, wn, lane, acc);
+        if (do_csum) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) csum += Bs[cur][kk * LBo::LD + tid];
         }
-        mma_tile<BK, C::LDD, C::LDD>(As[cur], Bs[cur], wm, wn, lane, acc);
         if (more) {
             la.store(As[cur ^ 1]);
             lb.store(Bs[cur ^ 1]);
@@ -329,32 +474,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* 
     float* Pd = P + (long)split * K1 * N;
     const int h = lane >> 5, l = lane & 31;
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-        const int col = n0 + wn * 64 + bj * 32 + l;
+    for (int bj = 0; bj < NJ; ++bj) {
+        const int col = n0 + wn * (32 * NJ) + bj * 32 + l;
         if (col >= N) continue;
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
+        for (int bi = 0; bi < MI; ++bi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = i0 + wm * (32 * MI) + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
             }
     }
+    if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
 }
 
-// C[i] (+)= sum_s P[s][i], fixed order
-__global__ void splitk_reduce_kernel(const float* __restrict__ P, int splits, long n, int K1, int N,
-                                     float* __restrict__ Cm, long ldc, int accumulate) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+// C[i] (+)= sum_s P[s][i]; bias_grad[n] (+)= sum_s Pc[s][n]   (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, const float* __restrict__ Pc, int splits,
+                                     long n, int N, float* __restrict__ Cm, long ldc, int accumulate,
+                                     float* __restrict__ bias_grad) {
+    const long total = n + (bias_grad ? N : 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += P[(long)k * n + i];
-        const long row = i / N, col = i - row * N;
-        float* d = Cm + row * ldc + col;
-        *d = accumulate ? *d + s : s;
+        if (i < n) {
+            for (int k = 0; k < splits; ++k) s += P[(long)k * n + i];
+            const long row = i / N, col = i - row * N;
+            float* d = Cm + row * ldc + col;
+            *d = accumulate ? *d + s : s;
+        } else {
+            const long c = i - n;
+            for (int k = 0; k < splits; ++k) s += Pc[(long)k * N + c];
+            bias_grad[c] = accumulate ? bias_grad[c] + s : s;
+        }
     }
 }
 
-// column sums: stage 1 partial[rs][N] over row slices, stage 2 fixed-order reduce
+// column sums (standalone): stage 1 partial[rs][N] over row slices, stage 2 fixed-order reduce
 __global__ __launch_bounds__(256) void colsum_stage1(RowsD A, long M, int N, long rows_per_slice,
                                                      float* __restrict__ partial) {
     __shared__ float red[256];
@@ -365,7 +519,7 @@ __global__ __launch_bounds__(256) void colsum_stage1(RowsD A, long M, int N, lon
     if (mend > M) mend = M;
     float s = 0.f;
     if (c < N)
-        for (long m = mbeg + g; m < mend; m += 4) s += A.base[row_offset(A, m) + c];
+        for (long m = mbeg + g; m < mend; m += 4) s += A.base[row_offset(A, (unsigned)m) + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && c < N)
@@ -381,6 +535,9 @@ __global__ void colsum_stage2(const float* __restrict__ partial, int slices, int
     out[c] = accumulate ? out[c] + s : s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 inline bool rows_aligned(const lidbox_rows_t& r) {
@@ -389,117 +546,229 @@ inline bool rows_aligned(const lidbox_rows_t& r) {
 
 inline RowsD to_dev(const lidbox_rows_t& r) { return RowsD{r.base, r.batch_stride, r.row_stride, r.batch, r.rows_per_batch}; }
 
-constexpr int GEMM_BK = 16;
+constexpr int NUM_CU = 256;
+
+struct RowsChoice {
+    int bm, bn, splits, k_per_split;
+};
+
+// Cost model in "K-steps of a 128x128 tile at the full fp32 MFMA rate" (~1 us each per CU).
+// A CU's resident workgroups share its four matrix pipes, so a CU's time is the SUM of its
+// tiles' MFMA time; co-resident workgroups hide each other's barrier / staging stalls, a lone
+// workgroup cannot (measured: 1 WG/CU keeps the pipe ~50 % busy, 3+ WG/CU ~90 %).
+const int CAND[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+const double TILE_EFF[4] = {1.0, 0.95, 0.95, 0.88};      // staging traffic per flop grows as tiles shrink
+const int RESIDENT[4] = {3, 4, 4, 6};                    // workgroups per CU (VGPR / LDS limited)
+constexpr double FIXED_STEPS = 3.0;                      // prologue + epilogue of one tile, in K-steps
+
+inline double conc_eff(double w) {
+    if (w <= 1.0) return 0.55;
+    if (w <= 2.0) return 0.55 + 0.25 * (w - 1.0);
+    if (w <= 3.0) return 0.80 + 0.10 * (w - 2.0);
+    return 0.92;
+}
+
+inline double launch_cost(int c, long wgs, double ksteps) {
+    const int bm = CAND[c][0], bn = CAND[c][1];
+    const double tile_t = (bm * bn / 16384.0) * (ksteps + FIXED_STEPS) / TILE_EFF[c];
+    const double per_cu = (double)lbx_cdiv(wgs, NUM_CU);
+    const double conc = per_cu < RESIDENT[c] ? (double)wgs / NUM_CU : (double)RESIDENT[c];
+    return per_cu * tile_t / conc_eff(conc < 1.0 ? 1.0 : conc);
+}
+
+RowsChoice choose_rows(long M, int N, int K, size_t ws_bytes) {
+    RowsChoice best{128, 128, 1, K};
+    double best_cost = 1e30;
+    for (int c = 0; c < 4; ++c) {
+        const int bm = CAND[c][0], bn = CAND[c][1];
+        const long tiles = lbx_cdiv(M, bm) * lbx_cdiv(N, bn);
+        for (int s = 1; s <= 64; s *= 2) {
+            int kps = (int)(lbx_cdiv(lbx_cdiv(K, s), BK) * BK);
+            const int splits = (int)lbx_cdiv(K, kps);
+            if (s > 1 && (splits < 2 || kps < 4 * BK)) break;
+            if (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) break;
+            double cost = launch_cost(c, tiles * splits, (double)kps / BK);
+            if (splits > 1) cost += 5.0 + (double)M * N * 4.0 * (splits + 1) / 3.0e6;   // reduce pass
+            if (cost < best_cost) { best_cost = cost; best = RowsChoice{bm, bn, splits, kps}; }
+            if (splits < s) break;
+        }
+    }
+    return best;
+}
+
+template <int BM, int BN, bool B_KINNER>
+void launch_rows_t(bool al, dim3 grid, hipStream_t st, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, float* P,
+                   long M, int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps) {
+    if (al)
+        hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, B_KINNER, true>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, M,
+                           K, N, epi, aux, tiles_n, ntiles, kps);
+    else
+        hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, B_KINNER, false>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, M,
+                           K, N, epi, aux, tiles_n, ntiles, kps);
+}
 
 template <bool B_KINNER>
 int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd, int K, int N, int epi,
-                const float* aux, hipStream_t st) {
+                const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
     const long M = (long)A.batch * A.rows_per_batch;
     if (M == 0 || N == 0) return LIDBOX_OK;
-    const int tiles_n = (int)lbx_cdiv(N, BN);
-    const long tiles_m = lbx_cdiv(M, BM);
-    const long nwg = tiles_m * tiles_n;
+    RowsChoice ch = choose_rows(M, N, K, ws ? ws_bytes : 0);
+    if (const char* f = getenv("LIDBOX_GEMM_TILE")) {             // tuning aid: "128x128" etc.
+        int bm = 0, bn = 0;
+        if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K;
+        }
+    }
+    const int tiles_n = (int)lbx_cdiv(N, ch.bn);
+    const long ntiles = lbx_cdiv(M, ch.bm) * tiles_n;
     // float4 paths: A rows and K multiple of 4; B: NN needs N%4 (columns), NT needs K%4 (rows)
     const bool al = rows_aligned(A) && K % 4 == 0 && aligned16(Bm) && ldb % 4 == 0 &&
                     (B_KINNER ? true : N % 4 == 0);
     RowsD Ad = to_dev(A);
     RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
-    if (al)
-        hipLaunchKernelGGL((gemm_rows_kernel<GEMM_BK, B_KINNER, true>), dim3((unsigned)nwg), dim3(256), 0, st,
-                           Ad, Bm, ldb, Co, M, K, N, epi, aux, tiles_n, (unsigned)nwg);
-    else
-        hipLaunchKernelGGL((gemm_rows_kernel<GEMM_BK, B_KINNER, false>), dim3((unsigned)nwg), dim3(256), 0, st,
-                           Ad, Bm, ldb, Co, M, K, N, epi, aux, tiles_n, (unsigned)nwg);
+    dim3 grid((unsigned)ntiles, (unsigned)ch.splits);
+    float* P = (float*)ws;
+#define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+    if (ch.bm == 128 && ch.bn == 128) LBX_ROWS(128, 128);
+    else if (ch.bm == 128) LBX_ROWS(128, 64);
+    else if (ch.bn == 128) LBX_ROWS(64, 128);
+    else LBX_ROWS(64, 64);
+#undef LBX_ROWS
     LBX_LAUNCH_OK();
+    if (ch.splits > 1) {
+        long g = lbx_cdiv(M * N, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, ch.splits, M, N,
+                           Co, epi, aux);
+        LBX_LAUNCH_OK();
+    }
     return LIDBOX_OK;
 }
 
 int check_rows(const char* fn, const void* base, long bs, long rs, int batch, int rpb) {
-    if (!base || batch < 0 || rpb < 0 || rs < 0 || bs < 0) {
+    if (!base || batch < 0 || rpb < 0 || rs < 0 || bs < 0 || (long)batch * rpb > 0x7fffffffL) {
         lidbox_set_error("%s: invalid rows descriptor", fn);
         return LIDBOX_E_INVALID;
     }
     return LIDBOX_OK;
 }
 
-void tn_plan(long M, int K1, int N, int* splits, long* rows_per_split) {
-    const long ntiles = lbx_cdiv(K1, BM) * lbx_cdiv(N, BN);
-    long s = lbx_cdiv(1024, ntiles);                 // aim at ~4 workgroups per CU
-    const long max_s = lbx_cdiv(M, 8 * GEMM_BK);     // at least 8 K-steps per split
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    if (s > 256) s = 256;
-    long rps = lbx_cdiv(M, s);
-    rps = lbx_cdiv(rps, GEMM_BK) * GEMM_BK;
-    s = lbx_cdiv(M, rps);
-    *splits = (int)s;
-    *rows_per_split = rps;
+struct TnPlan {
+    int bm, bn, splits;
+    long rows_per_split;
+};
+
+TnPlan tn_plan(long M, int K1, int N) {
+    TnPlan best{128, 128, 1, M};
+    double best_cost = 1e30;
+    for (int c = 0; c < 4; ++c) {
+        const int bm = CAND[c][0], bn = CAND[c][1];
+        const long tiles = lbx_cdiv(K1, bm) * lbx_cdiv(N, bn);
+        for (long target = NUM_CU; target <= 8 * NUM_CU; target += NUM_CU / 2) {
+            long s = target / tiles;
+            if (s < 1) s = 1;
+            const long max_s = lbx_cdiv(M, 4 * BK);
+            if (s > max_s) s = max_s;
+            if (s < 1) s = 1;
+            long rps = lbx_cdiv(lbx_cdiv(M, s), BK) * BK;
+            s = lbx_cdiv(M, rps);
+            double cost = launch_cost(c, tiles * s, (double)rps / BK);
+            cost += 5.0 + (double)K1 * N * 4.0 * (s + 1) / 3.0e6;
+            if (cost < best_cost) { best_cost = cost; best = TnPlan{bm, bn, (int)s, rps}; }
+        }
+    }
+    return best;
+}
+
+template <int BM, int BN>
+void launch_tn_t(bool al, unsigned grid, hipStream_t st, RowsD A, RowsD Bd, float* P, float* Pc, long M, int K1, int N,
+                 int tiles_n, int ntiles, long rps) {
+    if (al)
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, true>), dim3(grid), dim3(256), 0, st, A, Bd, P, Pc, M, K1, N, tiles_n,
+                           ntiles, rps);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, false>), dim3(grid), dim3(256), 0, st, A, Bd, P, Pc, M, K1, N, tiles_n,
+                           ntiles, rps);
+}
+
+int validate_rows_call(const char* fn, const lidbox_rows_t& A, const float* Bm, long ldb, const lidbox_rows_out_t& C,
+                       int K, int N, int epilogue, const float* aux, long ldb_min) {
+    if (check_rows(fn, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
+    if (check_rows(fn, C.base, C.batch_stride, C.row_stride, C.batch, C.rows_per_batch)) return LIDBOX_E_INVALID;
+    const bool needs_aux = epilogue == LIDBOX_EPI_BIAS || epilogue == LIDBOX_EPI_BIAS_RELU ||
+                           epilogue == LIDBOX_EPI_RELU_MASK || epilogue == LIDBOX_EPI_ACCUM_RELU_MASK;
+    const char* msg = nullptr;
+    if (!Bm || K < 1 || N < 0 || ldb < ldb_min) msg = "B != NULL, K >= 1, N >= 0, ldb large enough";
+    else if ((long)A.batch * A.rows_per_batch != (long)C.batch * C.rows_per_batch) msg = "A and C row counts differ";
+    else if (epilogue < LIDBOX_EPI_NONE || epilogue > LIDBOX_EPI_ACCUM_RELU_MASK) msg = "epilogue";
+    else if (needs_aux && !aux) msg = "aux required by this epilogue";
+    if (msg) {
+        lidbox_set_error("%s: invalid argument: %s", fn, msg);
+        return LIDBOX_E_INVALID;
+    }
+    return LIDBOX_OK;
 }
 
 }  // namespace
 
+extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    // room for the deepest split the cost model may pick for a small-M problem (capped at 64 MiB)
+    const RowsChoice ch = choose_rows(M, N, K, (size_t)64 << 20);
+    return ch.splits > 1 ? (size_t)ch.splits * M * N * sizeof(float) : 0;
+}
+
 extern "C" int lidbox_gemm_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N,
-                              int epilogue, const float* aux, lidbox_stream_t stream) {
-    if (check_rows(__func__, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
-    if (check_rows(__func__, C.base, C.batch_stride, C.row_stride, C.batch, C.rows_per_batch)) return LIDBOX_E_INVALID;
-    LBX_ARG(Bm && K >= 1 && N >= 0 && ldb >= N, "B != NULL, K >= 1, ldb >= N");
-    LBX_ARG((long)A.batch * A.rows_per_batch == (long)C.batch * C.rows_per_batch, "A and C row counts differ");
-    LBX_ARG(epilogue >= LIDBOX_EPI_NONE && epilogue <= LIDBOX_EPI_ACCUM_RELU_MASK, "epilogue");
-    LBX_ARG(!(epilogue == LIDBOX_EPI_BIAS || epilogue == LIDBOX_EPI_BIAS_RELU || epilogue == LIDBOX_EPI_RELU_MASK ||
-              epilogue == LIDBOX_EPI_ACCUM_RELU_MASK) || aux, "aux required by this epilogue");
-    return launch_rows<false>(A, Bm, ldb, C, K, N, epilogue, aux, (hipStream_t)stream);
+                              int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                              lidbox_stream_t stream) {
+    if (validate_rows_call(__func__, A, Bm, ldb, C, K, N, epilogue, aux, N)) return LIDBOX_E_INVALID;
+    return launch_rows<false>(A, Bm, ldb, C, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int lidbox_gemm_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N,
-                              int epilogue, const float* aux, lidbox_stream_t stream) {
-    if (check_rows(__func__, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
-    if (check_rows(__func__, C.base, C.batch_stride, C.row_stride, C.batch, C.rows_per_batch)) return LIDBOX_E_INVALID;
-    LBX_ARG(Bm && K >= 1 && N >= 0 && ldb >= K, "B != NULL, K >= 1, ldb >= K");
-    LBX_ARG((long)A.batch * A.rows_per_batch == (long)C.batch * C.rows_per_batch, "A and C row counts differ");
-    LBX_ARG(epilogue >= LIDBOX_EPI_NONE && epilogue <= LIDBOX_EPI_ACCUM_RELU_MASK, "epilogue");
-    LBX_ARG(!(epilogue == LIDBOX_EPI_BIAS || epilogue == LIDBOX_EPI_BIAS_RELU || epilogue == LIDBOX_EPI_RELU_MASK ||
-              epilogue == LIDBOX_EPI_ACCUM_RELU_MASK) || aux, "aux required by this epilogue");
-    return launch_rows<true>(A, Bm, ldb, C, K, N, epilogue, aux, (hipStream_t)stream);
+                              int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                              lidbox_stream_t stream) {
+    if (validate_rows_call(__func__, A, Bm, ldb, C, K, N, epilogue, aux, K)) return LIDBOX_E_INVALID;
+    return launch_rows<true>(A, Bm, ldb, C, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t lidbox_gemm_tn_workspace(int M, int K1, int N) {
     if (M <= 0 || K1 <= 0 || N <= 0) return 0;
-    int splits;
-    long rps;
-    tn_plan(M, K1, N, &splits, &rps);
-    return (size_t)splits * K1 * N * sizeof(float);
+    const TnPlan pl = tn_plan(M, K1, N);
+    return ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
 }
 
 extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N,
-                              int accumulate, void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
+                              int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
+                              lidbox_stream_t stream) {
     if (check_rows(__func__, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
     if (check_rows(__func__, Bd.base, Bd.batch_stride, Bd.row_stride, Bd.batch, Bd.rows_per_batch)) return LIDBOX_E_INVALID;
     LBX_ARG(Cm && K1 >= 1 && N >= 1 && ldc >= N, "C != NULL, K1, N >= 1, ldc >= N");
     const long M = (long)A.batch * A.rows_per_batch;
     LBX_ARG(M == (long)Bd.batch * Bd.rows_per_batch, "A and B row counts differ");
-    LBX_ARG(M >= 1 && M <= 0x7fffffffL, "1 <= M < 2^31");
-    int splits;
-    long rps;
-    tn_plan(M, K1, N, &splits, &rps);
-    const size_t need = (size_t)splits * K1 * N * sizeof(float);
+    LBX_ARG(M >= 1, "M >= 1");
+    const TnPlan pl = tn_plan(M, K1, N);
+    const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
     LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_tn_workspace)");
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_n = (int)lbx_cdiv(N, BN);
-    const int ntiles = (int)(lbx_cdiv(K1, BM) * tiles_n);
+    const int tiles_n = (int)lbx_cdiv(N, pl.bn);
+    const int ntiles = (int)(lbx_cdiv(K1, pl.bm) * tiles_n);
     const bool al = rows_aligned(A) && rows_aligned(Bd) && K1 % 4 == 0 && N % 4 == 0;
     float* P = (float*)workspace;
-    if (al)
-        hipLaunchKernelGGL((gemm_tn_kernel<GEMM_BK, true>), dim3((unsigned)(ntiles * splits)), dim3(256), 0, st,
-                           to_dev(A), to_dev(Bd), P, M, K1, N, tiles_n, ntiles, splits, rps);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<GEMM_BK, false>), dim3((unsigned)(ntiles * splits)), dim3(256), 0, st,
-                           to_dev(A), to_dev(Bd), P, M, K1, N, tiles_n, ntiles, splits, rps);
+    float* Pc = bias_grad ? P + (size_t)pl.splits * K1 * N : nullptr;
+    const unsigned grid = (unsigned)(ntiles * pl.splits);
+#define LBX_TN(BM_, BN_) launch_tn_t<BM_, BN_>(al, grid, st, to_dev(A), to_dev(Bd), P, Pc, M, K1, N, tiles_n, ntiles, pl.rows_per_split)
+    if (pl.bm == 128 && pl.bn == 128) LBX_TN(128, 128);
+    else if (pl.bm == 128) LBX_TN(128, 64);
+    else if (pl.bn == 128) LBX_TN(64, 128);
+    else LBX_TN(64, 64);
+#undef LBX_TN
     LBX_LAUNCH_OK();
     const long n = (long)K1 * N;
-    long g = lbx_cdiv(n, 256);
+    long g = lbx_cdiv(n + N, 256);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, P, splits, n, K1, N, Cm, ldc,
-                       accumulate);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, (const float*)Pc,
+                       pl.splits, n, N, Cm, ldc, accumulate, bias_grad);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -111,7 +111,7 @@ def linear_to_mel(spectrograms, sample_rate, num_mel_bins=40, fmin=0.0, fmax=800
     Cd = nv.Rows(out.data_ptr(), 0, int(num_mel_bins), 1, B * T)
     with torch.cuda.device(S.device):
         nv.check(nv.lib.lidbox_gemm_nn(A, nv.ptr(W), int(num_mel_bins), Cd, F, int(num_mel_bins), nv.EPI_NONE,
-                                       None, nv.current_stream()))
+                                       None, None, 0, nv.current_stream()))
     return out
 
 

@@ -74,22 +74,23 @@ class _Workspace:
         self.logp = torch.zeros((B, model.denses[-1].units), **f32)
         self.emb = torch.zeros((B, model.denses[0].units), **f32)
         self.loss = torch.zeros(4, **f32)
-        # GEMM / reduction workspaces sized for the largest layer
-        tn_bytes, cs_bytes = 16, 16
+        # one GEMM workspace sized for the largest split (wgrad partials, small-M split-K partials)
+        ws_bytes = 16
         cin = model.input_dim
         for i, c in enumerate(convs):
             M = B * self.Ts[i + 1]
             if M > 0:
-                tn_bytes = max(tn_bytes, nv.lib.lidbox_gemm_tn_workspace(M, c.k * cin, c.filters))
-                cs_bytes = max(cs_bytes, nv.lib.lidbox_colsum_workspace(M, c.filters))
+                ws_bytes = max(ws_bytes, nv.lib.lidbox_gemm_tn_workspace(M, c.k * cin, c.filters),
+                               nv.lib.lidbox_gemm_rows_workspace(M, c.filters, c.k * cin),
+                               nv.lib.lidbox_gemm_rows_workspace(M, c.k * cin, c.filters))
             cin = c.filters
         din = P
         for d in model.denses:
-            tn_bytes = max(tn_bytes, nv.lib.lidbox_gemm_tn_workspace(B, din, d.units))
-            cs_bytes = max(cs_bytes, nv.lib.lidbox_colsum_workspace(B, d.units))
+            ws_bytes = max(ws_bytes, nv.lib.lidbox_gemm_tn_workspace(B, din, d.units),
+                           nv.lib.lidbox_gemm_rows_workspace(B, d.units, din),
+                           nv.lib.lidbox_gemm_rows_workspace(B, din, d.units))
             din = d.units
-        self.tn_ws = torch.empty(tn_bytes, dtype=torch.uint8, device=dev)
-        self.cs_ws = torch.empty(cs_bytes, dtype=torch.uint8, device=dev)
+        self.gemm_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
     def input_view(self):
         """[B, T, C0] view of act[0] behind its causal zero rows."""
@@ -206,7 +207,8 @@ class SequentialTDNN:
             if ws.B * ws.Ts[i + 1] > 0:
                 nv.check(lib.lidbox_gemm_nn(self._conv_rows_in(ws, i), self._p(c.name + ".W"), c.filters,
                                             self._rows_out(ws.act[i + 1], ws, i + 1), c.k * cin, c.filters,
-                                            nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"), st))
+                                            nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
+                                            nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
             cin = c.filters
         last = ws.act[-1]
         T, C = last.shape[1], last.shape[2]
@@ -219,7 +221,7 @@ class SequentialTDNN:
             epi = nv.EPI_BIAS_RELU if (d.relu and not emb) else nv.EPI_BIAS
             nv.check(lib.lidbox_gemm_nn(_rows(x.data_ptr(), 0, din, 1, ws.B), self._p(d.name + ".W"), d.units,
                                         _rows(out.data_ptr(), 0, d.units, 1, ws.B), din, d.units, epi,
-                                        self._p(d.name + ".b"), st))
+                                        self._p(d.name + ".b"), nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
             if emb:
                 return ws.emb
             x, din = out, d.units
@@ -240,8 +242,7 @@ class SequentialTDNN:
         st = nv.current_stream()
         lib = nv.lib
         B = ws.B
-        tn_ws, tn_n = nv.ptr(ws.tn_ws), ws.tn_ws.numel()
-        cs_ws, cs_n = nv.ptr(ws.cs_ws), ws.cs_ws.numel()
+        gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
         # ---- dense chain
         for j in range(len(self.denses) - 1, -1, -1):
             d = self.denses[j]
@@ -249,14 +250,13 @@ class SequentialTDNN:
             din = x.shape[1]
             dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
             nv.check(lib.lidbox_gemm_tn(_rows(x.data_ptr(), 0, din, 1, B), dy, self._p(d.name + ".W", True),
-                                        d.units, din, d.units, 0, tn_ws, tn_n, st))
-            nv.check(lib.lidbox_colsum(dy, d.units, self._p(d.name + ".b", True), 0, cs_ws, cs_n, st))
+                                        d.units, din, d.units, 0, self._p(d.name + ".b", True), gws, gws_n, st))
             dst = ws.dpooled if j == 0 else ws.dh[j - 1]
             relu_prev = j > 0 and self.denses[j - 1].relu
             nv.check(lib.lidbox_gemm_nt(dy, self._p(d.name + ".W"), d.units,
                                         _rows(dst.data_ptr(), 0, din, 1, B), d.units, din,
                                         nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE,
-                                        nv.ptr(x) if relu_prev else None, st))
+                                        nv.ptr(x) if relu_prev else None, gws, gws_n, st))
         # ---- pooling (fused with the ReLU backward of the last conv)
         last = ws.act[-1]
         T, C = last.shape[1], last.shape[2]
@@ -273,8 +273,7 @@ class SequentialTDNN:
         st = nv.current_stream()
         lib = nv.lib
         B = ws.B
-        tn_ws, tn_n = nv.ptr(ws.tn_ws), ws.tn_ws.numel()
-        cs_ws, cs_n = nv.ptr(ws.cs_ws), ws.cs_ws.numel()
+        gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
         c = self.convs[i]
         cin = self.input_dim if i == 0 else self.convs[i - 1].filters
         K = c.k * cin
@@ -285,8 +284,7 @@ class SequentialTDNN:
             return
         dy = self._rows_out(ws.dact[i + 1], ws, i + 1)
         nv.check(lib.lidbox_gemm_tn(self._conv_rows_in(ws, i), dy, self._p(c.name + ".W", True), c.filters,
-                                    K, c.filters, 0, tn_ws, tn_n, st))
-        nv.check(lib.lidbox_colsum(dy, c.filters, self._p(c.name + ".b", True), 0, cs_ws, cs_n, st))
+                                    K, c.filters, 0, self._p(c.name + ".b", True), gws, gws_n, st))
         if i == 0:
             return
         # dgrad into dact[i].  Window t touches padded rows [t*s, t*s+k).  Group g = taps
@@ -310,7 +308,7 @@ class SequentialTDNN:
                 epi = nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE
             else:
                 epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
-            nv.check(lib.lidbox_gemm_nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, st))
+            nv.check(lib.lidbox_gemm_nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
 
     # ------------------------------------------------------------------ public call
     def _load_input(self, ws, x, training):

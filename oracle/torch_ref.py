@@ -134,4 +134,4 @@ class TrainStepCPU:
         loss = sparse_ce_from_logits(xvector_fwd(self.params, x), labels)
         loss.backward()
         self.opt.step()
-        return float(loss)
+        return float(loss.detach())

@@ -39,14 +39,21 @@ def test_gemm_nn_plain(M, K, N):
     a, b, bi = _dev(A), _dev(B), _dev(bias)
     c = torch.full((M, N), 7.0, device="cuda")
     st = nv.current_stream()
-    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_NONE, None, st))
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_NONE, None, None, 0, st))
     _close(c.cpu().numpy(), A @ B)
     nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU,
-                                   nv.ptr(bi), st))
+                                   nv.ptr(bi), None, 0, st))
     _close(c.cpu().numpy(), np.maximum(A @ B + bias, 0))
     nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS,
-                                   nv.ptr(bi), st))
+                                   nv.ptr(bi), None, 0, st))
     _close(c.cpu().numpy(), A @ B + bias)
+    # with a split-K workspace (small-M problems split along K; epilogue fused into the reduce)
+    wsb = max(16, nv.lib.lidbox_gemm_rows_workspace(M, N, K))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    c.fill_(-3.0)
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU,
+                                   nv.ptr(bi), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), np.maximum(A @ B + bias, 0))
 
 
 @pytest.mark.parametrize("M,K,N", [(128, 512, 1024), (99, 512, 1536), (7, 5, 3), (256, 4, 512), (300, 100, 3000)])
@@ -59,17 +66,23 @@ def test_gemm_nt_and_epilogues(M, K, N):
     c = torch.zeros((M, N), device="cuda")
     st = nv.current_stream()
     ref = A @ Bt.T
-    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_NONE, None, st))
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_NONE, None, None, 0, st))
     _close(c.cpu().numpy(), ref)
     nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
-                                   nv.ptr(mk), st))
+                                   nv.ptr(mk), None, 0, st))
     _close(c.cpu().numpy(), ref * (mask > 0))
     c.fill_(1.5)
-    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_ACCUM, None, st))
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_ACCUM, None, None, 0, st))
     _close(c.cpu().numpy(), ref + 1.5)
     c.fill_(-2.0)
     nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N,
-                                   nv.EPI_ACCUM_RELU_MASK, nv.ptr(mk), st))
+                                   nv.EPI_ACCUM_RELU_MASK, nv.ptr(mk), None, 0, st))
+    _close(c.cpu().numpy(), ref * (mask > 0) - 2.0)
+    wsb = max(16, nv.lib.lidbox_gemm_rows_workspace(M, N, K))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    c.fill_(-2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N,
+                                   nv.EPI_ACCUM_RELU_MASK, nv.ptr(mk), nv.ptr(ws), wsb, st))
     _close(c.cpu().numpy(), ref * (mask > 0) - 2.0)
 
 
@@ -83,20 +96,26 @@ def test_gemm_tn_and_colsum(M, K1, N):
     st = nv.current_stream()
     wsb = nv.lib.lidbox_gemm_tn_workspace(M, K1, N)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
-    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K1, N, 0, nv.ptr(ws),
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K1, N, 0, None, nv.ptr(ws),
                                    wsb, st))
     ref = A.T @ B
     _close(c.cpu().numpy(), ref)
-    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K1, N, 1, nv.ptr(ws),
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K1, N, 1, None, nv.ptr(ws),
                                    wsb, st))
     _close(c.cpu().numpy(), 2 * ref)
     # determinism: bit-identical on a second run
     c2 = torch.empty_like(c)
-    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c2), N, K1, N, 0, nv.ptr(ws),
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c2), N, K1, N, 0, None, nv.ptr(ws),
                                    wsb, st))
     c3 = torch.empty_like(c)
-    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c3), N, K1, N, 0, nv.ptr(ws),
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c3), N, K1, N, 0, None, nv.ptr(ws),
                                    wsb, st))
+    assert torch.equal(c2, c3)
+    # bias gradient fused into the wgrad kernel (column sums of B from the tiles already in LDS)
+    bg = torch.full((N,), 9.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c3), N, K1, N, 0, nv.ptr(bg),
+                                   nv.ptr(ws), wsb, st))
+    _close(bg.cpu().numpy(), B.sum(axis=0))
     assert torch.equal(c2, c3)
     csb = nv.lib.lidbox_colsum_workspace(M, N)
     cws = torch.empty(csb, dtype=torch.uint8, device="cuda")
@@ -295,7 +314,7 @@ def test_abi_rejects_bad_arguments():
     from lidbox_amd import _native as nv
     x = torch.zeros(16, device="cuda")
     assert nv.lib.lidbox_gemm_nn(nv.Rows(None, 0, 4, 1, 4), nv.ptr(x), 4, nv.Rows(x.data_ptr(), 0, 4, 1, 4), 4, 4, 0,
-                                 None, None) == -1
+                                 None, None, 0, None) == -1
     assert "lidbox_gemm_nn" in nv.last_error()
     assert nv.lib.lidbox_stats_pool_fwd(None, 1, 1, 1, 1, 1, None, None) == -1
     assert nv.lib.lidbox_ap_loss_fwd_bwd(nv.ptr(x), nv.ptr(x), 1, 2, 3, 1.0, 1.0, nv.ptr(x), None, None) == -1

@@ -1,5 +1,7 @@
 """Micro-benchmark of the fused log-mel kernel: achieved algorithmic GB/s vs the 8 TB/s HBM roofline."""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lidbox_amd.features import audio
 from lidbox_amd import _native as nv
