@@ -114,25 +114,40 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(seconds, batch=32):
-    """oracle/torch_ref.py train step on the host cores, bounded sample."""
+def cpu_baseline(seconds, batch=64):
+    """oracle/torch_ref.py train step on the host cores, bounded sample.  torch-CPU does not scale past a
+    few dozen threads on this workload (256 threads is 10x SLOWER than 16 on the 2 x 64-core host), so the
+    thread count is chosen by a short sweep and reported as `cores`."""
     from oracle.torch_ref import TrainStepCPU
     from lidbox_amd.testutil import synthetic_batch
-    threads = os.cpu_count() or 1
-    step = TrainStepCPU(num_outputs=NUM_LANGS, seed=0, threads=threads)
+    ncpu = os.cpu_count() or 1
     sig, y = synthetic_batch(batch, NUM_LANGS, SAMPLE_RATE, DURATION_S)
     sig_t, y_t = torch.from_numpy(sig), torch.from_numpy(y.astype(np.int64))
-    step.step(sig_t, y_t)                                            # warm-up
+    step = TrainStepCPU(num_outputs=NUM_LANGS, seed=0, threads=min(ncpu, 8))
+    best_threads, best_rate = min(ncpu, 8), 0.0
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        step.step(sig_t, y_t)                                        # warm-up at this thread count
+        n, t0 = 0, time.perf_counter()
+        while n < 3 or (time.perf_counter() - t0 < 1.5 and n < 20):
+            step.step(sig_t, y_t)
+            n += 1
+        rate = n * batch / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_threads, best_rate = th, rate
+    torch.set_num_threads(best_threads)
+    step.step(sig_t, y_t)
     n, t0 = 0, time.perf_counter()
     while True:
         step.step(sig_t, y_t)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 200:
+        if dt >= seconds or n >= 400:
             break
-    return dict(value=round(n * batch / dt, 2), unit="utterances/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(n * batch / dt, 2), unit="utterances/s", cores=best_threads, kind="port",
                 sample="%d train steps of %d utterances (log-mel + x-vector fwd/bwd + Adam, fp32, torch-CPU "
-                       "restatement oracle/torch_ref.py; TensorFlow unavailable) in %.1f s" % (n, batch, dt))
+                       "restatement oracle/torch_ref.py; TensorFlow unavailable) in %.1f s on %d of %d logical "
+                       "cores (best of a 8/16/32/64-thread sweep)" % (n, batch, dt, best_threads, ncpu))
 
 
 def main():

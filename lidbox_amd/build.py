@@ -21,7 +21,7 @@ OBJDIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("LIDBOX_HIPCC_FLAGS", "").split()
 
 
 def _sources():

@@ -40,7 +40,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+#ifndef LBX_GEMM_BK
+#define LBX_GEMM_BK 16
+#endif
+constexpr int BK = LBX_GEMM_BK;           // K depth of one LDS tile (tuning aid: -DLBX_GEMM_BK=32)
 
 struct RowsD {
     const float* base;
@@ -70,19 +73,21 @@ __device__ __forceinline__ long row_offset(const RowsOutD& r, unsigned m) {
 //      LDS [BK][ROWS + 2].  Each thread keeps one source pointer per pass and bumps it by BK.
 template <int ROWS, bool ALIGNED>
 struct KInnerLoader {
-    static constexpr int PASSES = ROWS / 64;          // 256 threads = 64 rows x 4 float4
-    static constexpr int LD = ROWS + 2;
+    static constexpr int F4R = BK / 4;                // float4 per tile row: 4 (BK 16) or 8 (BK 32)
+    static constexpr int RPP = 256 / F4R;             // tile rows per pass: 64 or 32
+    static constexpr int PASSES = ROWS / RPP;
+    static constexpr int LD = ROWS + 8 / F4R;         // = 2 or 1 (mod 32): conflict-free transposed stores
     float4 v[PASSES];
     const float* ptr[PASSES];                         // nullptr = row outside the matrix
     int c4, r0, k;
 
     __device__ __forceinline__ void init(const RowsD& rows, long row_base, long nrows, int tid, int kbeg) {
-        c4 = tid & 3;
-        r0 = tid >> 2;
+        c4 = tid % F4R;
+        r0 = tid / F4R;
         k = kbeg + c4 * 4;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const long r = row_base + r0 + p * 64;
+            const long r = row_base + r0 + p * RPP;
             ptr[p] = r < nrows ? rows.base + row_offset(rows, (unsigned)r) + k : nullptr;
         }
     }
@@ -109,7 +114,7 @@ struct KInnerLoader {
     __device__ __forceinline__ void store(float* tile) const {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            float* d = tile + (c4 * 4) * LD + r0 + p * 64;
+            float* d = tile + (c4 * 4) * LD + r0 + p * RPP;
             d[0 * LD] = v[p].x;
             d[1 * LD] = v[p].y;
             d[2 * LD] = v[p].z;
@@ -558,7 +563,7 @@ struct RowsChoice {
 // workgroup cannot (measured: 1 WG/CU keeps the pipe ~50 % busy, 3+ WG/CU ~90 %).
 const int CAND[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
 const double TILE_EFF[4] = {1.0, 0.95, 0.95, 0.88};      // staging traffic per flop grows as tiles shrink
-const int RESIDENT[4] = {3, 4, 4, 6};                    // workgroups per CU (VGPR / LDS limited)
+const int RESIDENT[4] = {BK == 16 ? 3 : 2, BK == 16 ? 4 : 3, BK == 16 ? 4 : 3, BK == 16 ? 6 : 4};   // workgroups per CU (VGPR / LDS limited)
 constexpr double FIXED_STEPS = 3.0;                      // prologue + epilogue of one tile, in K-steps
 
 inline double conc_eff(double w) {
@@ -579,7 +584,7 @@ inline double launch_cost(int c, long wgs, double ksteps) {
 RowsChoice choose_rows(long M, int N, int K, size_t ws_bytes) {
     RowsChoice best{128, 128, 1, K};
     double best_cost = 1e30;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = (BK > 16 ? 1 : 0); c < 4; ++c) {
         const int bm = CAND[c][0], bn = CAND[c][1];
         const long tiles = lbx_cdiv(M, bm) * lbx_cdiv(N, bn);
         for (int s = 1; s <= 64; s *= 2) {
@@ -617,6 +622,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
         int bm = 0, bn = 0;
         if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
             ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K;
+            if (BK > 16 && bm == 128 && bn == 128) ch.bn = 64;
         }
     }
     const int tiles_n = (int)lbx_cdiv(N, ch.bn);
@@ -629,8 +635,11 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     dim3 grid((unsigned)ntiles, (unsigned)ch.splits);
     float* P = (float*)ws;
 #define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+#if LBX_GEMM_BK == 16
     if (ch.bm == 128 && ch.bn == 128) LBX_ROWS(128, 128);
-    else if (ch.bm == 128) LBX_ROWS(128, 64);
+    else
+#endif
+    if (ch.bm == 128) LBX_ROWS(128, 64);
     else if (ch.bn == 128) LBX_ROWS(64, 128);
     else LBX_ROWS(64, 64);
 #undef LBX_ROWS
@@ -661,7 +670,7 @@ struct TnPlan {
 TnPlan tn_plan(long M, int K1, int N) {
     TnPlan best{128, 128, 1, M};
     double best_cost = 1e30;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = (BK > 16 ? 1 : 0); c < 4; ++c) {
         const int bm = CAND[c][0], bn = CAND[c][1];
         const long tiles = lbx_cdiv(K1, bm) * lbx_cdiv(N, bn);
         for (long target = NUM_CU; target <= 8 * NUM_CU; target += NUM_CU / 2) {
@@ -758,8 +767,11 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     float* Pc = bias_grad ? P + (size_t)pl.splits * K1 * N : nullptr;
     const unsigned grid = (unsigned)(ntiles * pl.splits);
 #define LBX_TN(BM_, BN_) launch_tn_t<BM_, BN_>(al, grid, st, to_dev(A), to_dev(Bd), P, Pc, M, K1, N, tiles_n, ntiles, pl.rows_per_split)
+#if LBX_GEMM_BK == 16
     if (pl.bm == 128 && pl.bn == 128) LBX_TN(128, 128);
-    else if (pl.bm == 128) LBX_TN(128, 64);
+    else
+#endif
+    if (pl.bm == 128) LBX_TN(128, 64);
     else if (pl.bn == 128) LBX_TN(64, 128);
     else LBX_TN(64, 64);
 #undef LBX_TN

@@ -1,0 +1,99 @@
+// Microbenchmark: add the K-loop ingredients of gemm.hip one at a time to a pure MFMA loop.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// FEAT bits: 1 = LDS operand reads, 2 = LDS stores (transposed b32 x8 + b128 x2), 4 = barrier per K-step,
+//            8 = global loads (4 x float4 per thread per K-step), 16 = double-buffer toggle
+template <int FEAT>
+__global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float* out, int ksteps, long gstride) {
+    __shared__ __attribute__((aligned(16))) float As[2][16 * 130];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 16 * 130; i += 256) (&As[0][0])[i] = (float)(i & 7);
+    for (int i = tid; i < 2 * 16 * 128; i += 256) (&Bs[0][0])[i] = (float)(i & 3);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int h = lane >> 5, l = lane & 31, wm = wave >> 1, wn = wave & 1;
+    const int c4 = tid & 3, r0 = tid >> 2;
+    // A panel shared by 8 consecutive workgroups (the n-tiles of one m-tile), B panel shared by all
+    const float* gp = g + (long)(blockIdx.x >> 3) * gstride + (long)r0 * 1536 + c4 * 4;
+    const float* gb = g + (long)r0 * 1536 + c4 * 4;
+    float4 va[2] = {make_float4(1, 2, 3, 4), make_float4(1, 2, 3, 4)}, vb[2] = {make_float4(1, 2, 3, 4), make_float4(1, 2, 3, 4)};
+    float ra0 = 1.f, ra1 = 2.f, rb0 = 3.f, rb1 = 4.f;
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const int cur = (FEAT & 16) ? (kt & 1) : 0;
+        if (FEAT & 8) {
+            va[0] = *reinterpret_cast<const float4*>(gp);
+            va[1] = *reinterpret_cast<const float4*>(gp + 64 * 1536);
+            vb[0] = *reinterpret_cast<const float4*>(gb);
+            vb[1] = *reinterpret_cast<const float4*>(gb + 64 * 1536);
+            gp += 16;
+            gb += 16;
+        }
+        const float* ap = As[cur] + h * 130 + wm * 64 + l;
+        const float* bp = Bs[cur] + h * 128 + wn * 64 + l;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            if (FEAT & 1) { ra0 = ap[kk * 130]; ra1 = ap[kk * 130 + 32]; rb0 = bp[kk * 128]; rb1 = bp[kk * 128 + 32]; }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb1, acc[1][1], 0, 0, 0);
+        }
+        if (FEAT & 2) {
+            float* da = As[cur ^ ((FEAT & 16) ? 1 : 0)];
+            float* db = Bs[cur ^ ((FEAT & 16) ? 1 : 0)];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float* d = da + (c4 * 4) * 130 + r0 + p * 64;
+                d[0] = va[p].x; d[130] = va[p].y; d[260] = va[p].z; d[390] = va[p].w;
+            }
+            *reinterpret_cast<float4*>(db + ((tid >> 5)) * 128 + (tid & 31) * 4) = vb[0];
+            *reinterpret_cast<float4*>(db + ((tid >> 5) + 8) * 128 + (tid & 31) * 4) = vb[1];
+        }
+        if (FEAT & 4) __syncthreads();
+    }
+    float s = va[0].x + vb[1].y;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int FEAT>
+static void run(const char* name, const float* g, float* out, int grid, int ksteps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const long gstride = 128L * 1536;
+    hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double fl = (double)grid * 4 * ksteps * 8 * 4 * 4096.0;
+    printf("  %-52s %8.1f us  %6.1f TF/s\n", name, ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    float *g, *out;
+    const int maxgrid = 1024;
+    hipMalloc(&g, (size_t)maxgrid * 256 * 1536 * 4);
+    hipMemset(g, 0, (size_t)maxgrid * 256 * 1536 * 4);
+    hipMalloc(&out, maxgrid * 256 * 4);
+    const int ksteps = 96;
+    for (int w = 1; w <= 4; ++w) {
+        const int grid = 256 * w;
+        printf("%d WG/CU (grid %d), %d K-steps\n", w, grid, ksteps);
+        run<0>("MFMA only", g, out, grid, ksteps);
+        run<1>("+ LDS operand reads", g, out, grid, ksteps);
+        run<1 | 2>("+ LDS stores", g, out, grid, ksteps);
+        run<1 | 2 | 4>("+ barrier", g, out, grid, ksteps);
+        run<1 | 2 | 4 | 16>("+ double-buffer toggle", g, out, grid, ksteps);
+        run<1 | 2 | 4 | 8 | 16>("+ global loads (full loop)", g, out, grid, ksteps);
+        run<1 | 4 | 8 | 16>("full minus LDS stores", g, out, grid, ksteps);
+        run<1 | 2 | 8 | 16>("full minus barrier", g, out, grid, ksteps);
+    }
+    return 0;
+}
