@@ -59,40 +59,45 @@ def parse_args():
 
 class KernelTimer:
     """Brackets every launch of the GEMM family and of the feature kernel with HIP events on the
-    stream they are launched on (torch's current stream) during an instrumented eager pass."""
+    stream they are launched on (torch's current stream) during an instrumented eager pass.
+    Launches are keyed by the exact kernel instantiation (tile shape from lidbox_gemm_plan_query),
+    i.e. by the names rocprofv3 --stats reports."""
 
-    FAMILIES = {
-        "lidbox_gemm_nn": "gemm_rows_kernel<NN>",
-        "lidbox_gemm_nt": "gemm_rows_kernel<NT>",
-        "lidbox_gemm_tn": "gemm_tn_kernel",
-        "lidbox_extract_features_fwd": "fused_feat512_kernel",
-    }
+    ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_extract_features_fwd": -1}
 
     def __init__(self, nv):
         self.nv = nv
-        self.records = {k: [] for k in self.FAMILIES}
+        self.records = {}
         self._orig = {}
 
-    def _work(self, name, args):
-        if name in ("lidbox_gemm_nn", "lidbox_gemm_nt"):
-            A, K, N = args[0], args[4], args[5]
-            return 2.0 * A.batch * A.rows_per_batch * K * N
-        if name == "lidbox_gemm_tn":
-            A, K1, N = args[0], args[4], args[5]
-            return 2.0 * A.batch * A.rows_per_batch * K1 * N
-        return float(args[3]) * BYTES_PER_UTT_FEATURE            # feature kernel: algorithmic bytes
+    def _classify(self, name, args):
+        import ctypes
+        kind = self.ENTRY[name]
+        if kind < 0:
+            return "fused_feat512_kernel", float(args[3]) * BYTES_PER_UTT_FEATURE
+        A, K, N = args[0], args[4], args[5]
+        M = A.batch * A.rows_per_batch
+        ws_bytes = args[9] if kind < 2 else 0
+        out = (ctypes.c_int * 4)()
+        self.nv.check(self.nv.lib.lidbox_gemm_plan_query(kind, M, N, K, int(ws_bytes or 0), out))
+        if kind == 2:
+            key = "gemm_tn_kernel<%d, %d>" % (out[0], out[1])
+        else:
+            key = "gemm_rows_kernel<%d, %d, %s>" % (out[0], out[1], "NT" if kind else "NN")
+        return key, 2.0 * M * K * N
 
     def __enter__(self):
-        for name in self.FAMILIES:
+        for name in self.ENTRY:
             orig = getattr(self.nv.lib, name)
             self._orig[name] = orig
 
             def wrapper(*args, _n=name, _o=orig):
+                key, work = self._classify(_n, args)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _o(*args)
                 e1.record()
-                self.records[_n].append((e0, e1, self._work(_n, args)))
+                self.records.setdefault(key, []).append((e0, e1, work))
                 return rc
             setattr(self.nv.lib, name, wrapper)
         return self
@@ -104,13 +109,11 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, recs in self.records.items():
-            if not recs:
-                continue
+        for key, recs in self.records.items():
             ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
             work = sum(w for _, _, w in recs)
-            out[self.FAMILIES[name]] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs),
-                                            work_per_launch=work / len(recs), rate=work / (ms * 1e-3))
+            out[key] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs),
+                            work_per_launch=work / len(recs), rate=work / (ms * 1e-3))
         return out
 
 
@@ -241,7 +244,9 @@ def main():
                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                                   "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
-                                  "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3)}
+                                  "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
+                                  "note": "HIP-event bracket per launch (includes the split-K reduce kernel where one "
+                                          "follows); rocprofv3 --stats lists the same instantiation by this name"}
             gemm_ms = sum(v["total_ms"] for v in gemms.values()) / nsteps
             gemm_flops = sum(v["rate"] * v["total_ms"] * 1e-3 for v in gemms.values()) / nsteps
             result["kernels"] = {k: {"launches_per_step": v["launches"] // nsteps, "ms_per_step": round(v["total_ms"] / nsteps, 4),

@@ -153,6 +153,10 @@ enum {
     LIDBOX_EPI_ACCUM_RELU_MASK = 5 /* C += . * (mask > 0)                                          */
 };
 
+/* Which decomposition the cost model picks (for profiling tools: it names the kernel instantiation a
+ * launch will use).  kind 0 = nn, 1 = nt, 2 = tn (then K = K1).  out4 = {BM, BN, splits, k or rows per split}. */
+int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t workspace_bytes, int* out4);
+
 /* Split-K workspace (bytes) that lets lidbox_gemm_nn / _nt fill the chip when M*N is small
  * (Dense layers at M = batch): partial sums are reduced in a fixed order with the epilogue
  * fused into the reduce.  0 = not needed.  Passing NULL/0 is always legal (no split). */

@@ -720,6 +720,18 @@ int validate_rows_call(const char* fn, const lidbox_rows_t& A, const float* Bm, 
 
 }  // namespace
 
+extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t workspace_bytes, int* out4) {
+    LBX_ARG(out4 && M > 0 && N > 0 && K > 0 && kind >= 0 && kind <= 2, "kind in {0 nn, 1 nt, 2 tn}, positive sizes");
+    if (kind == 2) {           // tn: (M rows contracted, K = K1, N)
+        const TnPlan pl = tn_plan(M, K, N);
+        out4[0] = pl.bm; out4[1] = pl.bn; out4[2] = pl.splits; out4[3] = (int)pl.rows_per_split;
+    } else {
+        const RowsChoice ch = choose_rows(M, N, K, workspace_bytes);
+        out4[0] = ch.bm; out4[1] = ch.bn; out4[2] = ch.splits; out4[3] = ch.k_per_split;
+    }
+    return LIDBOX_OK;
+}
+
 extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // room for the deepest split the cost model may pick for a small-M problem (capped at 64 MiB)
