@@ -71,6 +71,9 @@ __device__ __forceinline__ long row_offset(const RowsOutD& r, unsigned m) {
 
 // ---- K-inner operand (contraction index contiguous in HBM): ROWS x BK tile, transposed into
 //      LDS [BK][ROWS + 2].  Each thread keeps one source pointer per pass and bumps it by BK.
+//      Rows outside the matrix are CLAMPED to row 0 (finite data whose products only reach
+//      output rows/columns that are never stored), so interior K-steps carry no predicates at
+//      all; only the tail step (CHECK) tests k and zero-fills.
 template <int ROWS, bool ALIGNED>
 struct KInnerLoader {
     static constexpr int F4R = BK / 4;                // float4 per tile row: 4 (BK 16) or 8 (BK 32)
@@ -78,7 +81,7 @@ struct KInnerLoader {
     static constexpr int PASSES = ROWS / RPP;
     static constexpr int LD = ROWS + 8 / F4R;         // = 2 or 1 (mod 32): conflict-free transposed stores
     float4 v[PASSES];
-    const float* ptr[PASSES];                         // nullptr = row outside the matrix
+    const float* ptr[PASSES];
     int c4, r0, k;
 
     __device__ __forceinline__ void init(const RowsD& rows, long row_base, long nrows, int tid, int kbeg) {
@@ -88,15 +91,20 @@ struct KInnerLoader {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const long r = row_base + r0 + p * RPP;
-            ptr[p] = r < nrows ? rows.base + row_offset(rows, (unsigned)r) + k : nullptr;
+            ptr[p] = rows.base + (r < nrows ? row_offset(rows, (unsigned)r) : 0) + k;
         }
     }
     // loads the tile starting at the current k, then advances by BK
+    template <bool CHECK>
     __device__ __forceinline__ void load(int kend) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ptr[p]) {
+            float4 x;
+            if (!CHECK) {
+                if (ALIGNED) x = *reinterpret_cast<const float4*>(ptr[p]);
+                else x = make_float4(ptr[p][0], ptr[p][1], ptr[p][2], ptr[p][3]);
+            } else {
+                x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ALIGNED) {
                     if (k < kend) x = *reinterpret_cast<const float4*>(ptr[p]);
                 } else {
@@ -105,8 +113,8 @@ struct KInnerLoader {
                     if (k + 2 < kend) x.z = ptr[p][2];
                     if (k + 3 < kend) x.w = ptr[p][3];
                 }
-                ptr[p] += BK;
             }
+            ptr[p] += BK;
             v[p] = x;
         }
         k += BK;
@@ -123,7 +131,9 @@ struct KInnerLoader {
     }
 };
 
-// ---- K-outer operand: BK x COLS tile copied into LDS [BK][COLS]; rows are the contraction index
+// ---- K-outer operand: BK x COLS tile copied into LDS [BK][COLS]; rows are the contraction index.
+//      Columns outside the matrix are clamped to column 0 on the aligned path (never stored);
+//      the unaligned path keeps per-element column tests (it must not read past a row's end).
 template <int COLS, bool ALIGNED>
 struct KOuterLoader {
     static constexpr int F4 = COLS / 4;                // float4 per tile row: 32 or 16
@@ -133,48 +143,49 @@ struct KOuterLoader {
     float4 v[PASSES];
     const float* ptr[PASSES];                          // plain-matrix mode: bumped by BK*ld per step
     long step;
-    int c4, kk0, c, kcur, ncols_;
+    int c4, kk0, c, cload, kcur, ncols_;
 
-    __device__ __forceinline__ void init(int tid) {
+    __device__ __forceinline__ void init(int tid, int col0, int ncols) {
         c4 = tid % F4;
         kk0 = tid / F4;
+        c = col0 + c4 * 4;
+        ncols_ = ncols;
+        cload = (ALIGNED && c >= ncols) ? 0 : c;       // clamped column used for addressing
     }
     // plain matrix: row k at base + k*ld
     __device__ __forceinline__ void init_plain(const float* base, long ld, int kbeg, int col0, int ncols, int tid) {
-        init(tid);
-        c = col0 + c4 * 4;
-        ncols_ = ncols;
+        init(tid, col0, ncols);
         kcur = kbeg + kk0;
         step = (long)BK * ld;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) ptr[p] = base + (long)(kcur + RPP * p) * ld + c;
+        for (int p = 0; p < PASSES; ++p) ptr[p] = base + (long)(kcur + RPP * p) * ld + cload;
     }
+    template <bool CHECK>
     __device__ __forceinline__ void load_plain(int kend) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            v[p] = fetch((kcur + RPP * p) < kend ? ptr[p] : nullptr, c, ncols_);
+            v[p] = fetch<CHECK>(ptr[p], (kcur + RPP * p) < kend);
             ptr[p] += step;
         }
         kcur += BK;
     }
     // implicit rows: caller supplies the per-pass row offsets (tracked incrementally)
+    template <bool CHECK>
     __device__ __forceinline__ void load_rows(const float* base, const long (&off)[PASSES],
-                                              const bool (&ok)[PASSES], int col0, int ncols) {
-        const int cc = col0 + c4 * 4;
+                                              const bool (&ok)[PASSES]) {
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) v[p] = fetch(ok[p] ? base + off[p] + cc : nullptr, cc, ncols);
+        for (int p = 0; p < PASSES; ++p) v[p] = fetch<CHECK>(base + off[p] + cload, ok[p]);
     }
-    __device__ __forceinline__ float4 fetch(const float* src, int cc, int ncols) const {
+    template <bool CHECK>
+    __device__ __forceinline__ float4 fetch(const float* src, bool row_ok) const {
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (src) {
-            if (ALIGNED) {
-                if (cc < ncols) x = *reinterpret_cast<const float4*>(src);
-            } else {
-                if (cc + 0 < ncols) x.x = src[0];
-                if (cc + 1 < ncols) x.y = src[1];
-                if (cc + 2 < ncols) x.z = src[2];
-                if (cc + 3 < ncols) x.w = src[3];
-            }
+        if (ALIGNED) {
+            if (!CHECK || row_ok) x = *reinterpret_cast<const float4*>(src);
+        } else if (!CHECK || row_ok) {
+            if (c + 0 < ncols_) x.x = src[0];
+            if (c + 1 < ncols_) x.y = src[1];
+            if (c + 2 < ncols_) x.z = src[2];
+            if (c + 3 < ncols_) x.w = src[3];
         }
         return x;
     }
@@ -278,25 +289,31 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
 
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        la.load(kend);
-        if (B_KINNER) lbi.load(kend);
-        else lbo.load_plain(kend);
+        la.template load<true>(kend);
+        if (B_KINNER) lbi.template load<true>(kend);
+        else lbo.template load_plain<true>(kend);
         la.store(As[0]);
         if (B_KINNER) lbi.store(Bs[0]);
         else lbo.store(Bs[0]);
     }
     __syncthreads();
 
+    // The prefetch of step kt targets tile kt+1; only the LAST tile can be partial, so interior
+    // prefetches carry no predicates (a wave-uniform scalar branch picks the variant).  One MMA
+    // site keeps the accumulators in place.
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            la.load(kend);
-            if (B_KINNER) lbi.load(kend);
-            else lbo.load_plain(kend);
+        if (kt + 2 < nk) {
+            la.template load<false>(kend);
+            if (B_KINNER) lbi.template load<false>(kend);
+            else lbo.template load_plain<false>(kend);
+        } else if (kt + 1 < nk) {
+            la.template load<true>(kend);
+            if (B_KINNER) lbi.template load<true>(kend);
+            else lbo.template load_plain<true>(kend);
         }
         mma_tile<MI, NJ, LDA, LDB>(As[cur], Bs[cur], wm, wn, lane, acc);
-        if (more) {
+        if (kt + 1 < nk) {
             la.store(As[cur ^ 1]);
             if (B_KINNER) lbi.store(Bs[cur ^ 1]);
             else lbo.store(Bs[cur ^ 1]);
@@ -394,8 +411,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* 
 
     LAo la;
     LBo lb;
-    la.init(tid);
-    lb.init(tid);
+    la.init(tid, i0, K1);
+    lb.init(tid, n0, N);
     // per-pass offset of the contraction row this thread fetches; advanced by BK rows per step with
     // adds only: off += BK*rs, and "+= bs - rpb*rs" whenever t crosses into the next utterance
     long am[LAo::PASSES], bm_[LBo::PASSES], aoff[LAo::PASSES], boff[LBo::PASSES];
@@ -419,30 +436,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* 
         bt[p] = (unsigned)bm_[p] - (Bd.batch == 1 ? 0u : bq * b_rpb);
         boff[p] = (long)bq * Bd.bs + (long)bt[p] * Bd.rs;
     }
-    auto fetch = [&]() {
-        bool oka[LAo::PASSES], okb[LBo::PASSES];
-        long offa[LAo::PASSES], offb[LBo::PASSES];
-#pragma unroll
-        for (int p = 0; p < LAo::PASSES; ++p) {
-            oka[p] = am[p] < mend;
-            offa[p] = aoff[p];
-            am[p] += BK;
-            at[p] += BK;
-            aoff[p] += a_step;
-            while (at[p] >= a_rpb) { at[p] -= a_rpb; aoff[p] += a_wrap; }
-        }
-#pragma unroll
-        for (int p = 0; p < LBo::PASSES; ++p) {
-            okb[p] = bm_[p] < mend;
-            offb[p] = boff[p];
-            bm_[p] += BK;
-            bt[p] += BK;
-            boff[p] += b_step;
-            while (bt[p] >= b_rpb) { bt[p] -= b_rpb; boff[p] += b_wrap; }
-        }
-        la.load_rows(A.base, offa, oka, i0, K1);
-        lb.load_rows(Bd.base, offb, okb, n0, N);
-    };
+    // CHECK = the tile may run past mend (only the last tile of the slice): row tests + zero fill
+#define LBX_TN_FETCH(CHECK)                                                             \
+    {                                                                                   \
+        bool oka[LAo::PASSES], okb[LBo::PASSES];                                        \
+        long offa[LAo::PASSES], offb[LBo::PASSES];                                      \
+        _Pragma("unroll") for (int p = 0; p < LAo::PASSES; ++p) {                       \
+            oka[p] = am[p] < mend;                                                      \
+            offa[p] = (CHECK && !oka[p]) ? 0 : aoff[p];                                 \
+            am[p] += BK;                                                                \
+            at[p] += BK;                                                                \
+            aoff[p] += a_step;                                                          \
+            while (at[p] >= a_rpb) { at[p] -= a_rpb; aoff[p] += a_wrap; }               \
+        }                                                                               \
+        _Pragma("unroll") for (int p = 0; p < LBo::PASSES; ++p) {                       \
+            okb[p] = bm_[p] < mend;                                                     \
+            offb[p] = (CHECK && !okb[p]) ? 0 : boff[p];                                 \
+            bm_[p] += BK;                                                               \
+            bt[p] += BK;                                                                \
+            boff[p] += b_step;                                                          \
+            while (bt[p] >= b_rpb) { bt[p] -= b_rpb; boff[p] += b_wrap; }               \
+        }                                                                               \
+        la.template load_rows<CHECK>(A.base, offa, oka);                                \
+        lb.template load_rows<CHECK>(Bd.base, offb, okb);                               \
+    }
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -456,26 +473,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* 
 
     const int nk = (int)((mend - mbeg + BK - 1) / BK);
     if (nk > 0) {
-        fetch();
+        LBX_TN_FETCH(true)
         la.store(As[0]);
         lb.store(Bs[0]);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) fetch();
+        if (kt + 2 < nk) LBX_TN_FETCH(false)
+        else if (kt + 1 < nk) LBX_TN_FETCH(true)
         mma_tile<MI, NJ, LAo::LD, LBo::LD>(As[cur], Bs[cur], wm, wn, lane, acc);
         if (do_csum) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) csum += Bs[cur][kk * LBo::LD + tid];
         }
-        if (more) {
+        if (kt + 1 < nk) {
             la.store(As[cur ^ 1]);
             lb.store(Bs[cur ^ 1]);
         }
         __syncthreads();
     }
+#undef LBX_TN_FETCH
     float* Pd = P + (long)split * K1 * N;
     const int h = lane >> 5, l = lane & 31;
 #pragma unroll
@@ -563,7 +581,7 @@ struct RowsChoice {
 // workgroup cannot (measured: 1 WG/CU keeps the pipe ~50 % busy, 3+ WG/CU ~90 %).
 const int CAND[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
 const double TILE_EFF[4] = {1.0, 0.95, 0.95, 0.88};      // staging traffic per flop grows as tiles shrink
-const int RESIDENT[4] = {BK == 16 ? 3 : 2, BK == 16 ? 4 : 3, BK == 16 ? 4 : 3, BK == 16 ? 6 : 4};   // workgroups per CU (VGPR / LDS limited)
+const int RESIDENT[4] = {BK == 16 ? 3 : 2, BK == 16 ? 6 : 3, BK == 16 ? 6 : 3, BK == 16 ? 8 : 4};   // workgroups per CU (VGPR / LDS limited)
 constexpr double FIXED_STEPS = 3.0;                      // prologue + epilogue of one tile, in K-steps
 
 inline double conc_eff(double w) {
