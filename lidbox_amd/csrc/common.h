@@ -36,12 +36,15 @@ void lidbox_set_error(const char* fmt, ...);
 
 static inline long lbx_cdiv(long a, long b) { return (a + b - 1) / b; }
 
-// LDS hand-off between lanes of ONE wave: DS instructions of a wave execute in order, so no
-// hardware wait is needed -- only the compiler must keep program order.
+// LDS hand-off between lanes of ONE wave: the DS instructions of a wave are issued and executed in
+// order, so a later ds_read observes an earlier ds_write of any lane without a hardware wait.
+// Only the COMPILER must keep program order -- a wavefront-scope fence would do that too, but it
+// lowers to s_waitcnt vmcnt(0) lgkmcnt(0) and serialises every hand-off behind all outstanding
+// global loads/stores.
 __device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -330,7 +330,7 @@ __device__ __forceinline__ void untangle(float2 zk, float2 zm, float2 w, float& 
 }
 
 template <int KIND, bool VEC4, bool POW2>
-__global__ __launch_bounds__(256) void fused_feat512_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS carve: tables, then one scratch block per wave
     float* s_win = reinterpret_cast<float*>(smem);                    // 2048 B
@@ -383,25 +383,36 @@ __global__ __launch_bounds__(256) void fused_feat512_kernel(const FusedArgs a) {
 
         // ---- 1. load + window.  lane q holds n2 = 2q (za) and 2q+1 (zb), n1 = 0..15:
         //         packed sample n = 16*n1 + n2  <->  reals 32*n1 + 4q .. +3
+        //         The loads are issued in two batches of 8 with NO control flow around them (a branch
+        //         per load makes the compiler wait for each one before issuing the next: 13 serialized
+        //         HBM round trips per tile): lanes whose samples lie outside the frame / utterance read
+        //         signals[0..3] instead and are zeroed by a select.
         float2 za[16], zb[16];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const int idx = 32 * n1 + 4 * q;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (32 * n1 < a.L) {                         // wave-uniform
+        for (int half = 0; half < 2; ++half) {
+            float4 x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = 32 * (8 * half + j) + 4 * q;
                 if (VEC4) {
-                    if (valid && idx < a.L) x = *reinterpret_cast<const float4*>(src + idx);
+                    x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : a.signals);
                 } else {
-                    if (valid && idx + 0 < a.L) x.x = src[idx + 0];
-                    if (valid && idx + 1 < a.L) x.y = src[idx + 1];
-                    if (valid && idx + 2 < a.L) x.z = src[idx + 2];
-                    if (valid && idx + 3 < a.L) x.w = src[idx + 3];
+                    const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : a.signals;
+                    const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : a.signals;
+                    const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : a.signals;
+                    const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : a.signals;
+                    x[j] = make_float4(*p0, *p1, *p2, *p3);
                 }
-                const float4 w = *reinterpret_cast<const float4*>(s_win + idx);
-                x.x *= w.x; x.y *= w.y; x.z *= w.z; x.w *= w.w;
             }
-            za[n1] = make_float2(x.x, x.y);
-            zb[n1] = make_float2(x.z, x.w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n1 = 8 * half + j;
+                const int idx = 32 * n1 + 4 * q;
+                const float4 w = *reinterpret_cast<const float4*>(s_win + idx);      // zero beyond L
+                za[n1] = make_float2((valid && idx + 0 < a.L) ? x[j].x * w.x : 0.f, (valid && idx + 1 < a.L) ? x[j].y * w.y : 0.f);
+                zb[n1] = make_float2((valid && idx + 2 < a.L) ? x[j].z * w.z : 0.f, (valid && idx + 3 < a.L) ? x[j].w * w.w : 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
@@ -493,10 +504,12 @@ __global__ __launch_bounds__(256) void fused_feat512_kernel(const FusedArgs a) {
         const int nvalid = min(8, a.T - t0);             // frames of this tile inside the utterance
         if (KIND == LIDBOX_FEAT_SPECTROGRAM) {
             float* dst = a.out + (long)b * a.out_bs + (long)t0 * 257;
-            const int total = nvalid * 257;
-            for (int i = lane; i < total; i += 64) {
-                const int ff = i / 257, k = i - ff * 257;
-                dst[i] = s_P[ff * P_STRIDE + k];
+            for (int ff = 0; ff < nvalid; ++ff) {
+#pragma unroll
+                for (int k0 = 0; k0 < 320; k0 += 64) {
+                    const int k = k0 + lane;
+                    if (k < 257) dst[ff * 257 + k] = s_P[ff * P_STRIDE + k];
+                }
             }
         } else {
             // ---- 7. banded mel: lane (f, q) owns bands q, q+8, ...

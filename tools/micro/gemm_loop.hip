@@ -60,6 +60,100 @@ __global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float*
     out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// Full loop with prefetch distance 2: loads for tile t+2 are issued at step t and written to LDS at step t+1,
+// so the end-of-step wait is for loads issued a whole step earlier.
+__global__ __launch_bounds__(256) void kloop_pf2(const float* __restrict__ g, float* out, int ksteps, long gstride) {
+    __shared__ __attribute__((aligned(16))) float As[2][16 * 130];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 16 * 130; i += 256) (&As[0][0])[i] = (float)(i & 7);
+    for (int i = tid; i < 2 * 16 * 128; i += 256) (&Bs[0][0])[i] = (float)(i & 3);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int h = lane >> 5, l = lane & 31, wm = wave >> 1, wn = wave & 1;
+    const int c4 = tid & 3, r0 = tid >> 2;
+    const float* gp = g + (long)(blockIdx.x >> 3) * gstride + (long)r0 * 1536 + c4 * 4;
+    const float* gb = g + (long)r0 * 1536 + c4 * 4;
+    float4 va0[2], vb0[2], va1[2], vb1[2];
+#define LOADSET(VA, VB) { VA[0] = *reinterpret_cast<const float4*>(gp); VA[1] = *reinterpret_cast<const float4*>(gp + 64 * 1536); \
+                          VB[0] = *reinterpret_cast<const float4*>(gb); VB[1] = *reinterpret_cast<const float4*>(gb + 64 * 1536); gp += 16; gb += 16; }
+#define STORESET(VA, VB, BUF) { float* da = As[BUF]; float* db = Bs[BUF]; \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) { float* d = da + (c4 * 4) * 130 + r0 + p * 64; d[0] = VA[p].x; d[130] = VA[p].y; d[260] = VA[p].z; d[390] = VA[p].w; } \
+        *reinterpret_cast<float4*>(db + ((tid >> 5)) * 128 + (tid & 31) * 4) = VB[0]; \
+        *reinterpret_cast<float4*>(db + ((tid >> 5) + 8) * 128 + (tid & 31) * 4) = VB[1]; }
+#define MMA(BUF) { const float* ap = As[BUF] + h * 130 + wm * 64 + l; const float* bp = Bs[BUF] + h * 128 + wn * 64 + l; \
+        _Pragma("unroll") for (int kk = 0; kk < 16; kk += 2) { \
+            const float ra0 = ap[kk * 130], ra1 = ap[kk * 130 + 32], rb0 = bp[kk * 128], rb1 = bp[kk * 128 + 32]; \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb0, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb1, acc[0][1], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb0, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb1, acc[1][1], 0, 0, 0); } }
+    LOADSET(va1, vb1)                       // tile 1 (tile 0 is already "in LDS")
+    for (int kt = 0; kt < ksteps; kt += 2) {
+        LOADSET(va0, vb0)                   // tile kt+2
+        MMA(0)
+        STORESET(va1, vb1, 1)               // tile kt+1, loaded one step ago
+        __syncthreads();
+        LOADSET(va1, vb1)                   // tile kt+3
+        MMA(1)
+        STORESET(va0, vb0, 0)               // tile kt+2
+        __syncthreads();
+    }
+    float s = va0[0].x + vb1[1].y;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+// Full loop, distance-1 prefetch, but the LDS stores of the next tile are issued in the MIDDLE of this
+// tile's MFMAs (after kk = SPLIT) so they execute in the shadow of the matrix pipe.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void kloop_mid(const float* __restrict__ g, float* out, int ksteps, long gstride) {
+    __shared__ __attribute__((aligned(16))) float As[2][16 * 130];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 16 * 130; i += 256) (&As[0][0])[i] = (float)(i & 7);
+    for (int i = tid; i < 2 * 16 * 128; i += 256) (&Bs[0][0])[i] = (float)(i & 3);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int h = lane >> 5, l = lane & 31, wm = wave >> 1, wn = wave & 1;
+    const int c4 = tid & 3, r0 = tid >> 2;
+    const float* gp = g + (long)(blockIdx.x >> 3) * gstride + (long)r0 * 1536 + c4 * 4;
+    const float* gb = g + (long)r0 * 1536 + c4 * 4;
+    float4 va[2], vb[2];
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const int cur = kt & 1;
+        va[0] = *reinterpret_cast<const float4*>(gp); va[1] = *reinterpret_cast<const float4*>(gp + 64 * 1536);
+        vb[0] = *reinterpret_cast<const float4*>(gb); vb[1] = *reinterpret_cast<const float4*>(gb + 64 * 1536);
+        gp += 16; gb += 16;
+        const float* ap = As[cur] + h * 130 + wm * 64 + l;
+        const float* bp = Bs[cur] + h * 128 + wn * 64 + l;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float ra0 = ap[kk * 130], ra1 = ap[kk * 130 + 32], rb0 = bp[kk * 128], rb1 = bp[kk * 128 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb1, acc[1][1], 0, 0, 0);
+            if (kk == SPLIT) {
+                __builtin_amdgcn_sched_barrier(0);
+                float* da = As[cur ^ 1]; float* db = Bs[cur ^ 1];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) { float* d = da + (c4 * 4) * 130 + r0 + p * 64; d[0] = va[p].x; d[130] = va[p].y; d[260] = va[p].z; d[390] = va[p].w; }
+                *reinterpret_cast<float4*>(db + ((tid >> 5)) * 128 + (tid & 31) * 4) = vb[0];
+                *reinterpret_cast<float4*>(db + ((tid >> 5) + 8) * 128 + (tid & 31) * 4) = vb[1];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    float s = va[0].x + vb[1].y;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int FEAT>
 static void run(const char* name, const float* g, float* out, int grid, int ksteps) {
     hipEvent_t e0, e1;
@@ -92,6 +186,25 @@ int main() {
         run<1 | 2 | 4>("+ barrier", g, out, grid, ksteps);
         run<1 | 2 | 4 | 16>("+ double-buffer toggle", g, out, grid, ksteps);
         run<1 | 2 | 4 | 8 | 16>("+ global loads (full loop)", g, out, grid, ksteps);
+        {
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            hipLaunchKernelGGL(kloop_pf2, dim3(grid), dim3(256), 0, 0, g, out, ksteps, 128L * 1536);
+            hipDeviceSynchronize(); hipEventRecord(e0);
+            for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kloop_pf2, dim3(grid), dim3(256), 0, 0, g, out, ksteps, 128L * 1536);
+            hipEventRecord(e1); hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+            const double fl = (double)grid * 4 * ksteps * 8 * 4 * 4096.0;
+            printf("  %-52s %8.1f us  %6.1f TF/s\n", "full loop, prefetch distance 2 (unroll x2)", ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12);
+        }
+#define RUNK(KERN, NAME) { hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); \
+            hipLaunchKernelGGL(KERN, dim3(grid), dim3(256), 0, 0, g, out, ksteps, 128L * 1536); \
+            hipDeviceSynchronize(); hipEventRecord(e0); \
+            for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(KERN, dim3(grid), dim3(256), 0, 0, g, out, ksteps, 128L * 1536); \
+            hipEventRecord(e1); hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); \
+            const double fl = (double)grid * 4 * ksteps * 8 * 4 * 4096.0; \
+            printf("  %-52s %8.1f us  %6.1f TF/s\n", NAME, ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12); }
+        RUNK(kloop_mid<6>, "full loop, LDS stores after kk=6 (mid-MMA)")
+        RUNK(kloop_mid<10>, "full loop, LDS stores after kk=10")
+        RUNK(kloop_mid<14>, "full loop, LDS stores after kk=14 (end, ref)")
         run<1 | 4 | 8 | 16>("full minus LDS stores", g, out, grid, ksteps);
         run<1 | 2 | 8 | 16>("full minus barrier", g, out, grid, ksteps);
     }
