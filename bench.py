@@ -117,6 +117,30 @@ class KernelTimer:
         return out
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of `kernel_key` from the newest committed PMC summary (profiles/*traffic*.json,
+    produced by tools/traffic_from_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    same command).  bench.py cannot run rocprofv3 on itself, so this is read back, not measured live."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")))
+    if not files:
+        return None
+    try:
+        kern = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    m = re.match(r"gemm_rows_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
+    if m:
+        name = "gemm_rows_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), "true" if m.group(3) == "NT" else "false")
+    elif kernel_key.startswith("gemm_tn_kernel<"):
+        name = kernel_key[:-1] + ", true>"
+    else:
+        name = "fused_feat512_kernel<2, true, true>"
+    v = kern.get(name)
+    return int(v["hbm_bytes_per_launch"]) if v else None
+
+
 def cpu_baseline(seconds, batch=64):
     """oracle/torch_ref.py train step on the host cores, bounded sample.  torch-CPU does not scale past a
     few dozen threads on this workload (256 threads is 10x SLOWER than 16 on the 2 x 64-core host), so the
@@ -242,7 +266,7 @@ def main():
             ach = d["rate"] / 1e12
             result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
                                   "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
                                   "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
                                   "note": "HIP-event bracket per launch (includes the split-K reduce kernel where one "
@@ -260,7 +284,7 @@ def main():
                 gbs = f["rate"] / 1e9
                 result["roofline_feature"] = {"kernel": "fused_feat512_kernel", "bound": "hbm", "achieved": round(gbs, 1),
                                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                              "traffic": None, "avg_launch_us": round(f["avg_us"], 2),
+                                              "traffic": pmc_traffic("fused_feat512_kernel"), "avg_launch_us": round(f["avg_us"], 2),
                                               "bytes_per_launch": int(f["work_per_launch"])}
         # whole-step view of the same roofline: algorithmic train flops / step time
         result["step_tflops"] = round(value / world * FLOPS_PER_UTT_TRAIN / 1e12, 2)
