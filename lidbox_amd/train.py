@@ -157,6 +157,7 @@ class Trainer:
         bounds, self.split_conv = plan_buckets(model, num_buckets)
         self.sync = GradSync(model.flat_grad, bounds, group)
         self.use_graph = bool(use_graph)
+        self._warming = False            # True during the pre-capture warm-up pass: streaming metrics must not count it
         self._graphs = {}
         self._static = {}
 
@@ -199,9 +200,9 @@ class Trainer:
                                                 1.0 / B, nv.ptr(per), nv.ptr(dzn), st))
             nv.check(lib.lidbox_l2_normalize_bwd(nv.ptr(out), nv.ptr(dzn), B, D, nv.ptr(ws.dh[-1]), st))
             ws.loss[0:1].copy_(per.mean(dim=0, keepdim=True))
-            if self.metric is not None:
+            if self.metric is not None and not self._warming:
                 self.metric._update_sparse(labels, -torch.acos(zn[:, :self.ap.N]))
-        if self.loss_kind == "nll" and self.metric is not None:
+        if self.loss_kind == "nll" and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)
 
     def _ap_buffers(self, ws, D):
@@ -256,9 +257,13 @@ class Trainer:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                # warm-up on a side stream (required before capture); keeps optimizer state untouched
-                seg_a()
-                seg_b()
+                # warm-up on a side stream (required before capture); keeps optimizer and metric state untouched
+                self._warming = True
+                try:
+                    seg_a()
+                    seg_b()
+                finally:
+                    self._warming = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(self.device)
             if self.sync.active:

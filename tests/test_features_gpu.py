@@ -209,3 +209,26 @@ def test_errors_raise():
         tf_utils.extract_features(torch.zeros(2, 1000), [16000, 16000], "spectrogram")    # CPU tensor: no fallback
     with pytest.raises(FloatingPointError):
         tf_utils.extract_features(torch.full((1, 1000), float("nan"), device="cuda"), [16000], "spectrogram")
+
+
+def test_steps_extract_features_config_surface(synth):
+    """reference lidbox/data/steps.py:708-736 config schema: batch -> features -> unbatch, adds input + feature_type"""
+    from lidbox_amd.data import steps
+    sig, labels = synth
+    ds = [dict(id="utt%d" % i, signal=sig[i], sample_rate=16000, target=int(labels[i])) for i in range(len(sig))]
+    config = {"type": "mfcc", "spectrogram": {"frame_length_ms": 25, "frame_step_ms": 10, "fft_length": 512},
+              "melspectrogram": {"num_mel_bins": 40, "fmin": 20.0, "fmax": 7000.0}, "mfcc": {"coef_begin": 1, "coef_end": 14},
+              "window_normalization": {"window_len": -1, "normalize_variance": True}, "batch_size": 4}
+    out = list(steps.extract_features(ds, config))
+    assert [o["id"] for o in out] == [d["id"] for d in ds]
+    ref = fo.extract_features(sig, [16000] * len(sig), "mfcc", melspec_kwargs=config["melspectrogram"],
+                              mfcc_kwargs=config["mfcc"], window_norm_kwargs=config["window_normalization"])
+    for o, r in zip(out, ref):
+        assert o["feature_type"] == "mfcc" and tuple(o["input"].shape) == (198, 13)
+        assert np.abs(o["input"].cpu().numpy() - r).max() <= 2e-3
+    # group_by_input_length: ragged signals end up in same-length batches
+    ragged = [dict(signal=sig[i][:n], sample_rate=16000) for i, n in enumerate([8000, 16000, 8000, 16000, 8000, 4000])]
+    got = list(steps.extract_features(ragged, {"type": "logmelspectrogram", "group_by_input_length": {"max_batch_size": 2}}))
+    assert sorted(o["input"].shape[0] for o in got) == sorted([48, 98, 48, 98, 48, 23])
+    with pytest.raises(ValueError):
+        list(steps.extract_features(ds, {"type": "spectrogram", "device": "/CPU"}))

@@ -223,3 +223,67 @@ def test_angular_proximity_head_train_step():
         assert np.abs(m.param(k, grad=True).cpu().numpy() - rg).max() <= 2e-3 * np.abs(rg).max(), k
     l0 = float(t.train_step(_dev(x), _dev(y, np.int32)))
     assert np.isfinite(l0) and 0.0 <= float(metric.result()) <= 1.0
+
+
+def test_config4_mfcc_cmvn_cnn_train_step():
+    """BASELINE configs[3]: MFCC(1:13) + CMVN front-end -> lidbox.models.cnn, train step from waveforms"""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import cnn
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    sig, y = synthetic_batch(6, num_labels=4, duration_s=1.0)
+    sd, yd = _dev(sig), _dev(y, np.int32)
+    m = cnn.create((98, 12), 4, seed=5)
+    plan = audio.get_plan(16000, 400, 160)
+    t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_MFCC, cmvn=True), use_graph=True)
+    # oracle: MFCC + CMVN (window_len=-1) -> cnn forward -> sparse CE
+    feats = fo.extract_features(sig, [16000] * 6, "mfcc", window_norm_kwargs=dict(window_len=-1, normalize_variance=True))
+    assert feats.shape == (6, 98, 12)
+    ref_loss = mo.sparse_ce_from_logits(mo.cnn_fwd(_oracle_params(m), feats), y)
+    l0 = float(t.train_step(sd, yd))
+    assert abs(l0 - ref_loss) <= 2e-4 * abs(ref_loss), (l0, ref_loss)
+    for _ in range(15):
+        l1 = float(t.train_step(sd, yd))
+    assert np.isfinite(l1) and l1 < l0
+
+
+def test_config5_xvector_ap_cavg_100_languages():
+    """BASELINE configs[4] in fp32: x-vector trunk -> segment1 (affine, D=512) -> L2 norm ->
+    SparseAngularProximity(N=100) + C_avg(100 thresholds on -theta), one train step from waveforms"""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.losses import SparseAngularProximity
+    from lidbox_amd.metrics import SparseAverageDetectionCost
+    from lidbox_amd.models import xvector
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    N, D, B = 100, 512, 16
+    sig, y = synthetic_batch(B, num_labels=N, duration_s=0.5)
+    convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
+             xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
+             xvector.frame_layer(1500, 1, 1, name="frame5")]
+    m = SequentialTDNN((48, 40), convs, "stats", [DenseSpec("segment1", D, relu=False)], output_activation=None, seed=0)
+    metric = SparseAverageDetectionCost(N, np.linspace(-np.pi, 0, 100))
+    t = Trainer(m, loss=SparseAngularProximity(N, D), feature=dict(plan=audio.get_plan(16000, 400, 160), kind=nv.FEAT_LOGMEL),
+                use_graph=True, metric=metric)
+    sd, yd = _dev(sig), _dev(y, np.int32)
+    # oracle loss at step 0
+    feats = fo.extract_features(sig, [16000] * B, "logmelspectrogram")
+    p = _oracle_params(m)
+    h = feats
+    for name, f, k, s_ in mo.XVECTOR_FRAMES:
+        h = mo.conv1d_causal_fwd(h, p[name + ".W"], p[name + ".b"], s_)
+    z = mo.dense_fwd(mo.stats_pool_fwd(h), p["segment1.W"], p["segment1.b"], relu=False)
+    ref = mo.ap_loss(y, mo.l2_normalize(z), N)
+    l0 = float(t.train_step(sd, yd))
+    assert abs(l0 - ref) <= 1e-4 * abs(ref), (l0, ref)
+    for _ in range(5):
+        l1 = float(t.train_step(sd, yd))
+    assert np.isfinite(l1) and l1 < l0
+    c = float(metric.result())
+    assert 0.0 <= c <= 1.0
+    # 6 steps x B examples x 100 thresholds: each example lands in tp or fn of its label once per threshold
+    # (and the pre-capture warm-up pass must NOT have been counted)
+    assert float(metric.tp.sum() + metric.fn.sum()) == 6 * B * 100

@@ -154,11 +154,68 @@ __global__ __launch_bounds__(256) void kloop_mid(const float* __restrict__ g, fl
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// wgrad-like loop: BOTH operands are K-outer tiles [16][128] copied without transposition.
+// DMA = false: global -> VGPR -> ds_write_b128 (what gemm_tn_kernel does)
+// DMA = true : global_load_lds (LDS-DMA, 16 B per lane, no VGPR round trip, no ds_write)
+template <bool DMA>
+__global__ __launch_bounds__(256) void kloop_tn(const float* __restrict__ g, float* out, int ksteps, long gstride) {
+    __shared__ __attribute__((aligned(16))) float As[2][16 * 128];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 16 * 128; i += 256) { (&As[0][0])[i] = (float)(i & 7); (&Bs[0][0])[i] = (float)(i & 3); }
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int h = lane >> 5, l = lane & 31, wm = wave >> 1, wn = wave & 1;
+    // thread -> (row kk0 (+8), float4 column c4) of the 16 x 128 tile; rows of the source are 1536 floats apart
+    const int c4 = tid & 31, kk0 = tid >> 5;
+    const float* ga = g + (long)(blockIdx.x >> 3) * gstride + (long)kk0 * 1536 + c4 * 4;
+    const float* gb = g + (long)kk0 * 1536 + 512 + c4 * 4;
+    float4 va[2], vb[2];
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        if (DMA) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                // wave w, pass p covers tile rows 2w + 8p .. +1  (LDS destination = wave-uniform base + lane*16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + (long)p * 8 * 1536),
+                                                 (__attribute__((address_space(3))) void*)(&As[nxt][(2 * wave + 8 * p) * 128]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long)p * 8 * 1536),
+                                                 (__attribute__((address_space(3))) void*)(&Bs[nxt][(2 * wave + 8 * p) * 128]), 16, 0, 0);
+            }
+        } else {
+            va[0] = *reinterpret_cast<const float4*>(ga); va[1] = *reinterpret_cast<const float4*>(ga + 8 * 1536);
+            vb[0] = *reinterpret_cast<const float4*>(gb); vb[1] = *reinterpret_cast<const float4*>(gb + 8 * 1536);
+        }
+        ga += 16 * 1536; gb += 16 * 1536;
+        const float* ap = As[cur] + h * 128 + wm * 64 + l;
+        const float* bp = Bs[cur] + h * 128 + wn * 64 + l;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float ra0 = ap[kk * 128], ra1 = ap[kk * 128 + 32], rb0 = bp[kk * 128], rb1 = bp[kk * 128 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb1, acc[1][1], 0, 0, 0);
+        }
+        if (!DMA) {
+            *reinterpret_cast<float4*>(&As[nxt][kk0 * 128 + c4 * 4]) = va[0];
+            *reinterpret_cast<float4*>(&As[nxt][(kk0 + 8) * 128 + c4 * 4]) = va[1];
+            *reinterpret_cast<float4*>(&Bs[nxt][kk0 * 128 + c4 * 4]) = vb[0];
+            *reinterpret_cast<float4*>(&Bs[nxt][(kk0 + 8) * 128 + c4 * 4]) = vb[1];
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int FEAT>
 static void run(const char* name, const float* g, float* out, int grid, int ksteps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const long gstride = 128L * 1536;
+    const long gstride = 128L * 1536;   // (kloop_tn walks 1536 rows of 1536 floats: stays inside the 1.5 GB buffer)
     hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride);
     hipDeviceSynchronize();
     hipEventRecord(e0);
@@ -202,6 +259,8 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); \
             const double fl = (double)grid * 4 * ksteps * 8 * 4 * 4096.0; \
             printf("  %-52s %8.1f us  %6.1f TF/s\n", NAME, ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12); }
+        RUNK(kloop_tn<false>, "wgrad-like loop, register staging + ds_write_b128")
+        RUNK(kloop_tn<true>, "wgrad-like loop, global_load_lds (LDS-DMA)")
         RUNK(kloop_mid<6>, "full loop, LDS stores after kk=6 (mid-MMA)")
         RUNK(kloop_mid<10>, "full loop, LDS stores after kk=10")
         RUNK(kloop_mid<14>, "full loop, LDS stores after kk=14 (end, ref)")
