@@ -248,7 +248,7 @@ __device__ __forceinline__ float apply_epi(float v, int epi, float bias, const f
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool B_KINNER, bool ALIGNED>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
-                                                        RowsOutD Cd, float* __restrict__ P, long M, int K,
+                                                        RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K,
                                                         int N, int epi, const float* __restrict__ aux,
                                                         int tiles_n, unsigned ntiles, int k_per_split) {
     constexpr int MI = BM / 64, NJ = BN / 64;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
     const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
     const int tn = chunk % tiles_n;
     const long tm = chunk / tiles_n;
-    const long m0 = tm * BM;
+    const long m0 = m_beg + tm * BM;            // this launch covers rows [m_beg, M)
     const int n0 = tn * BN;
     const int split = blockIdx.y;
     const int kbeg = split * k_per_split;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
         colok[bj] = col[bj] < N;
         bias[bj] = (has_bias && colok[bj]) ? aux[col[bj]] : 0.f;
     }
-    float* const out_base = partial ? P + (long)split * M * N : Cd.base;
+    float* const out_base = partial ? P + ((long)split * (M - m_beg) - m_beg) * N : Cd.base;   // P[split][row - m_beg][n]
     const long out_rs = partial ? (long)N : Cd.rs;
     const bool batched = !partial && Cd.batch != 1;
 #pragma unroll
@@ -369,16 +369,16 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
     }
 }
 
-// C rows = epi( sum_s P[s][M][N] ), fixed order
-__global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long M, int N, RowsOutD Cd,
+// C rows [m_beg, m_beg + Msub) = epi( sum_s P[s][Msub][N] ), fixed order
+__global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long m_beg, long Msub, int N, RowsOutD Cd,
                                    int epi, const float* __restrict__ aux) {
-    const long total = M * N;
+    const long total = Msub * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += P[(long)k * total + i];
         const long row = i / N;
         const int col = (int)(i - row * N);
-        const long off = row_offset(Cd, (unsigned)row);
+        const long off = row_offset(Cd, (unsigned)(m_beg + row));
         const float bias = (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU) ? aux[col] : 0.f;
         float* dst = Cd.base + off + col;
         *dst = apply_epi(s, epi, bias, aux, off + col, dst);
@@ -621,38 +621,25 @@ RowsChoice choose_rows(long M, int N, int K, size_t ws_bytes) {
 
 template <int BM, int BN, bool B_KINNER>
 void launch_rows_t(bool al, dim3 grid, hipStream_t st, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, float* P,
-                   long M, int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps) {
+                   long m_beg, long m_end, int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps) {
     if (al)
-        hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, B_KINNER, true>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, M,
-                           K, N, epi, aux, tiles_n, ntiles, kps);
+        hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, B_KINNER, true>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, m_beg,
+                           m_end, K, N, epi, aux, tiles_n, ntiles, kps);
     else
-        hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, B_KINNER, false>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, M,
-                           K, N, epi, aux, tiles_n, ntiles, kps);
+        hipLaunchKernelGGL((gemm_rows_kernel<BM, BN, B_KINNER, false>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, m_beg,
+                           m_end, K, N, epi, aux, tiles_n, ntiles, kps);
 }
 
+// one launch (+ its split-K reduce) over the row range [m_beg, m_end) with a given decomposition
 template <bool B_KINNER>
-int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd, int K, int N, int epi,
-                const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
-    const long M = (long)A.batch * A.rows_per_batch;
-    if (M == 0 || N == 0) return LIDBOX_OK;
-    RowsChoice ch = choose_rows(M, N, K, ws ? ws_bytes : 0);
-    if (const char* f = getenv("LIDBOX_GEMM_TILE")) {             // tuning aid: "128x128" etc.
-        int bm = 0, bn = 0;
-        if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
-            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K;
-            if (BK > 16 && bm == 128 && bn == 128) ch.bn = 64;
-        }
-    }
+int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, long m_beg,
+                      long m_end, int K, int N, int epi, const float* aux, float* P, hipStream_t st) {
+    const long Msub = m_end - m_beg;
+    if (Msub <= 0) return LIDBOX_OK;
     const int tiles_n = (int)lbx_cdiv(N, ch.bn);
-    const long ntiles = lbx_cdiv(M, ch.bm) * tiles_n;
-    // float4 paths: A rows and K multiple of 4; B: NN needs N%4 (columns), NT needs K%4 (rows)
-    const bool al = rows_aligned(A) && K % 4 == 0 && aligned16(Bm) && ldb % 4 == 0 &&
-                    (B_KINNER ? true : N % 4 == 0);
-    RowsD Ad = to_dev(A);
-    RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    const long ntiles = lbx_cdiv(Msub, ch.bm) * tiles_n;
     dim3 grid((unsigned)ntiles, (unsigned)ch.splits);
-    float* P = (float*)ws;
-#define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+#define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
 #if LBX_GEMM_BK == 16
     if (ch.bm == 128 && ch.bn == 128) LBX_ROWS(128, 128);
     else
@@ -663,13 +650,71 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
 #undef LBX_ROWS
     LBX_LAUNCH_OK();
     if (ch.splits > 1) {
-        long g = lbx_cdiv(M * N, 256);
+        long g = lbx_cdiv(Msub * N, 256);
         if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, ch.splits, M, N,
-                           Co, epi, aux);
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, ch.splits, m_beg,
+                           Msub, N, Co, epi, aux);
         LBX_LAUNCH_OK();
     }
     return LIDBOX_OK;
+}
+
+inline int cand_index(int bm, int bn) { return bm == 128 ? (bn == 128 ? 0 : 1) : (bn == 128 ? 2 : 3); }
+
+template <bool B_KINNER>
+int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd, int K, int N, int epi,
+                const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long M = (long)A.batch * A.rows_per_batch;
+    if (M == 0 || N == 0) return LIDBOX_OK;
+    const size_t wsb = ws ? ws_bytes : 0;
+    RowsChoice ch = choose_rows(M, N, K, wsb);
+    if (const char* f = getenv("LIDBOX_GEMM_TILE")) {             // tuning aid: "128x128" etc.
+        int bm = 0, bn = 0;
+        if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K;
+            if (BK > 16 && bm == 128 && bn == 128) ch.bn = 64;
+        }
+    }
+    // float4 paths: A rows and K multiple of 4; B: NN needs N%4 (columns), NT needs K%4 (rows)
+    const bool al = rows_aligned(A) && K % 4 == 0 && aligned16(Bm) && ldb % 4 == 0 &&
+                    (B_KINNER ? true : N % 4 == 0);
+    RowsD Ad = to_dev(A);
+    RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    float* P = (float*)ws;
+
+    // Tail quantisation: with W workgroups on 256 CUs the last partial round runs at the pace of a
+    // full one (measured: the last 3 % of frame2's rows cost 21 % of its time).  When the main
+    // decomposition is unsplit and leaves such a tail, launch it over the largest row prefix whose
+    // workgroup count is a whole number of rounds, and hand the few remaining rows to a second
+    // launch planned on its own (small tiles, split along K) -- if the cost model agrees.
+    static const bool no_tail_split = getenv("LIDBOX_GEMM_NO_TAIL_SPLIT") != nullptr;
+    if (!no_tail_split && ch.splits == 1) {
+        const int tiles_n = (int)lbx_cdiv(N, ch.bn);
+        const long tiles_m = lbx_cdiv(M, ch.bm);
+        const long wgs = tiles_m * tiles_n;
+        const long rounds = wgs / NUM_CU;                       // whole rounds
+        if (rounds >= 1 && wgs % NUM_CU != 0) {
+            const long main_tiles_m = rounds * NUM_CU / tiles_n;  // row tiles of the prefix (rounded down)
+            const long m_main = main_tiles_m * ch.bm;
+            const long m_rem = M - m_main;
+            if (main_tiles_m >= 1 && m_rem > 0) {
+                const RowsChoice rem = choose_rows(m_rem, N, K, wsb);
+                const int c = cand_index(ch.bm, ch.bn), cr = cand_index(rem.bm, rem.bn);
+                const double ksteps = (double)lbx_cdiv(K, BK);
+                const double whole = launch_cost(c, wgs, ksteps);
+                double split = launch_cost(c, main_tiles_m * tiles_n, ksteps) + 4.0 +
+                               launch_cost(cr, lbx_cdiv(m_rem, rem.bm) * lbx_cdiv(N, rem.bn) * rem.splits,
+                                           (double)rem.k_per_split / BK);
+                if (rem.splits > 1) split += 5.0 + (double)m_rem * N * 4.0 * (rem.splits + 1) / 3.0e6;
+                if (split < 0.97 * whole) {
+                    int rc = launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, m_main, K, N, epi, aux, P, st);
+                    if (rc) return rc;
+                    return launch_rows_range<B_KINNER>(rem, al, Ad, Bm, ldb, Co, m_main, M, K, N, epi, aux, P, st);
+                }
+            }
+        }
+    }
+    return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st);
 }
 
 int check_rows(const char* fn, const void* base, long bs, long rs, int batch, int rpb) {
