@@ -287,3 +287,47 @@ def test_config5_xvector_ap_cavg_100_languages():
     # 6 steps x B examples x 100 thresholds: each example lands in tp or fn of its label once per threshold
     # (and the pre-capture warm-up pass must NOT have been counted)
     assert float(metric.tp.sum() + metric.fn.sum()) == 6 * B * 100
+
+
+def test_xvector_extended_matches_oracle_forward_and_backward():
+    """reference xvector_extended.py:22-43 -- strides 1/2/3/4, incl. k=3 with stride 4"""
+    from lidbox_amd.models import xvector_extended
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(21)
+    B, T, C, N = 3, 130, 20, 6
+    x = rng.standard_normal((B, T, C))
+    y = rng.integers(0, N, size=B).astype(np.int32)
+    m = xvector_extended.create((T, C), N, seed=9)
+    assert [c.name for c in m.convs] == ["frame%d" % i for i in range(1, 11)]
+    rngb = np.random.default_rng(22)
+    m.set_weights({k: rngb.standard_normal(v.shape) * 0.05 for k, v in m.get_weights().items() if k.endswith(".b")})
+    p = _oracle_params(m)
+    # oracle forward / backward through the generic conv + pool + dense restatement
+    acts, h = [x], x
+    for (f, k, s_), c in zip(xvector_extended.FRAMES, m.convs):
+        h = mo.conv1d_causal_fwd(h, p[c.name + ".W"], p[c.name + ".b"], s_)
+        acts.append(h)
+    assert [a.shape[1] for a in acts] == [130, 130, 130, 65, 65, 22, 22, 6, 6, 6, 6]
+    pooled = mo.stats_pool_fwd(h)
+    s1 = mo.dense_fwd(pooled, p["segment1.W"], p["segment1.b"])
+    s2 = mo.dense_fwd(s1, p["segment2.W"], p["segment2.b"])
+    z = mo.dense_fwd(s2, p["output.W"], p["output.b"], relu=False)
+    logp = mo.log_softmax(z)
+    got = m(_dev(x)).cpu().numpy()
+    assert np.abs(got - logp).max() < 1e-3
+    ref_loss = mo.sparse_ce_from_logits(logp, y)
+    dz = mo.sparse_ce_from_logits_grad(logp, y)
+    g = {}
+    dh, g["output.W"], g["output.b"] = mo.dense_bwd(s2, p["output.W"], z, dz, relu=False)
+    dh, g["segment2.W"], g["segment2.b"] = mo.dense_bwd(s1, p["segment2.W"], s2, dh)
+    dh, g["segment1.W"], g["segment1.b"] = mo.dense_bwd(pooled, p["segment1.W"], s1, dh)
+    dh = mo.stats_pool_bwd(acts[-1], dh)
+    for i in range(9, -1, -1):
+        c = m.convs[i]
+        dh, g[c.name + ".W"], g[c.name + ".b"] = mo.conv1d_causal_bwd(acts[i], p[c.name + ".W"], acts[i + 1], dh,
+                                                                       xvector_extended.FRAMES[i][2], need_dx=(i > 0))
+    loss, _ = Trainer(m, use_graph=False).loss_and_grads(_dev(x), _dev(y, np.int32))
+    assert abs(float(loss) - ref_loss) <= 1e-4 * abs(ref_loss)
+    for name, ref in g.items():
+        gotg = m.param(name, grad=True).cpu().numpy()
+        assert np.abs(gotg - ref).max() <= 1e-3 * max(1e-12, np.abs(ref).max()), name
