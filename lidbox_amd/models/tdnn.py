@@ -91,6 +91,7 @@ class _Workspace:
                            nv.lib.lidbox_gemm_rows_workspace(B, din, d.units))
             din = d.units
         self.gemm_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self.gemm_ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)     # wgrad side stream's own workspace
 
     def input_view(self):
         """[B, T, C0] view of act[0] behind its causal zero rows."""
@@ -133,6 +134,9 @@ class SequentialTDNN:
         self.flat_grad = torch.zeros_like(self.flat)
         self._init_weights(seed)
         self._ws = {}
+        # optional second HIP stream: wgrad GEMMs run on it concurrently with the dgrad chain (they only
+        # share read-only inputs), which fills the tail rounds and the nearly empty dense-layer launches
+        self.wgrad_stream = None
 
     # ------------------------------------------------------------------ parameters
     def _init_weights(self, seed):
@@ -231,11 +235,28 @@ class SequentialTDNN:
         return ws.logp
 
     # ------------------------------------------------------------------ backward
+    def _launch_wgrad(self, ws, launch):
+        """launch(workspace_ptr, workspace_bytes, stream): on the side stream (after everything enqueued so
+        far on the current stream) when one is configured, else inline."""
+        side = self.wgrad_stream
+        if side is None:
+            launch(nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), nv.current_stream())
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch(nv.ptr(ws.gemm_ws2), ws.gemm_ws2.numel(), nv.current_stream())
+
+    def join_wgrad(self):
+        """make the side stream's wgrad results visible to the current stream"""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
     def backward_ws(self, ws):
         """dh[-1] must hold d loss / d logits.  Fills flat_grad (overwrites)."""
         self.backward_head_ws(ws)
         for i in range(len(self.convs) - 1, -1, -1):
             self.backward_conv_ws(ws, i)
+        self.join_wgrad()
 
     def backward_head_ws(self, ws):
         """dense chain + pooling backward: fills the dense gradients and dact[-1]."""
@@ -249,8 +270,9 @@ class SequentialTDNN:
             x = ws.pooled if j == 0 else ws.h[j - 1]
             din = x.shape[1]
             dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
-            nv.check(lib.lidbox_gemm_tn(_rows(x.data_ptr(), 0, din, 1, B), dy, self._p(d.name + ".W", True),
-                                        d.units, din, d.units, 0, self._p(d.name + ".b", True), gws, gws_n, st))
+            A_rows = _rows(x.data_ptr(), 0, din, 1, B)
+            self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(lib.lidbox_gemm_tn(
+                A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)))
             dst = ws.dpooled if j == 0 else ws.dh[j - 1]
             relu_prev = j > 0 and self.denses[j - 1].relu
             nv.check(lib.lidbox_gemm_nt(dy, self._p(d.name + ".W"), d.units,
@@ -283,8 +305,9 @@ class SequentialTDNN:
             self.param(c.name + ".b", True).zero_()
             return
         dy = self._rows_out(ws.dact[i + 1], ws, i + 1)
-        nv.check(lib.lidbox_gemm_tn(self._conv_rows_in(ws, i), dy, self._p(c.name + ".W", True), c.filters,
-                                    K, c.filters, 0, self._p(c.name + ".b", True), gws, gws_n, st))
+        A_rows = self._conv_rows_in(ws, i)
+        self._launch_wgrad(ws, lambda w, n, s_: nv.check(lib.lidbox_gemm_tn(
+            A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
         if i == 0:
             return
         # dgrad into dact[i].  Window t touches padded rows [t*s, t*s+k).  Group g = taps
