@@ -29,7 +29,7 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("LIDBOX_FORCE_GRAD_SYNC")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -66,6 +66,8 @@ class GradSync:
         assert self.bounds[0] == 0 and self.bounds[-1] == flat.numel()
         assert all(a < b for a, b in zip(self.bounds, self.bounds[1:]))
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if os.environ.get("LIDBOX_FORCE_GRAD_SYNC") and dist.is_available() and dist.is_initialized():
+            self.active = True           # test aid: exercise the collective path even at world_size 1
         self.world = dist.get_world_size(group) if self.active else 1
         self.cuda = flat.is_cuda
         self.side = torch.cuda.Stream(device=flat.device) if (self.cuda and self.active) else None

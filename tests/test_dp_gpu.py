@@ -103,3 +103,20 @@ def test_two_rank_step_equals_single_process_step(tmp_path, use_graph):
     assert np.median(diff) <= 1e-6, np.median(diff)
     assert (diff > 2e-4).mean() <= 1e-3, (diff > 2e-4).mean()
     assert diff.max() <= 3 * 2e-3 + 1e-6                       # never more than 3 steps of +-lr apart
+
+
+def test_rccl_backend_between_graph_segments_world1():
+    """The real RCCL backend (nccl) on the one GPU there is: world_size 1 with the collective path forced on,
+    so init_process_group('nccl'), the side-stream all_reduce launches and the three-segment hipGraph replay are
+    all exercised exactly as in the N-GPU bench (the reduction itself is the identity at world 1)."""
+    import json
+    env = dict(os.environ, LIDBOX_FORCE_GRAD_SYNC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--batch", "32", "--no-cpu-baseline", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 1 and r["steps"] == 5 and r["value"] > 0
+    assert np.isfinite(r["config"]["final_loss"])

@@ -211,6 +211,55 @@ __global__ __launch_bounds__(256) void kloop_tn(const float* __restrict__ g, flo
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// NN-like loop where the B (weights, [K][N], L2-resident) operand never touches LDS: each lane loads its
+// MFMA B registers directly (lanes 0-31 / 32-63 read two 128-byte rows: coalesced dwords), one K-step ahead.
+// A (activations, K-inner) still goes global -> VGPR -> transposed LDS tile.
+__global__ __launch_bounds__(256) void kloop_bdirect(const float* __restrict__ g, float* out, int ksteps, long gstride) {
+    __shared__ __attribute__((aligned(16))) float As[2][16 * 130];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 16 * 130; i += 256) (&As[0][0])[i] = (float)(i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int h = lane >> 5, l = lane & 31, wm = wave >> 1, wn = wave & 1;
+    const int c4 = tid & 3, r0 = tid >> 2;
+    const float* gp = g + (long)(blockIdx.x >> 3) * gstride + (long)r0 * 1536 + c4 * 4;
+    // B: row k has 512 floats (ldb = 512); this lane's column n = (blockIdx&7)*64?  use wn*64 + l (+32)
+    const float* gb = g + 4096 + (long)h * 512 + (blockIdx.x & 7) * 64 + wn * 32 + l;   // 64-wide n tile: NJ = 1 per wave half... keep 2 regs
+    float bcur[16], bnxt[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bcur[i] = gb[(long)(i >> 1) * 2 * 512 + (i & 1) * 32];
+    gb += 16 * 512;
+    float4 va[2];
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const int cur = kt & 1;
+        va[0] = *reinterpret_cast<const float4*>(gp); va[1] = *reinterpret_cast<const float4*>(gp + 64 * 1536);
+        gp += 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bnxt[i] = gb[(long)(i >> 1) * 2 * 512 + (i & 1) * 32];
+        gb += 16 * 512;
+        const float* ap = As[cur] + h * 130 + wm * 64 + l;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float ra0 = ap[kk * 130], ra1 = ap[kk * 130 + 32];
+            const float rb0 = bcur[kk], rb1 = bcur[kk + 1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0, rb1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb1, acc[1][1], 0, 0, 0);
+        }
+        float* da = As[cur ^ 1];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { float* d = da + (c4 * 4) * 130 + r0 + p * 64; d[0] = va[p].x; d[130] = va[p].y; d[260] = va[p].z; d[390] = va[p].w; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bcur[i] = bnxt[i];
+        __syncthreads();
+    }
+    float s = va[0].x;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int FEAT>
 static void run(const char* name, const float* g, float* out, int grid, int ksteps) {
     hipEvent_t e0, e1;
@@ -259,6 +308,7 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1); float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); \
             const double fl = (double)grid * 4 * ksteps * 8 * 4 * 4096.0; \
             printf("  %-52s %8.1f us  %6.1f TF/s\n", NAME, ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12); }
+        RUNK(kloop_bdirect, "NN loop, B operand direct from L2 (no LDS)")
         RUNK(kloop_tn<false>, "wgrad-like loop, register staging + ds_write_b128")
         RUNK(kloop_tn<true>, "wgrad-like loop, global_load_lds (LDS-DMA)")
         RUNK(kloop_mid<6>, "full loop, LDS stores after kk=6 (mid-MMA)")
