@@ -186,6 +186,26 @@ int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1
                    int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                    lidbox_stream_t stream);
 
+/* ---- bf16-compute variants (BASELINE config 5: "bf16 compute / fp32 master") -------------------
+ * Same arguments, layouts, epilogues and determinism as lidbox_gemm_nn / _nt / _tn.  Every buffer
+ * stays fp32 in HBM; both operands are rounded to bfloat16 (round-to-nearest-even) while they are
+ * staged on chip, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), epilogues and the fused
+ * bias gradient are fp32.  Result == fp32 GEMM of the bf16-rounded operands up to summation order.
+ * Requires 16-byte aligned bases/workspace and K (K1), N, ldb, row and batch strides that are
+ * multiples of 4 (LIDBOX_E_INVALID otherwise) -- true of every x-vector / CNN layer.  Workspaces
+ * are sized by their own functions (the decompositions differ from the fp32 family's). */
+size_t lidbox_gemm_bf16_rows_workspace(long M, int N, int K);
+int lidbox_gemm_bf16_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C,
+                        int K, int N, int epilogue, const float* aux,
+                        void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+int lidbox_gemm_bf16_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C,
+                        int K, int N, int epilogue, const float* aux,
+                        void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+size_t lidbox_gemm_bf16_tn_workspace(int M, int K1, int N);
+int lidbox_gemm_bf16_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1, int N,
+                        int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
+                        lidbox_stream_t stream);
+
 /* out[n] (+)= sum_m rows[m, n]  -- bias gradient; deterministic two-stage reduction through
  * `workspace` (>= lidbox_colsum_workspace() bytes). */
 size_t lidbox_colsum_workspace(long M, int N);

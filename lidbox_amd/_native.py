@@ -70,6 +70,11 @@ _SIGS = {
     "lidbox_gemm_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "lidbox_gemm_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_bf16_rows_workspace": (_sz, [_l, _i, _i]),
+    "lidbox_gemm_bf16_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_bf16_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_bf16_tn_workspace": (_sz, [_i, _i, _i]),
+    "lidbox_gemm_bf16_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_colsum_workspace": (_sz, [_l, _i]),
     "lidbox_colsum": (_i, [Rows, _i, _vp, _i, _vp, _sz, _vp]),
     "lidbox_stats_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),

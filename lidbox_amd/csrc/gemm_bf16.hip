@@ -1,0 +1,494 @@
+// gemm_bf16.hip -- bf16-MFMA GEMM family (gfx950): the "bf16 compute / fp32 master" variant of the
+// Conv1D / Dense forward, dgrad and wgrad GEMMs in gemm.hip (BASELINE config 5).
+//
+// Replaces (reference file:line): the same call sites as gemm.hip --
+//   lidbox/models/xvector.py:38-43,53-64 (frame_layer / segment_layer), lidbox/models/cnn.py:32-41
+// when the model is run under a bfloat16 compute policy.  The reference has no such switch of its
+// own (Keras' mixed_bfloat16 policy would be set outside lidbox); the numerical contract here is:
+//   * every tensor in HBM stays fp32 (weights = the fp32 master copy, activations, gradients);
+//   * both GEMM operands are rounded to bfloat16, round-to-nearest-even, as they are staged into
+//     LDS (v_cvt_pk_bf16_f32);
+//   * products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; bias / ReLU / mask / accumulate
+//     epilogues, bias gradients, pooling, losses and Adam are unchanged fp32 code.
+// So a result equals the fp32 GEMM of the bf16-rounded operands up to fp32 summation order, which
+// is what tests/test_gemm_bf16_gpu.py checks.
+//
+// Design
+//   * Same implicit-row addressing as gemm.hip (lidbox_rows_t), same C ABI shape, same split
+//     decompositions with fixed-order reduce kernels (gemm_shared.h).
+//   * Workgroup tile 128 x 128, K depth 32 per LDS tile = two MFMAs (K = 16 each) per 32x32 block;
+//     4 waves as 2 x 2, each 64 x 64 = 2 x 2 blocks.  At 32 cycles per MFMA a K-step is 256 matrix
+//     cycles per wave against 32 KB of fp32 operand data, i.e. the loop is bound by the L2 -> LDS
+//     path (64 B/clk/CU), not by the 2.5 PFLOP/s pipe: keeping fp32 in HBM trades peak rate for
+//     leaving every other kernel and buffer untouched.
+//   * LDS tiles are [row][k] bf16 with an 80-byte row stride for BOTH operands: the MFMA operand
+//     fetch (lane -> row lane&31, 8 consecutive k at 8*(lane>>5)) is one ds_read_b128, conflict-free
+//     over the four 16-lane groups the hardware serves it in; staging stores are ds_write_b64 of
+//     4 consecutive k, and each 16-lane store group covers 8 k-quads x 2 rows that differ by 4
+//     (80*4 = 64 mod 128 bytes) -> conflict-free too.
+//       - operands whose contraction index is contiguous in HBM (A of NN/NT, B of NT): one
+//         float4 -> 4 bf16, no transpose;
+//       - operands whose contraction index is the row (B of NN, both operands of TN): a thread
+//         loads a 4(k) x 4(col) block as four float4 and writes its transpose.
+//   * wgrad's bias gradient (column sums of dY) is accumulated in fp32 from the staged float4
+//     registers BEFORE rounding, so it is bit-for-bit the quantity the fp32 path computes up to
+//     summation order.
+// Requirements (checked, LIDBOX_E_INVALID otherwise): 16-byte aligned bases, K (K1) and N multiples
+// of 4, row/batch strides multiples of 4 -- true of every layer of the x-vector / CNN models.
+// Roofline: MFMA bf16 dense, 2.5 PFLOP/s (MI355X_MICROARCH.md); practical bound = L2->LDS traffic.
+#include "gemm_shared.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;        // contraction depth of one LDS tile
+constexpr int BT = 128;       // tile rows (M side) = tile columns (N side)
+constexpr int LDT = 40;       // LDS row stride in bf16: 32 + 8 pad = 80 bytes
+constexpr int TILE_ELEMS = BT * LDT;
+
+__device__ __forceinline__ bf16x4 to_bf16(const float4& v) {
+    f32x4 x = {v.x, v.y, v.z, v.w};
+    return __builtin_convertvector(x, bf16x4);
+}
+
+// ---- operand with the contraction index contiguous in HBM: 128 rows x 32 k.
+//      thread -> k-quad (tid & 7) of row r0 + 32*pass; a wave's load covers 8 rows x 128 B.
+//      r0 swaps bits 0 and 2 of (tid >> 3) so that the two rows of a 16-lane store group differ by 4.
+struct KInner16 {
+    static constexpr int PASSES = BT / 32;
+    float4 v[PASSES];
+    const float* ptr[PASSES];
+    int kq, r0, k;
+
+    __device__ __forceinline__ void init(const RowsD& rows, long row_base, long nrows, int tid, int kbeg) {
+        kq = tid & 7;
+        const int rs = tid >> 3;
+        r0 = (rs & 0x1a) | ((rs & 1) << 2) | ((rs >> 2) & 1);
+        k = kbeg + 4 * kq;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const long r = row_base + r0 + 32 * p;
+            // rows outside the matrix are clamped to row 0: finite data that only reaches outputs never stored
+            ptr[p] = rows.base + (r < nrows ? row_offset(rows, (unsigned)r) : 0) + k;
+        }
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void load(int kend) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!CHECK || k < kend) x = *reinterpret_cast<const float4*>(ptr[p]);
+            ptr[p] += BK;
+            v[p] = x;
+        }
+        k += BK;
+    }
+    __device__ __forceinline__ void store(__bf16* tile) const {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+            *reinterpret_cast<bf16x4*>(tile + (r0 + 32 * p) * LDT + 4 * kq) = to_bf16(v[p]);
+    }
+};
+
+// ---- operand whose ROWS are the contraction index: 32 k x 128 columns.
+//      thread -> k rows 4*kq .. 4*kq+3 (kq = lane & 7), columns 4*nq .. 4*nq+3 (nq = tid >> 3);
+//      each of the four loads of a wave covers 8 k-rows x 128 B.  store() writes the 4x4 transpose.
+struct KOuter16 {
+    float4 v[4];
+    int kq, nq, cload;
+
+    __device__ __forceinline__ void init(int tid, int col0, int ncols) {
+        kq = tid & 7;
+        nq = tid >> 3;
+        const int c = col0 + 4 * nq;
+        cload = c < ncols ? c : 0;              // clamped column (results never stored)
+    }
+    __device__ __forceinline__ void store(__bf16* tile) const {
+        const float4 x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+        __bf16* d = tile + (4 * nq) * LDT + 4 * kq;
+        *reinterpret_cast<bf16x4*>(d + 0 * LDT) = to_bf16(make_float4(x0.x, x1.x, x2.x, x3.x));
+        *reinterpret_cast<bf16x4*>(d + 1 * LDT) = to_bf16(make_float4(x0.y, x1.y, x2.y, x3.y));
+        *reinterpret_cast<bf16x4*>(d + 2 * LDT) = to_bf16(make_float4(x0.z, x1.z, x2.z, x3.z));
+        *reinterpret_cast<bf16x4*>(d + 3 * LDT) = to_bf16(make_float4(x0.w, x1.w, x2.w, x3.w));
+    }
+};
+
+// plain matrix B[K][N] (NN): row k at base + k*ld
+struct KOuterPlain : KOuter16 {
+    const float* ptr;
+    long ld, step;
+    int k;
+    __device__ __forceinline__ void init_plain(const float* base, long ld_, int kbeg, int col0, int ncols, int tid) {
+        init(tid, col0, ncols);
+        ld = ld_;
+        k = kbeg + 4 * kq;
+        ptr = base + (long)k * ld + cload;
+        step = (long)BK * ld;
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void load(int kend) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!CHECK || k + j < kend) x = *reinterpret_cast<const float4*>(ptr + j * ld);
+            v[j] = x;
+        }
+        ptr += step;
+        k += BK;
+    }
+};
+
+// implicit rows (TN): contraction row m at row_offset(rows, m); the first of the thread's four rows is
+// tracked incrementally (adds only), the other three follow at +rs unless they cross an utterance.
+struct KOuterRows : KOuter16 {
+    RowsD rows;
+    long m, off, step, wrap;
+    unsigned t, rpb;
+    __device__ __forceinline__ void init_rows(const RowsD& r, long mbeg, int col0, int ncols, int tid) {
+        init(tid, col0, ncols);
+        rows = r;
+        m = mbeg + 4 * kq;
+        rpb = r.batch == 1 ? 0xffffffffu : (unsigned)r.rpb;
+        const unsigned b = r.batch == 1 ? 0u : (unsigned)m / rpb;
+        t = (unsigned)m - (r.batch == 1 ? 0u : b * rpb);
+        off = (long)b * r.bs + (long)t * r.rs;
+        step = (long)BK * r.rs;
+        wrap = r.batch == 1 ? 0 : r.bs - (long)r.rpb * r.rs;
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void load(long mend) {
+        const bool fast = t + 3 < rpb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!CHECK || m + j < mend) {
+                const long o = fast ? off + j * rows.rs : row_offset(rows, (unsigned)(m + j));
+                x = *reinterpret_cast<const float4*>(rows.base + o + cload);
+            }
+            v[j] = x;
+        }
+        m += BK;
+        t += BK;
+        off += step;
+        while (t >= rpb) { t -= rpb; off += wrap; }
+    }
+};
+
+// 64 x 64 per wave: 2 x 2 blocks, two K=16 MFMAs each, over one LDS tile pair
+__device__ __forceinline__ void mma_tile16(const __bf16* As, const __bf16* Bs, int wm, int wn, int lane,
+                                           f32x16 (&acc)[2][2]) {
+    const int h = lane >> 5, l = lane & 31;
+    const __bf16* ap = As + (wm * 64 + l) * LDT + 8 * h;
+    const __bf16* bp = Bs + (wn * 64 + l) * LDT + 8 * h;
+    bf16x8 a[2][2], b[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[ks][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDT + ks * 16);
+            b[ks][i] = *reinterpret_cast<const bf16x8*>(bp + i * 32 * LDT + ks * 16);
+        }
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K] . B)    B_KINNER = false: B[K][N] (NN)   true: B[N][K] (NT)
+// grid.x = tiles (XCD-chunk remapped), grid.y = K splits (partials to P, rows_reduce_kernel finishes)
+// ------------------------------------------------------------------------------------------------
+template <bool B_KINNER>
+__global__ __launch_bounds__(256) void gemm16_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
+                                                          float* __restrict__ P, long M, int K, int N, int epi,
+                                                          const float* __restrict__ aux, int tiles_n, unsigned ntiles,
+                                                          int k_per_split) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][TILE_ELEMS];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TILE_ELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const int tn = chunk % tiles_n;
+    const long m0 = (long)(chunk / tiles_n) * BT;
+    const int n0 = tn * BT;
+    const int split = blockIdx.y;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    KInner16 la;
+    la.init(A, m0, M, tid, kbeg);
+    KInner16 lbi;
+    KOuterPlain lbo;
+    const RowsD Brows{Bm, 0, ldb, 1, 0};
+    if (B_KINNER) lbi.init(Brows, n0, N, tid, kbeg);
+    else lbo.init_plain(Bm, ldb, kbeg, n0, N, tid);
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load<true>(kend);
+        if (B_KINNER) lbi.load<true>(kend);
+        else lbo.load<true>(kend);
+        la.store(As[0]);
+        if (B_KINNER) lbi.store(Bs[0]);
+        else lbo.store(Bs[0]);
+    }
+    __syncthreads();
+    // prefetch of step kt targets tile kt+1; only the last tile can be partial
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 2 < nk) {
+            la.load<false>(kend);
+            if (B_KINNER) lbi.load<false>(kend);
+            else lbo.load<false>(kend);
+        } else if (kt + 1 < nk) {
+            la.load<true>(kend);
+            if (B_KINNER) lbi.load<true>(kend);
+            else lbo.load<true>(kend);
+        }
+        mma_tile16(As[cur], Bs[cur], wm, wn, lane, acc);
+        if (kt + 1 < nk) {
+            la.store(As[cur ^ 1]);
+            if (B_KINNER) lbi.store(Bs[cur ^ 1]);
+            else lbo.store(Bs[cur ^ 1]);
+        }
+        __syncthreads();
+    }
+    store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, 0, M, N, epi, aux, Cd, P, split);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = fp32 column sums of B[Mslice]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm16_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P,
+                                                        float* __restrict__ Pc, long M, int K1, int N, int tiles_n,
+                                                        int ntiles, long rows_per_split) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][TILE_ELEMS];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TILE_ELEMS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // consecutive block ids = the tiles of one M slice: they read the same A/B rows (L2 reuse)
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int i0 = tk * BT, n0 = tn * BT;
+    const long mbeg = (long)split * rows_per_split;
+    long mend = mbeg + rows_per_split;
+    if (mend > M) mend = M;
+
+    KOuterRows la, lb;
+    la.init_rows(A, mbeg, i0, K1, tid);
+    lb.init_rows(Bd, mbeg, n0, N, tid);
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_csum = (Pc != nullptr) && tk == 0;
+
+    const int nk = (int)((mend - mbeg + BK - 1) / BK);
+#define LBX_TN16_ACC()                                                                   \
+    if (do_csum) {                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
+            csum.x += lb.v[j].x; csum.y += lb.v[j].y; csum.z += lb.v[j].z; csum.w += lb.v[j].w; \
+        }                                                                                \
+    }
+    if (nk > 0) {
+        la.load<true>(mend);
+        lb.load<true>(mend);
+        LBX_TN16_ACC()
+        la.store(As[0]);
+        lb.store(Bs[0]);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 2 < nk) { la.load<false>(mend); lb.load<false>(mend); }
+        else if (kt + 1 < nk) { la.load<true>(mend); lb.load<true>(mend); }
+        mma_tile16(As[cur], Bs[cur], wm, wn, lane, acc);
+        if (kt + 1 < nk) {
+            LBX_TN16_ACC()
+            la.store(As[cur ^ 1]);
+            lb.store(Bs[cur ^ 1]);
+        }
+        __syncthreads();
+    }
+#undef LBX_TN16_ACC
+    float* Pd = P + (long)split * K1 * N;
+    const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int col = n0 + wn * 64 + bj * 32 + l;
+        if (col >= N) continue;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
+            }
+    }
+    if (do_csum) {
+        // the 8 k-quad lanes of one column quad are lanes (lane & ~7) + 0..7: fixed-order butterfly
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            csum.x += __shfl_xor(csum.x, o, 64);
+            csum.y += __shfl_xor(csum.y, o, 64);
+            csum.z += __shfl_xor(csum.z, o, 64);
+            csum.w += __shfl_xor(csum.w, o, 64);
+        }
+        const int c = n0 + 4 * lb.nq;
+        if (lb.kq == 0 && c < N) *reinterpret_cast<float4*>(Pc + (long)split * N + c) = csum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Rows16Plan {
+    int splits, k_per_split;
+};
+
+// One tile shape; small-M problems (Dense layers) are split along K until ~3 workgroups per CU exist.
+Rows16Plan plan_rows16(long M, int N, int K, size_t ws_bytes) {
+    const long tiles = lbx_cdiv(M, BT) * lbx_cdiv(N, BT);
+    Rows16Plan best{1, K};
+    if (tiles >= 2 * NUM_CU) return best;
+    long s = lbx_cdiv(3 * NUM_CU, tiles);
+    const long max_s = K / (2 * BK);                 // at least two K-steps per split
+    if (s > max_s) s = max_s;
+    if (s > 64) s = 64;
+    while (s > 1 && (size_t)s * M * N * sizeof(float) > ws_bytes) --s;
+    if (s <= 1) return best;
+    const int kps = (int)(lbx_cdiv(lbx_cdiv(K, s), BK) * BK);
+    const int splits = (int)lbx_cdiv(K, kps);
+    if (splits <= 1) return best;
+    return Rows16Plan{splits, kps};
+}
+
+struct Tn16Plan {
+    int splits;
+    long rows_per_split;
+};
+
+Tn16Plan plan_tn16(long M, int K1, int N) {
+    const long tiles = lbx_cdiv(K1, BT) * lbx_cdiv(N, BT);
+    long s = lbx_cdiv(3 * NUM_CU, tiles);
+    const long max_s = lbx_cdiv(M, 4 * BK);          // at least four K-steps per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    const long rps = lbx_cdiv(lbx_cdiv(M, s), BK) * BK;
+    return Tn16Plan{(int)lbx_cdiv(M, rps), rps};
+}
+
+const char* const ALIGN_MSG =
+    "bf16 path needs 16-byte aligned operands and K, N, leading dimensions and row strides that are multiples of 4";
+
+template <bool B_KINNER>
+int launch_rows16(const char* fn, lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd, int K, int N, int epi,
+                  const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long M = (long)A.batch * A.rows_per_batch;
+    if (M == 0 || N == 0) return LIDBOX_OK;
+    const lidbox_rows_t Cin{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    if (!(rows_aligned(A) && rows_aligned(Cin) && K % 4 == 0 && aligned16(Bm) && ldb % 4 == 0 &&
+          (B_KINNER || N % 4 == 0) && aligned16(ws))) {
+        lidbox_set_error("%s: invalid argument: %s", fn, ALIGN_MSG);
+        return LIDBOX_E_INVALID;
+    }
+    const Rows16Plan pl = plan_rows16(M, N, K, ws ? ws_bytes : 0);
+    const int tiles_n = (int)lbx_cdiv(N, BT);
+    const long ntiles = lbx_cdiv(M, BT) * tiles_n;
+    const RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    float* P = (float*)ws;
+    hipLaunchKernelGGL((gemm16_rows_kernel<B_KINNER>), dim3((unsigned)ntiles, (unsigned)pl.splits), dim3(256), 0, st,
+                       to_dev(A), Bm, ldb, Co, P, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, pl.k_per_split);
+    LBX_LAUNCH_OK();
+    if (pl.splits > 1) {
+        long g = lbx_cdiv(M * N, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, pl.splits, 0L, M, N,
+                           Co, epi, aux);
+        LBX_LAUNCH_OK();
+    }
+    return LIDBOX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t lidbox_gemm_bf16_rows_workspace(long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const Rows16Plan pl = plan_rows16(M, N, K, (size_t)64 << 20);
+    return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int lidbox_gemm_bf16_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N,
+                                   int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                                   lidbox_stream_t stream) {
+    if (validate_rows_call(__func__, A, Bm, ldb, C, K, N, epilogue, aux, N)) return LIDBOX_E_INVALID;
+    return launch_rows16<false>(__func__, A, Bm, ldb, C, K, N, epilogue, aux, workspace, workspace_bytes,
+                                (hipStream_t)stream);
+}
+
+extern "C" int lidbox_gemm_bf16_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N,
+                                   int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                                   lidbox_stream_t stream) {
+    if (validate_rows_call(__func__, A, Bm, ldb, C, K, N, epilogue, aux, K)) return LIDBOX_E_INVALID;
+    return launch_rows16<true>(__func__, A, Bm, ldb, C, K, N, epilogue, aux, workspace, workspace_bytes,
+                               (hipStream_t)stream);
+}
+
+extern "C" size_t lidbox_gemm_bf16_tn_workspace(int M, int K1, int N) {
+    if (M <= 0 || K1 <= 0 || N <= 0) return 0;
+    const Tn16Plan pl = plan_tn16(M, K1, N);
+    return ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+}
+
+extern "C" int lidbox_gemm_bf16_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N,
+                                   int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
+                                   lidbox_stream_t stream) {
+    if (check_rows(__func__, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
+    if (check_rows(__func__, Bd.base, Bd.batch_stride, Bd.row_stride, Bd.batch, Bd.rows_per_batch)) return LIDBOX_E_INVALID;
+    LBX_ARG(Cm && K1 >= 1 && N >= 1 && ldc >= N, "C != NULL, K1, N >= 1, ldc >= N");
+    const long M = (long)A.batch * A.rows_per_batch;
+    LBX_ARG(M == (long)Bd.batch * Bd.rows_per_batch, "A and B row counts differ");
+    LBX_ARG(M >= 1, "M >= 1");
+    LBX_ARG(rows_aligned(A) && rows_aligned(Bd) && K1 % 4 == 0 && N % 4 == 0 && aligned16(workspace), ALIGN_MSG);
+    const Tn16Plan pl = plan_tn16(M, K1, N);
+    const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+    LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_bf16_tn_workspace)");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_n = (int)lbx_cdiv(N, BT);
+    const int ntiles = (int)(lbx_cdiv(K1, BT) * tiles_n);
+    float* P = (float*)workspace;
+    float* Pc = bias_grad ? P + (size_t)pl.splits * K1 * N : nullptr;
+    hipLaunchKernelGGL(gemm16_tn_kernel, dim3((unsigned)(ntiles * pl.splits)), dim3(256), 0, st, to_dev(A), to_dev(Bd), P,
+                       Pc, M, K1, N, tiles_n, ntiles, pl.rows_per_split);
+    LBX_LAUNCH_OK();
+    const long n = (long)K1 * N;
+    long g = lbx_cdiv(n + N, 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, (const float*)Pc,
+                       pl.splits, n, N, Cm, ldc, accumulate, bias_grad);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}

@@ -1,0 +1,177 @@
+// gemm_shared.h -- pieces common to the fp32 (gemm.hip) and bf16 (gemm_bf16.hip) MFMA GEMM families:
+// implicit-row descriptors, the fused epilogue of one workgroup tile, the fixed-order reduce kernels
+// of the split decompositions, and argument validation.  Both families produce the accumulator
+// layout of a 32x32 MFMA block (lane -> column lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)).
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NUM_CU = 256;
+
+struct RowsD {
+    const float* base;
+    long bs, rs;
+    int batch, rpb;
+};
+
+struct RowsOutD {
+    float* base;
+    long bs, rs;
+    int batch, rpb;
+};
+
+// m < 2^31 always (checked on the host): 32-bit unsigned division
+__device__ __forceinline__ long row_offset(const RowsD& r, unsigned m) {
+    if (r.batch == 1) return (long)m * r.rs;
+    const unsigned b = m / (unsigned)r.rpb;
+    return (long)b * r.bs + (long)(m - b * (unsigned)r.rpb) * r.rs;
+}
+__device__ __forceinline__ long row_offset(const RowsOutD& r, unsigned m) {
+    if (r.batch == 1) return (long)m * r.rs;
+    const unsigned b = m / (unsigned)r.rpb;
+    return (long)b * r.bs + (long)(m - b * (unsigned)r.rpb) * r.rs;
+}
+
+__device__ __forceinline__ float apply_epi(float v, int epi, float bias, const float* aux, long idx,
+                                           const float* dst) {
+    switch (epi) {
+        case LIDBOX_EPI_BIAS: return v + bias;
+        case LIDBOX_EPI_BIAS_RELU: return fmaxf(v + bias, 0.f);
+        case LIDBOX_EPI_RELU_MASK: return aux[idx] > 0.f ? v : 0.f;
+        case LIDBOX_EPI_ACCUM: return v + *dst;
+        case LIDBOX_EPI_ACCUM_RELU_MASK: return *dst + (aux[idx] > 0.f ? v : 0.f);
+        default: return v;
+    }
+}
+
+// Epilogue of one workgroup tile held as MI x NJ accumulator blocks per wave (waves 2 x 2).
+// Rows of this launch are [m_beg, M).  gridDim.y > 1 = split along K: raw partial sums go to
+// P[split][row - m_beg][n] and rows_reduce_kernel applies the epilogue.
+template <int MI, int NJ>
+__device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], long m0, int n0, int wm, int wn, int lane,
+                                                long m_beg, long M, int N, int epi, const float* __restrict__ aux,
+                                                const RowsOutD& Cd, float* __restrict__ P, int split) {
+    // Epilogue kind as four uniform flags (no per-element switch); bias and column state hoisted.
+    const int h = lane >> 5, l = lane & 31;
+    const bool partial = gridDim.y > 1;
+    const bool has_bias = !partial && (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU);
+    const bool do_relu = !partial && epi == LIDBOX_EPI_BIAS_RELU;
+    const bool has_mask = !partial && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    const bool accum = !partial && (epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    int col[NJ];
+    bool colok[NJ];
+    float bias[NJ];
+#pragma unroll
+    for (int bj = 0; bj < NJ; ++bj) {
+        col[bj] = n0 + wn * (32 * NJ) + bj * 32 + l;
+        colok[bj] = col[bj] < N;
+        bias[bj] = (has_bias && colok[bj]) ? aux[col[bj]] : 0.f;
+    }
+    float* const out_base = partial ? P + ((long)split * (M - m_beg) - m_beg) * N : Cd.base;   // P[split][row - m_beg][n]
+    const long out_rs = partial ? (long)N : Cd.rs;
+    const bool batched = !partial && Cd.batch != 1;
+#pragma unroll
+    for (int bi = 0; bi < MI; ++bi) {
+        const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
+        // (b, t) of the block's first row; the other 15 rows are <= 27 below it
+        unsigned b0 = 0, t0 = (unsigned)rbase;
+        if (batched) { b0 = (unsigned)rbase / (unsigned)Cd.rpb; t0 = (unsigned)rbase - b0 * (unsigned)Cd.rpb; }
+        const long off0 = batched ? (long)b0 * Cd.bs + (long)t0 * Cd.rs : rbase * out_rs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const long row = rbase + dr;
+            if (row >= M) continue;
+            long off = off0 + dr * out_rs;
+            if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
+#pragma unroll
+            for (int bj = 0; bj < NJ; ++bj) {
+                if (!colok[bj]) continue;
+                float* dst = out_base + off + col[bj];
+                float v = acc[bi][bj][r] + bias[bj];
+                if (has_mask) v = aux[off + col[bj]] > 0.f ? v : 0.f;
+                if (accum) v += *dst;
+                if (do_relu) v = fmaxf(v, 0.f);
+                *dst = v;
+            }
+        }
+    }
+}
+
+// C rows [m_beg, m_beg + Msub) = epi( sum_s P[s][Msub][N] ), fixed order
+__global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long m_beg, long Msub, int N, RowsOutD Cd,
+                                   int epi, const float* __restrict__ aux) {
+    const long total = Msub * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += P[(long)k * total + i];
+        const long row = i / N;
+        const int col = (int)(i - row * N);
+        const long off = row_offset(Cd, (unsigned)(m_beg + row));
+        const float bias = (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU) ? aux[col] : 0.f;
+        float* dst = Cd.base + off + col;
+        *dst = apply_epi(s, epi, bias, aux, off + col, dst);
+    }
+}
+
+// C[i] (+)= sum_s P[s][i]; bias_grad[n] (+)= sum_s Pc[s][n]   (fixed order)
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, const float* __restrict__ Pc, int splits,
+                                     long n, int N, float* __restrict__ Cm, long ldc, int accumulate,
+                                     float* __restrict__ bias_grad) {
+    const long total = n + (bias_grad ? N : 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (i < n) {
+            for (int k = 0; k < splits; ++k) s += P[(long)k * n + i];
+            const long row = i / N, col = i - row * N;
+            float* d = Cm + row * ldc + col;
+            *d = accumulate ? *d + s : s;
+        } else {
+            const long c = i - n;
+            for (int k = 0; k < splits; ++k) s += Pc[(long)k * N + c];
+            bias_grad[c] = accumulate ? bias_grad[c] + s : s;
+        }
+    }
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+inline bool rows_aligned(const lidbox_rows_t& r) {
+    return aligned16(r.base) && r.row_stride % 4 == 0 && (r.batch == 1 || r.batch_stride % 4 == 0);
+}
+
+inline RowsD to_dev(const lidbox_rows_t& r) { return RowsD{r.base, r.batch_stride, r.row_stride, r.batch, r.rows_per_batch}; }
+
+int check_rows(const char* fn, const void* base, long bs, long rs, int batch, int rpb) {
+    if (!base || batch < 0 || rpb < 0 || rs < 0 || bs < 0 || (long)batch * rpb > 0x7fffffffL) {
+        lidbox_set_error("%s: invalid rows descriptor", fn);
+        return LIDBOX_E_INVALID;
+    }
+    return LIDBOX_OK;
+}
+
+int validate_rows_call(const char* fn, const lidbox_rows_t& A, const float* Bm, long ldb, const lidbox_rows_out_t& C,
+                       int K, int N, int epilogue, const float* aux, long ldb_min) {
+    if (check_rows(fn, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
+    if (check_rows(fn, C.base, C.batch_stride, C.row_stride, C.batch, C.rows_per_batch)) return LIDBOX_E_INVALID;
+    const bool needs_aux = epilogue == LIDBOX_EPI_BIAS || epilogue == LIDBOX_EPI_BIAS_RELU ||
+                           epilogue == LIDBOX_EPI_RELU_MASK || epilogue == LIDBOX_EPI_ACCUM_RELU_MASK;
+    const char* msg = nullptr;
+    if (!Bm || K < 1 || N < 0 || ldb < ldb_min) msg = "B != NULL, K >= 1, N >= 0, ldb large enough";
+    else if ((long)A.batch * A.rows_per_batch != (long)C.batch * C.rows_per_batch) msg = "A and C row counts differ";
+    else if (epilogue < LIDBOX_EPI_NONE || epilogue > LIDBOX_EPI_ACCUM_RELU_MASK) msg = "epilogue";
+    else if (needs_aux && !aux) msg = "aux required by this epilogue";
+    if (msg) {
+        lidbox_set_error("%s: invalid argument: %s", fn, msg);
+        return LIDBOX_E_INVALID;
+    }
+    return LIDBOX_OK;
+}
+
+}  // namespace

@@ -7,7 +7,7 @@ from .tdnn import ConvSpec, DenseSpec, EmbeddingExtractor, SequentialTDNN
 
 
 def create(input_shape, num_outputs, output_activation="log_softmax", padding="causal", channel_dropout_rate=0,
-           seed=None, device=None):
+           seed=None, device=None, compute_dtype="float32"):
     """reference cnn.py:25-45"""
     if padding != "causal":
         raise ValueError("only padding='causal' is supported")
@@ -19,7 +19,7 @@ def create(input_shape, num_outputs, output_activation="log_softmax", padding="c
     ]
     denses = [DenseSpec("fc_1", 1500), DenseSpec("fc_2", 600), DenseSpec("output", num_outputs, relu=False)]
     return SequentialTDNN(input_shape, convs, "avg", denses, name="MGB-3_CNN", output_activation=output_activation,
-                          channel_dropout_rate=channel_dropout_rate, seed=seed, device=device)
+                          channel_dropout_rate=channel_dropout_rate, seed=seed, device=device, compute_dtype=compute_dtype)
 
 
 loader = create

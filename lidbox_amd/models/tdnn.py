@@ -49,6 +49,25 @@ def _rows(t_ptr, batch_stride, row_stride, batch, rpb):
     return nv.Rows(t_ptr, int(batch_stride), int(row_stride), int(batch), int(rpb))
 
 
+class _GemmFamily:
+    """The C-ABI entry points of one GEMM family: fp32 MFMA (gemm.hip) or bf16 MFMA with fp32 storage and
+    accumulation (gemm_bf16.hip, BASELINE config 5).  Same signatures, separate workspace sizing."""
+
+    def __init__(self, compute_dtype):
+        lib = nv.lib
+        if compute_dtype in ("float32", "fp32", "f32", torch.float32):
+            self.name = "float32"
+            self.nn, self.nt, self.tn = lib.lidbox_gemm_nn, lib.lidbox_gemm_nt, lib.lidbox_gemm_tn
+            self.rows_workspace, self.tn_workspace = lib.lidbox_gemm_rows_workspace, lib.lidbox_gemm_tn_workspace
+        elif compute_dtype in ("bfloat16", "bf16", torch.bfloat16):
+            self.name = "bfloat16"
+            self.nn, self.nt, self.tn = lib.lidbox_gemm_bf16_nn, lib.lidbox_gemm_bf16_nt, lib.lidbox_gemm_bf16_tn
+            self.rows_workspace = lib.lidbox_gemm_bf16_rows_workspace
+            self.tn_workspace = lib.lidbox_gemm_bf16_tn_workspace
+        else:
+            raise ValueError("compute_dtype must be 'float32' or 'bfloat16', got %r" % (compute_dtype,))
+
+
 class _Workspace:
     """All per-(B, T) device buffers of one model."""
 
@@ -76,19 +95,18 @@ class _Workspace:
         self.loss = torch.zeros(4, **f32)
         # one GEMM workspace sized for the largest split (wgrad partials, small-M split-K partials)
         ws_bytes = 16
+        g = model.gemm
         cin = model.input_dim
         for i, c in enumerate(convs):
             M = B * self.Ts[i + 1]
             if M > 0:
-                ws_bytes = max(ws_bytes, nv.lib.lidbox_gemm_tn_workspace(M, c.k * cin, c.filters),
-                               nv.lib.lidbox_gemm_rows_workspace(M, c.filters, c.k * cin),
-                               nv.lib.lidbox_gemm_rows_workspace(M, c.k * cin, c.filters))
+                ws_bytes = max(ws_bytes, g.tn_workspace(M, c.k * cin, c.filters),
+                               g.rows_workspace(M, c.filters, c.k * cin), g.rows_workspace(M, c.k * cin, c.filters))
             cin = c.filters
         din = P
         for d in model.denses:
-            ws_bytes = max(ws_bytes, nv.lib.lidbox_gemm_tn_workspace(B, din, d.units),
-                           nv.lib.lidbox_gemm_rows_workspace(B, d.units, din),
-                           nv.lib.lidbox_gemm_rows_workspace(B, din, d.units))
+            ws_bytes = max(ws_bytes, g.tn_workspace(B, din, d.units), g.rows_workspace(B, d.units, din),
+                           g.rows_workspace(B, din, d.units))
             din = d.units
         self.gemm_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.gemm_ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)     # wgrad side stream's own workspace
@@ -102,7 +120,7 @@ class SequentialTDNN:
     """convs -> pool -> denses -> log_softmax, parameters in one flat buffer."""
 
     def __init__(self, input_shape, convs, pool, denses, name="tdnn", output_activation="log_softmax",
-                 channel_dropout_rate=0.0, seed=None, device=None):
+                 channel_dropout_rate=0.0, seed=None, device=None, compute_dtype="float32"):
         if not torch.cuda.is_available():
             raise nv.LidboxHipError("lidbox_amd models need a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -116,6 +134,14 @@ class SequentialTDNN:
         self.output_activation = output_activation
         self.channel_dropout_rate = float(channel_dropout_rate)
         self.embedding_layer = self.denses[0].name
+        # GEMM arithmetic: "float32" (exact fp32 MFMA) or "bfloat16" (operands rounded to bf16 on chip, fp32
+        # accumulate; all buffers, the master weights and every non-GEMM kernel stay fp32)
+        self.gemm = _GemmFamily(compute_dtype)
+        self.compute_dtype = self.gemm.name
+        if self.compute_dtype == "bfloat16":
+            widths = [self.input_dim] + [c.filters for c in self.convs] + [d.units for d in self.denses]
+            if any(w % 4 for w in widths):
+                raise ValueError("bfloat16 compute needs channel / unit counts that are multiples of 4, got %s" % widths)
         # ---- flat parameter layout
         self.layout = {}           # name -> (offset, shape)
         off = 0
@@ -209,7 +235,7 @@ class SequentialTDNN:
         cin = self.input_dim
         for i, c in enumerate(self.convs):
             if ws.B * ws.Ts[i + 1] > 0:
-                nv.check(lib.lidbox_gemm_nn(self._conv_rows_in(ws, i), self._p(c.name + ".W"), c.filters,
+                nv.check(self.gemm.nn(self._conv_rows_in(ws, i), self._p(c.name + ".W"), c.filters,
                                             self._rows_out(ws.act[i + 1], ws, i + 1), c.k * cin, c.filters,
                                             nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
                                             nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
@@ -223,7 +249,7 @@ class SequentialTDNN:
             emb = upto_embedding and j == 0
             out = ws.emb if emb else ws.h[j]
             epi = nv.EPI_BIAS_RELU if (d.relu and not emb) else nv.EPI_BIAS
-            nv.check(lib.lidbox_gemm_nn(_rows(x.data_ptr(), 0, din, 1, ws.B), self._p(d.name + ".W"), d.units,
+            nv.check(self.gemm.nn(_rows(x.data_ptr(), 0, din, 1, ws.B), self._p(d.name + ".W"), d.units,
                                         _rows(out.data_ptr(), 0, d.units, 1, ws.B), din, d.units, epi,
                                         self._p(d.name + ".b"), nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
             if emb:
@@ -271,11 +297,11 @@ class SequentialTDNN:
             din = x.shape[1]
             dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
             A_rows = _rows(x.data_ptr(), 0, din, 1, B)
-            self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(lib.lidbox_gemm_tn(
+            self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(self.gemm.tn(
                 A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)))
             dst = ws.dpooled if j == 0 else ws.dh[j - 1]
             relu_prev = j > 0 and self.denses[j - 1].relu
-            nv.check(lib.lidbox_gemm_nt(dy, self._p(d.name + ".W"), d.units,
+            nv.check(self.gemm.nt(dy, self._p(d.name + ".W"), d.units,
                                         _rows(dst.data_ptr(), 0, din, 1, B), d.units, din,
                                         nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE,
                                         nv.ptr(x) if relu_prev else None, gws, gws_n, st))
@@ -306,7 +332,7 @@ class SequentialTDNN:
             return
         dy = self._rows_out(ws.dact[i + 1], ws, i + 1)
         A_rows = self._conv_rows_in(ws, i)
-        self._launch_wgrad(ws, lambda w, n, s_: nv.check(lib.lidbox_gemm_tn(
+        self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
             A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
         if i == 0:
             return
@@ -331,7 +357,7 @@ class SequentialTDNN:
                 epi = nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE
             else:
                 epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
-            nv.check(lib.lidbox_gemm_nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+            nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
 
     # ------------------------------------------------------------------ public call
     def _load_input(self, ws, x, training):

@@ -27,9 +27,12 @@ def segment_layer(units, activation="relu", name="segment"):
     return DenseSpec(name, units, relu=(activation == "relu"))
 
 
-def create(input_shape, num_outputs, channel_dropout_rate=0, name="x-vector", seed=None, device=None):
+def create(input_shape, num_outputs, channel_dropout_rate=0, name="x-vector", seed=None, device=None,
+           compute_dtype="float32"):
     """reference xvector.py:46-67.  input_shape = (T or None, C); returns a callable model:
-    model(x [B,T,C], training=bool) -> log-probs [B, num_outputs]."""
+    model(x [B,T,C], training=bool) -> log-probs [B, num_outputs].
+    compute_dtype (not in the reference; Keras sets this through a global mixed-precision policy): "float32" or
+    "bfloat16" = GEMM operands rounded to bf16 on chip, fp32 accumulate, fp32 master weights (BASELINE config 5)."""
     convs = [
         frame_layer(512, 5, 1, name="frame1"),
         frame_layer(512, 3, 2, name="frame2"),
@@ -43,7 +46,7 @@ def create(input_shape, num_outputs, channel_dropout_rate=0, name="x-vector", se
         DenseSpec("outputs", num_outputs, relu=False),
     ]
     return SequentialTDNN(input_shape, convs, "stats", denses, name=name, output_activation="log_softmax",
-                          channel_dropout_rate=channel_dropout_rate, seed=seed, device=device)
+                          channel_dropout_rate=channel_dropout_rate, seed=seed, device=device, compute_dtype=compute_dtype)
 
 
 loader = create      # lidbox/models/keras_utils.py:134 calls `model_module.loader(...)`

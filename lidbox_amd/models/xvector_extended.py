@@ -11,13 +11,13 @@ FRAMES = [(512, 5, 1), (512, 1, 1), (512, 3, 2), (512, 1, 1), (512, 3, 3), (512,
           (512, 1, 1), (1500, 1, 1)]          # (filters, kernel_size, strides) of frame1..frame10, reference :25-34
 
 
-def create(input_shape, num_outputs, output_activation="log_softmax", seed=None, device=None):
+def create(input_shape, num_outputs, output_activation="log_softmax", seed=None, device=None, compute_dtype="float32"):
     """reference xvector_extended.py:22-43"""
     convs = [frame_layer(f, k, s, name="frame%d" % (i + 1)) for i, (f, k, s) in enumerate(FRAMES)]
     denses = [segment_layer(512, name="segment1"), segment_layer(512, name="segment2"),
               DenseSpec("output", num_outputs, relu=False)]
     return SequentialTDNN(input_shape, convs, "stats", denses, name="x-vector-extended",
-                          output_activation=output_activation, seed=seed, device=device)
+                          output_activation=output_activation, seed=seed, device=device, compute_dtype=compute_dtype)
 
 
 loader = create

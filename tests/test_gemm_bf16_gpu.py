@@ -1,0 +1,174 @@
+"""
+GPU parity of the bf16-compute GEMM family (lidbox_gemm_bf16_nn/_nt/_tn, BASELINE config 5).
+
+Contract under test (include/lidbox_hip.h): operands are rounded to bfloat16 round-to-nearest-even,
+products accumulate in fp32, epilogues / bias gradients are fp32.  A product of two bf16 values is
+exact in fp32, so the result must equal the float64 GEMM of the bf16-ROUNDED operands to fp32
+summation round-off -- rel 2e-5 of the result scale, the same tolerance as the fp32 family -- which
+is far tighter than the ~4e-3 relative step of bf16 itself: a wrong rounding mode, a dropped K tail
+or a transposed fragment cannot pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype))).cuda()
+
+
+def _rows(t, bs, rs, batch, rpb, off_floats=0):
+    from lidbox_amd import _native as nv
+    return nv.Rows(t.data_ptr() + 4 * off_floats, bs, rs, batch, rpb)
+
+
+def _bf16(x):
+    """float64 value of x after fp32 -> bf16 RNE rounding"""
+    return torch.from_numpy(np.asarray(x, np.float32)).bfloat16().double().numpy()
+
+
+def _close(got, ref, rel=2e-5):
+    scale = max(1e-30, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= rel * scale, (err, scale)
+
+
+def _ws(nbytes):
+    return torch.empty(max(16, nbytes), dtype=torch.uint8, device="cuda")
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 32, 128), (200, 200, 512), (33, 1536, 512), (1000, 260, 40), (5, 4, 8),
+                                   (256, 3000, 512), (130, 64, 1500), (256, 512, 4), (512, 512, 100), (1, 4, 4)])
+def test_bf16_gemm_nn(M, K, N):
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M * 7 + K)
+    A, B, bias = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal(N)
+    ref = _bf16(A) @ _bf16(B)
+    a, b, bi = _dev(A), _dev(B), _dev(bias)
+    c = torch.full((M, N), 7.0, device="cuda")
+    st = nv.current_stream()
+    ra, rc = _rows(a, 0, K, 1, M), _rows(c, 0, N, 1, M)
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(ra, nv.ptr(b), N, rc, K, N, nv.EPI_NONE, None, None, 0, st))
+    _close(c.cpu().numpy(), ref)
+    # it really is a bf16 product: the fp32 GEMM of the unrounded operands differs visibly once K is non-trivial
+    if K >= 200:
+        assert np.abs(c.cpu().numpy() - A.astype(np.float32) @ B.astype(np.float32)).max() > 1e-3
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(ra, nv.ptr(b), N, rc, K, N, nv.EPI_BIAS_RELU, nv.ptr(bi), None, 0, st))
+    _close(c.cpu().numpy(), np.maximum(ref + np.float32(bias), 0))
+    # split-K workspace path (small-M problems); epilogue fused into the reduce
+    wsb = nv.lib.lidbox_gemm_bf16_rows_workspace(M, N, K)
+    ws = _ws(wsb)
+    c.fill_(-3.0)
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(ra, nv.ptr(b), N, rc, K, N, nv.EPI_BIAS, nv.ptr(bi), nv.ptr(ws), ws.numel(), st))
+    _close(c.cpu().numpy(), ref + np.float32(bias))
+    c2 = torch.empty_like(c)
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(ra, nv.ptr(b), N, _rows(c2, 0, N, 1, M), K, N, nv.EPI_BIAS, nv.ptr(bi), nv.ptr(ws),
+                                        ws.numel(), st))
+    assert torch.equal(c, c2)                              # deterministic
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 512, 1024), (99, 512, 1536), (7, 8, 4), (256, 4, 512), (300, 100, 3000),
+                                   (256, 512, 512)])
+def test_bf16_gemm_nt_and_epilogues(M, K, N):
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + 3 * N)
+    A, B = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+    mask = rng.standard_normal((M, N))
+    ref = _bf16(A) @ _bf16(B).T
+    a, b, mk = _dev(A), _dev(B), _dev(mask)
+    c = torch.full((M, N), 2.0, device="cuda")
+    st = nv.current_stream()
+    ra, rc = _rows(a, 0, K, 1, M), _rows(c, 0, N, 1, M)
+    wsb = nv.lib.lidbox_gemm_bf16_rows_workspace(M, N, K)
+    ws = _ws(wsb)
+    nv.check(nv.lib.lidbox_gemm_bf16_nt(ra, nv.ptr(b), K, rc, K, N, nv.EPI_NONE, None, None, 0, st))
+    _close(c.cpu().numpy(), ref)
+    nv.check(nv.lib.lidbox_gemm_bf16_nt(ra, nv.ptr(b), K, rc, K, N, nv.EPI_RELU_MASK, nv.ptr(mk), nv.ptr(ws), ws.numel(), st))
+    _close(c.cpu().numpy(), ref * (mask > 0))
+    c.fill_(-2.0)
+    nv.check(nv.lib.lidbox_gemm_bf16_nt(ra, nv.ptr(b), K, rc, K, N, nv.EPI_ACCUM, None, nv.ptr(ws), ws.numel(), st))
+    _close(c.cpu().numpy(), ref - 2.0)
+    c.fill_(-2.0)
+    nv.check(nv.lib.lidbox_gemm_bf16_nt(ra, nv.ptr(b), K, rc, K, N, nv.EPI_ACCUM_RELU_MASK, nv.ptr(mk), None, 0, st))
+    _close(c.cpu().numpy(), ref * (mask > 0) - 2.0)
+
+
+@pytest.mark.parametrize("M,K1,N", [(4096, 200, 512), (1000, 1536, 512), (256, 3000, 512), (50, 8, 4), (8448, 512, 1500),
+                                    (37, 132, 260)])
+def test_bf16_gemm_tn_and_bias_grad(M, K1, N):
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + N)
+    A, B = rng.standard_normal((M, K1)), rng.standard_normal((M, N))
+    ref = _bf16(A).T @ _bf16(B)
+    a, b = _dev(A), _dev(B)
+    c = torch.full((K1, N), 3.0, device="cuda")
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_bf16_tn_workspace(M, K1, N)
+    ws = _ws(wsb)
+    ra, rb = _rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M)
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(ra, rb, nv.ptr(c), N, K1, N, 0, None, nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), ref)
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(ra, rb, nv.ptr(c), N, K1, N, 1, None, nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), 2 * ref)
+    c2, c3 = torch.empty_like(c), torch.empty_like(c)
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(ra, rb, nv.ptr(c2), N, K1, N, 0, None, nv.ptr(ws), wsb, st))
+    bg = torch.full((N,), 9.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(ra, rb, nv.ptr(c3), N, K1, N, 0, nv.ptr(bg), nv.ptr(ws), wsb, st))
+    assert torch.equal(c2, c3)                              # deterministic, with or without the fused bias gradient
+    # the bias gradient is summed in fp32 from the UNROUNDED operand
+    _close(bg.cpu().numpy(), np.asarray(B, np.float32).astype(np.float64).sum(axis=0), 1e-5)
+
+
+def test_bf16_gemm_batched_implicit_rows_match_fp32_layout():
+    """implicit causal rows (batch > 1, overlapping windows, strided) -- same addressing as the fp32 family"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(5)
+    Bn, T, C, k, s, Co = 3, 50, 8, 3, 2, 12
+    Tp = T + k - 1
+    x = np.zeros((Bn, Tp, C))
+    x[:, k - 1:] = rng.standard_normal((Bn, T, C))
+    W = rng.standard_normal((k * C, Co))
+    To = (T - 1) // s + 1
+    cols = np.stack([x[:, t * s:t * s + k].reshape(Bn, k * C) for t in range(To)], axis=1)      # [B, To, k*C]
+    ref = _bf16(cols) @ _bf16(W)
+    xd, wd = _dev(x), _dev(W)
+    y = torch.zeros(Bn, To, Co, device="cuda")
+    st = nv.current_stream()
+    ra = _rows(xd, Tp * C, s * C, Bn, To)
+    ry = _rows(y, To * Co, Co, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(ra, nv.ptr(wd), Co, ry, k * C, Co, nv.EPI_NONE, None, None, 0, st))
+    _close(y.cpu().numpy(), ref)
+    # wgrad over the same implicit rows: dW = cols^T . dY, with fused bias gradient
+    dY = rng.standard_normal((Bn, To, Co))
+    dyd = _dev(dY)
+    dW = torch.zeros(k * C, Co, device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    wsb = nv.lib.lidbox_gemm_bf16_tn_workspace(Bn * To, k * C, Co)
+    ws = _ws(wsb)
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(ra, _rows(dyd, To * Co, Co, Bn, To), nv.ptr(dW), Co, k * C, Co, 0, nv.ptr(db),
+                                        nv.ptr(ws), wsb, st))
+    _close(dW.cpu().numpy(), _bf16(cols).reshape(-1, k * C).T @ _bf16(dY).reshape(-1, Co))
+    _close(db.cpu().numpy(), np.asarray(dY, np.float32).astype(np.float64).reshape(-1, Co).sum(axis=0), 1e-5)
+    # rows_per_batch == 1 (every row crosses an utterance boundary)
+    ra1 = _rows(xd, Tp * C, s * C, Bn, 1)
+    y1 = torch.zeros(Bn, 1, Co, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(ra1, nv.ptr(wd), Co, _rows(y1, Co, Co, Bn, 1), k * C, Co, nv.EPI_NONE, None, None, 0, st))
+    _close(y1.cpu().numpy()[:, 0], ref[:, 0])
+    dW1 = torch.zeros(k * C, Co, device="cuda")
+    wsb1 = nv.lib.lidbox_gemm_bf16_tn_workspace(Bn, k * C, Co)
+    ws1 = _ws(wsb1)
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(ra1, _rows(dyd, To * Co, Co, Bn, 1), nv.ptr(dW1), Co, k * C, Co, 0, None, nv.ptr(ws1),
+                                        wsb1, st))
+    _close(dW1.cpu().numpy(), _bf16(cols[:, 0]).T @ _bf16(dY[:, 0]))
+
+
+def test_bf16_gemm_rejects_unaligned_shapes():
+    from lidbox_amd import _native as nv
+    a = torch.zeros(8, 7, device="cuda")
+    b = torch.zeros(7, 8, device="cuda")
+    c = torch.zeros(8, 8, device="cuda")
+    rc = nv.lib.lidbox_gemm_bf16_nn(_rows(a, 0, 7, 1, 8), nv.ptr(b), 8, _rows(c, 0, 8, 1, 8), 7, 8, nv.EPI_NONE, None, None, 0,
+                                    nv.current_stream())
+    assert rc != 0 and "multiples of 4" in nv.last_error()

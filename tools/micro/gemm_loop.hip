@@ -6,7 +6,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // FEAT bits: 1 = LDS operand reads, 2 = LDS stores (transposed b32 x8 + b128 x2), 4 = barrier per K-step,
 //            8 = global loads (4 x float4 per thread per K-step), 16 = double-buffer toggle
 template <int FEAT>
-__global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float* out, int ksteps, long gstride) {
+__global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float* out, int ksteps, long gstride, long long* clk) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     __shared__ __attribute__((aligned(16))) float As[2][16 * 130];
     __shared__ __attribute__((aligned(16))) float Bs[2][16 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float*
         }
         const float* ap = As[cur] + h * 130 + wm * 64 + l;
         const float* bp = Bs[cur] + h * 128 + wn * 64 + l;
+        if (FEAT & 32) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
             if (FEAT & 1) { ra0 = ap[kk * 130]; ra1 = ap[kk * 130 + 32]; rb0 = bp[kk * 128]; rb1 = bp[kk * 128 + 32]; }
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float*
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1, rb1, acc[1][1], 0, 0, 0);
         }
+        if (FEAT & 32) __builtin_amdgcn_s_setprio(0);
         if (FEAT & 2) {
             float* da = As[cur ^ ((FEAT & 16) ? 1 : 0)];
             float* db = Bs[cur ^ ((FEAT & 16) ? 1 : 0)];
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void kloop(const float* __restrict__ g, float*
     float s = va[0].x + vb[1].y;
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
     out[blockIdx.x * 256 + tid] = s;
+    if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 
@@ -265,15 +269,23 @@ static void run(const char* name, const float* g, float* out, int grid, int kste
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const long gstride = 128L * 1536;   // (kloop_tn walks 1536 rows of 1536 floats: stays inside the 1.5 GB buffer)
-    hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride);
+    static long long* clk = nullptr;
+    if (!clk) hipMalloc(&clk, 16);
+    int wall_khz = 0;
+    hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride, clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((kloop<FEAT>), dim3(grid), dim3(256), 0, 0, g, out, ksteps, gstride, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    long long h[2];
+    hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
     const double fl = (double)grid * 4 * ksteps * 8 * 4 * 4096.0;
-    printf("  %-52s %8.1f us  %6.1f TF/s\n", name, ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12);
+    // clock64 = shader clock, wall_clock64 = constant-rate counter: their ratio is the sustained shader clock
+    printf("  %-52s %8.1f us  %6.1f TF/s   shader clock %.0f MHz (wg0: %lld cyc)\n", name, ms * 200.0, fl * 5 / (ms * 1e-3) / 1e12,
+           h[1] ? (double)h[0] / ((double)h[1] / (wall_khz * 1e3)) / 1e6 : 0.0, h[0]);
 }
 
 int main() {
@@ -282,7 +294,7 @@ int main() {
     hipMalloc(&g, (size_t)maxgrid * 256 * 1536 * 4);
     hipMemset(g, 0, (size_t)maxgrid * 256 * 1536 * 4);
     hipMalloc(&out, maxgrid * 256 * 4);
-    const int ksteps = 96;
+    const int ksteps = 960;
     for (int w = 1; w <= 4; ++w) {
         const int grid = 256 * w;
         printf("%d WG/CU (grid %d), %d K-steps\n", w, grid, ksteps);
@@ -314,6 +326,8 @@ int main() {
         RUNK(kloop_mid<6>, "full loop, LDS stores after kk=6 (mid-MMA)")
         RUNK(kloop_mid<10>, "full loop, LDS stores after kk=10")
         RUNK(kloop_mid<14>, "full loop, LDS stores after kk=14 (end, ref)")
+        run<1 | 2 | 4 | 8 | 16 | 32>("full loop + s_setprio 3 in MFMA phase", g, out, grid, ksteps);
+        run<32>("MFMA only + s_setprio", g, out, grid, ksteps);
         run<1 | 4 | 8 | 16>("full minus LDS stores", g, out, grid, ksteps);
         run<1 | 2 | 8 | 16>("full minus barrier", g, out, grid, ksteps);
     }
