@@ -41,6 +41,7 @@ SAMPLE_RATE, DURATION_S = 16000, 2.0
 BYTES_PER_UTT_FEATURE = 32000 * 4 + 198 * 40 * 4           # 159 680 B
 FLOPS_PER_UTT_TRAIN = 918.7e6
 PEAK_FP32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
@@ -54,6 +55,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--compute-dtype", choices=["float32", "bfloat16"], default="float32",
+                    help="GEMM arithmetic; float32 is the BASELINE metric's configuration, bfloat16 = config 5's "
+                         "bf16-compute / fp32-master variant of the same workload")
     return ap.parse_args()
 
 
@@ -63,7 +67,8 @@ class KernelTimer:
     Launches are keyed by the exact kernel instantiation (tile shape from lidbox_gemm_plan_query),
     i.e. by the names rocprofv3 --stats reports."""
 
-    ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_extract_features_fwd": -1}
+    ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_extract_features_fwd": -1,
+             "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12}
 
     def __init__(self, nv):
         self.nv = nv
@@ -77,6 +82,8 @@ class KernelTimer:
             return "fused_feat512_kernel", float(args[3]) * BYTES_PER_UTT_FEATURE
         A, K, N = args[0], args[4], args[5]
         M = A.batch * A.rows_per_batch
+        if kind >= 10:                                        # bf16 family: one tile shape per entry point
+            return ("gemm16_tn_kernel", "gemm16_rows_kernel<NN>", "gemm16_rows_kernel<NT>")[(kind - 9) % 3], 2.0 * M * K * N
         ws_bytes = args[9] if kind < 2 else 0
         out = (ctypes.c_int * 4)()
         self.nv.check(self.nv.lib.lidbox_gemm_plan_query(kind, M, N, K, int(ws_bytes or 0), out))
@@ -205,7 +212,9 @@ def main():
     lab_d = torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)
     del sig
 
-    model = xvector.create((198, 40), NUM_LANGS, seed=0, device=dev)
+    model = xvector.create((198, 40), NUM_LANGS, seed=0, device=dev, compute_dtype=args.compute_dtype)
+    bf16 = args.compute_dtype == "bfloat16"
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     plan = audio.get_plan(SAMPLE_RATE, 400, 160, device=dev)
     trainer = Trainer(model, loss="sparse_categorical_crossentropy", feature=dict(plan=plan, kind=nv.FEAT_LOGMEL),
                       use_graph=not args.no_graph)
@@ -239,9 +248,10 @@ def main():
         "metric": "utterances/sec (16kHz x 2s) log-mel + x-vector train step",
         "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "log-mel + x-vector 4-lang train step, bs=%d per GPU, fp32 (BASELINE configs[%d])"
-                               % (B, 1 if world == 1 else 2),
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": "log-mel + x-vector 4-lang train step, bs=%d per GPU, %s (BASELINE configs[%d]%s)"
+                               % (B, "bf16 MFMA operands / fp32 accumulate, storage and master weights" if bf16 else "fp32",
+                                  1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""),
                    "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
                    "languages": NUM_LANGS, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world,
                    "hip_graph": not args.no_graph, "final_loss": round(final_loss, 6)},
@@ -265,8 +275,8 @@ def main():
             d = gemms[dom]
             ach = d["rate"] / 1e12
             result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
-                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                                  "peak": peak_mfma, "unit": "TFLOP/s",
+                                  "frac": round(ach / peak_mfma, 4), "traffic": pmc_traffic(dom),
                                   "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
                                   "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
                                   "note": "HIP-event bracket per launch (includes the split-K reduce kernel where one "

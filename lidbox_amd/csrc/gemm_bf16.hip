@@ -18,9 +18,11 @@
 //     decompositions with fixed-order reduce kernels (gemm_shared.h).
 //   * Workgroup tile 128 x 128, K depth 32 per LDS tile = two MFMAs (K = 16 each) per 32x32 block;
 //     4 waves as 2 x 2, each 64 x 64 = 2 x 2 blocks.  At 32 cycles per MFMA a K-step is 256 matrix
-//     cycles per wave against 32 KB of fp32 operand data, i.e. the loop is bound by the L2 -> LDS
-//     path (64 B/clk/CU), not by the 2.5 PFLOP/s pipe: keeping fp32 in HBM trades peak rate for
-//     leaving every other kernel and buffer untouched.
+//     cycles per wave against 32 KB of fp32 operand data, i.e. the loop is bound by the global-load
+//     path, not by the 2.5 PFLOP/s pipe: keeping fp32 in HBM trades peak rate for leaving every
+//     other kernel and buffer untouched.  Two tiles are kept in flight per workgroup (register ring
+//     of depth 2, ~190 VGPRs, 2 workgroups per CU) because one 256-cycle K-step cannot cover a loaded
+//     global round trip (measured in tools/micro/bf16_loop.hip).
 //   * LDS tiles are [row][k] bf16 with an 80-byte row stride for BOTH operands: the MFMA operand
 //     fetch (lane -> row lane&31, 8 consecutive k at 8*(lane>>5)) is one ds_read_b128, conflict-free
 //     over the four 16-lane groups the hardware serves it in; staging stores are ds_write_b64 of
@@ -49,18 +51,23 @@ constexpr int BT = 128;       // tile rows (M side) = tile columns (N side)
 constexpr int LDT = 40;       // LDS row stride in bf16: 32 + 8 pad = 80 bytes
 constexpr int TILE_ELEMS = BT * LDT;
 
-__device__ __forceinline__ bf16x4 to_bf16(const float4& v) {
-    f32x4 x = {v.x, v.y, v.z, v.w};
-    return __builtin_convertvector(x, bf16x4);
-}
+// Staging registers are native 4-float vectors (not HIP's float4 struct): the 4x4 transpose below is then
+// plain register picks -- with struct temporaries the compiler built it through scratch memory.
+__device__ __forceinline__ bf16x4 to_bf16(f32x4 x) { return __builtin_convertvector(x, bf16x4); }
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// Staging payload of one operand tile per thread: four float4 (16 VGPRs).  It lives OUTSIDE the loaders so
+// that the kernels can keep two tiles in flight (register ring of depth 2, see the K loops).
+struct Tile4 {
+    f32x4 v0, v1, v2, v3;
+};
 
 // ---- operand with the contraction index contiguous in HBM: 128 rows x 32 k.
-//      thread -> k-quad (tid & 7) of row r0 + 32*pass; a wave's load covers 8 rows x 128 B.
+//      thread -> k-quad (tid & 7) of rows r0 + 32*{0,1,2,3}; a wave's load covers 8 rows x 128 B.
 //      r0 swaps bits 0 and 2 of (tid >> 3) so that the two rows of a 16-lane store group differ by 4.
 struct KInner16 {
-    static constexpr int PASSES = BT / 32;
-    float4 v[PASSES];
-    const float* ptr[PASSES];
+    const float* ptr[4];
     int kq, r0, k;
 
     __device__ __forceinline__ void init(const RowsD& rows, long row_base, long nrows, int tid, int kbeg) {
@@ -69,27 +76,29 @@ struct KInner16 {
         r0 = (rs & 0x1a) | ((rs & 1) << 2) | ((rs >> 2) & 1);
         k = kbeg + 4 * kq;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
+        for (int p = 0; p < 4; ++p) {
             const long r = row_base + r0 + 32 * p;
             // rows outside the matrix are clamped to row 0: finite data that only reaches outputs never stored
             ptr[p] = rows.base + (r < nrows ? row_offset(rows, (unsigned)r) : 0) + k;
         }
     }
     template <bool CHECK>
-    __device__ __forceinline__ void load(int kend) {
+    __device__ __forceinline__ void load(Tile4& t, int kend) {
+        const bool in = !CHECK || k < kend;
+        t.v0 = in ? ldg4(ptr[0]) : zero4();
+        t.v1 = in ? ldg4(ptr[1]) : zero4();
+        t.v2 = in ? ldg4(ptr[2]) : zero4();
+        t.v3 = in ? ldg4(ptr[3]) : zero4();
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!CHECK || k < kend) x = *reinterpret_cast<const float4*>(ptr[p]);
-            ptr[p] += BK;
-            v[p] = x;
-        }
+        for (int p = 0; p < 4; ++p) ptr[p] += BK;
         k += BK;
     }
-    __device__ __forceinline__ void store(__bf16* tile) const {
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-            *reinterpret_cast<bf16x4*>(tile + (r0 + 32 * p) * LDT + 4 * kq) = to_bf16(v[p]);
+    __device__ __forceinline__ void store(__bf16* tile, const Tile4& t) const {
+        __bf16* d = tile + r0 * LDT + 4 * kq;
+        *reinterpret_cast<bf16x4*>(d + 0 * 32 * LDT) = to_bf16(t.v0);
+        *reinterpret_cast<bf16x4*>(d + 1 * 32 * LDT) = to_bf16(t.v1);
+        *reinterpret_cast<bf16x4*>(d + 2 * 32 * LDT) = to_bf16(t.v2);
+        *reinterpret_cast<bf16x4*>(d + 3 * 32 * LDT) = to_bf16(t.v3);
     }
 };
 
@@ -97,7 +106,6 @@ struct KInner16 {
 //      thread -> k rows 4*kq .. 4*kq+3 (kq = lane & 7), columns 4*nq .. 4*nq+3 (nq = tid >> 3);
 //      each of the four loads of a wave covers 8 k-rows x 128 B.  store() writes the 4x4 transpose.
 struct KOuter16 {
-    float4 v[4];
     int kq, nq, cload;
 
     __device__ __forceinline__ void init(int tid, int col0, int ncols) {
@@ -106,14 +114,15 @@ struct KOuter16 {
         const int c = col0 + 4 * nq;
         cload = c < ncols ? c : 0;              // clamped column (results never stored)
     }
-    __device__ __forceinline__ void store(__bf16* tile) const {
-        const float4 x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    __device__ __forceinline__ void store(__bf16* tile, const Tile4& t) const {
         __bf16* d = tile + (4 * nq) * LDT + 4 * kq;
-        *reinterpret_cast<bf16x4*>(d + 0 * LDT) = to_bf16(make_float4(x0.x, x1.x, x2.x, x3.x));
-        *reinterpret_cast<bf16x4*>(d + 1 * LDT) = to_bf16(make_float4(x0.y, x1.y, x2.y, x3.y));
-        *reinterpret_cast<bf16x4*>(d + 2 * LDT) = to_bf16(make_float4(x0.z, x1.z, x2.z, x3.z));
-        *reinterpret_cast<bf16x4*>(d + 3 * LDT) = to_bf16(make_float4(x0.w, x1.w, x2.w, x3.w));
+        *reinterpret_cast<bf16x4*>(d + 0 * LDT) = to_bf16(f32x4{t.v0.x, t.v1.x, t.v2.x, t.v3.x});
+        *reinterpret_cast<bf16x4*>(d + 1 * LDT) = to_bf16(f32x4{t.v0.y, t.v1.y, t.v2.y, t.v3.y});
+        *reinterpret_cast<bf16x4*>(d + 2 * LDT) = to_bf16(f32x4{t.v0.z, t.v1.z, t.v2.z, t.v3.z});
+        *reinterpret_cast<bf16x4*>(d + 3 * LDT) = to_bf16(f32x4{t.v0.w, t.v1.w, t.v2.w, t.v3.w});
     }
+    // fp32 column sums of a staged block (wgrad's bias gradient)
+    static __device__ __forceinline__ f32x4 colsum(const Tile4& t) { return (t.v0 + t.v1) + (t.v2 + t.v3); }
 };
 
 // plain matrix B[K][N] (NN): row k at base + k*ld
@@ -129,13 +138,11 @@ struct KOuterPlain : KOuter16 {
         step = (long)BK * ld;
     }
     template <bool CHECK>
-    __device__ __forceinline__ void load(int kend) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!CHECK || k + j < kend) x = *reinterpret_cast<const float4*>(ptr + j * ld);
-            v[j] = x;
-        }
+    __device__ __forceinline__ void load(Tile4& t, int kend) {
+        t.v0 = (!CHECK || k + 0 < kend) ? ldg4(ptr) : zero4();
+        t.v1 = (!CHECK || k + 1 < kend) ? ldg4(ptr + ld) : zero4();
+        t.v2 = (!CHECK || k + 2 < kend) ? ldg4(ptr + 2 * ld) : zero4();
+        t.v3 = (!CHECK || k + 3 < kend) ? ldg4(ptr + 3 * ld) : zero4();
         ptr += step;
         k += BK;
     }
@@ -159,17 +166,18 @@ struct KOuterRows : KOuter16 {
         wrap = r.batch == 1 ? 0 : r.bs - (long)r.rpb * r.rs;
     }
     template <bool CHECK>
-    __device__ __forceinline__ void load(long mend) {
+    __device__ __forceinline__ f32x4 fetch(int j, bool fast, long mend) const {
+        if (CHECK && m + j >= mend) return zero4();
+        const long o = fast ? off + j * rows.rs : row_offset(rows, (unsigned)(m + j));
+        return ldg4(rows.base + o + cload);
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void load(Tile4& x, long mend) {
         const bool fast = t + 3 < rpb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!CHECK || m + j < mend) {
-                const long o = fast ? off + j * rows.rs : row_offset(rows, (unsigned)(m + j));
-                x = *reinterpret_cast<const float4*>(rows.base + o + cload);
-            }
-            v[j] = x;
-        }
+        x.v0 = fetch<CHECK>(0, fast, mend);
+        x.v1 = fetch<CHECK>(1, fast, mend);
+        x.v2 = fetch<CHECK>(2, fast, mend);
+        x.v3 = fetch<CHECK>(3, fast, mend);
         m += BK;
         t += BK;
         off += step;
@@ -216,7 +224,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // grid.x = tiles (XCD-chunk remapped), grid.y = K splits (partials to P, rows_reduce_kernel finishes)
 // ------------------------------------------------------------------------------------------------
 template <bool B_KINNER>
-__global__ __launch_bounds__(256) void gemm16_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
+__global__ __launch_bounds__(256, 2) void gemm16_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
                                                           float* __restrict__ P, long M, int K, int N, int epi,
                                                           const float* __restrict__ aux, int tiles_n, unsigned ntiles,
                                                           int k_per_split) {
@@ -244,43 +252,55 @@ __global__ __launch_bounds__(256) void gemm16_rows_kernel(RowsD A, const float* 
     f32x16 acc[2][2];
     zero_acc(acc);
 
+    // Register ring of depth 2: while tile kt is multiplied out of LDS, tile kt+1 sits in registers (loaded one
+    // step ago, so its wait is short) and the loads of tile kt+2 are issued.  A 32-deep bf16 K-step is only
+    // 256 matrix cycles, far less than a loaded global round trip, so one tile in flight leaves the loop
+    // latency-bound (tools/micro/bf16_loop.hip: +58 % with one workgroup per CU, +13..22 % with 2-3).
+    Tile4 ra[2], rb[2];
     const int nk = (kend - kbeg + BK - 1) / BK;
+    auto fetch = [&](Tile4& a, Tile4& b, int t) {                // tile t; only the last tile can be partial
+        if (t + 1 < nk) {
+            la.load<false>(a, kend);
+            if (B_KINNER) lbi.load<false>(b, kend);
+            else lbo.load<false>(b, kend);
+        } else {
+            la.load<true>(a, kend);
+            if (B_KINNER) lbi.load<true>(b, kend);
+            else lbo.load<true>(b, kend);
+        }
+    };
+    auto stage = [&](int buf, const Tile4& a, const Tile4& b) {
+        la.store(As[buf], a);
+        if (B_KINNER) lbi.store(Bs[buf], b);
+        else lbo.store(Bs[buf], b);
+    };
     if (nk > 0) {
-        la.load<true>(kend);
-        if (B_KINNER) lbi.load<true>(kend);
-        else lbo.load<true>(kend);
-        la.store(As[0]);
-        if (B_KINNER) lbi.store(Bs[0]);
-        else lbo.store(Bs[0]);
+        fetch(ra[0], rb[0], 0);
+        if (nk > 1) fetch(ra[1], rb[1], 1);
+        stage(0, ra[0], rb[0]);
     }
     __syncthreads();
-    // prefetch of step kt targets tile kt+1; only the last tile can be partial
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 2 < nk) {
-            la.load<false>(kend);
-            if (B_KINNER) lbi.load<false>(kend);
-            else lbo.load<false>(kend);
-        } else if (kt + 1 < nk) {
-            la.load<true>(kend);
-            if (B_KINNER) lbi.load<true>(kend);
-            else lbo.load<true>(kend);
-        }
-        mma_tile16(As[cur], Bs[cur], wm, wn, lane, acc);
-        if (kt + 1 < nk) {
-            la.store(As[cur ^ 1]);
-            if (B_KINNER) lbi.store(Bs[cur ^ 1]);
-            else lbo.store(Bs[cur ^ 1]);
-        }
-        __syncthreads();
+    // step kt (parity PAR): registers [PAR^1] hold tile kt+1; tile kt+2 is loaded into registers [PAR]
+#define LBX16_STEP(PAR)                                                   \
+    {                                                                     \
+        if (kt + 2 < nk) fetch(ra[PAR], rb[PAR], kt + 2);                 \
+        mma_tile16(As[PAR], Bs[PAR], wm, wn, lane, acc);                  \
+        if (kt + 1 < nk) stage((PAR) ^ 1, ra[(PAR) ^ 1], rb[(PAR) ^ 1]);  \
+        __syncthreads();                                                  \
+        ++kt;                                                             \
     }
+    for (int kt = 0; kt < nk;) {
+        LBX16_STEP(0)
+        if (kt < nk) LBX16_STEP(1)
+    }
+#undef LBX16_STEP
     store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, 0, M, N, epi, aux, Cd, P, split);
 }
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = fp32 column sums of B[Mslice]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm16_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P,
+__global__ __launch_bounds__(256, 2) void gemm16_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P,
                                                         float* __restrict__ Pc, long M, int K1, int N, int tiles_n,
                                                         int ntiles, long rows_per_split) {
     __shared__ __attribute__((aligned(16))) __bf16 As[2][TILE_ELEMS];
@@ -303,37 +323,39 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(RowsD A, RowsD Bd, float
 
     f32x16 acc[2][2];
     zero_acc(acc);
-    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 csum = zero4();
     const bool do_csum = (Pc != nullptr) && tk == 0;
 
+    Tile4 ra[2], rb[2];                                          // register ring of depth 2 (see gemm16_rows_kernel)
     const int nk = (int)((mend - mbeg + BK - 1) / BK);
-#define LBX_TN16_ACC()                                                                   \
-    if (do_csum) {                                                                       \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
-            csum.x += lb.v[j].x; csum.y += lb.v[j].y; csum.z += lb.v[j].z; csum.w += lb.v[j].w; \
-        }                                                                                \
-    }
+    auto fetch = [&](Tile4& a, Tile4& b, int t) {
+        if (t + 1 < nk) { la.load<false>(a, mend); lb.load<false>(b, mend); }
+        else { la.load<true>(a, mend); lb.load<true>(b, mend); }
+    };
+    auto stage = [&](int buf, const Tile4& a, const Tile4& b) {
+        if (do_csum) csum += KOuter16::colsum(b);                // fp32, before rounding; every tile exactly once
+        la.store(As[buf], a);
+        lb.store(Bs[buf], b);
+    };
     if (nk > 0) {
-        la.load<true>(mend);
-        lb.load<true>(mend);
-        LBX_TN16_ACC()
-        la.store(As[0]);
-        lb.store(Bs[0]);
+        fetch(ra[0], rb[0], 0);
+        if (nk > 1) fetch(ra[1], rb[1], 1);
+        stage(0, ra[0], rb[0]);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 2 < nk) { la.load<false>(mend); lb.load<false>(mend); }
-        else if (kt + 1 < nk) { la.load<true>(mend); lb.load<true>(mend); }
-        mma_tile16(As[cur], Bs[cur], wm, wn, lane, acc);
-        if (kt + 1 < nk) {
-            LBX_TN16_ACC()
-            la.store(As[cur ^ 1]);
-            lb.store(Bs[cur ^ 1]);
-        }
-        __syncthreads();
+#define LBX16_STEP(PAR)                                                   \
+    {                                                                     \
+        if (kt + 2 < nk) fetch(ra[PAR], rb[PAR], kt + 2);                 \
+        mma_tile16(As[PAR], Bs[PAR], wm, wn, lane, acc);                  \
+        if (kt + 1 < nk) stage((PAR) ^ 1, ra[(PAR) ^ 1], rb[(PAR) ^ 1]);  \
+        __syncthreads();                                                  \
+        ++kt;                                                             \
     }
-#undef LBX_TN16_ACC
+    for (int kt = 0; kt < nk;) {
+        LBX16_STEP(0)
+        if (kt < nk) LBX16_STEP(1)
+    }
+#undef LBX16_STEP
     float* Pd = P + (long)split * K1 * N;
     const int h = lane >> 5, l = lane & 31;
 #pragma unroll
@@ -352,13 +374,15 @@ __global__ __launch_bounds__(256) void gemm16_tn_kernel(RowsD A, RowsD Bd, float
         // the 8 k-quad lanes of one column quad are lanes (lane & ~7) + 0..7: fixed-order butterfly
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) {
-            csum.x += __shfl_xor(csum.x, o, 64);
-            csum.y += __shfl_xor(csum.y, o, 64);
-            csum.z += __shfl_xor(csum.z, o, 64);
-            csum.w += __shfl_xor(csum.w, o, 64);
+            f32x4 other;
+            other.x = __shfl_xor(csum.x, o, 64);
+            other.y = __shfl_xor(csum.y, o, 64);
+            other.z = __shfl_xor(csum.z, o, 64);
+            other.w = __shfl_xor(csum.w, o, 64);
+            csum += other;
         }
         const int c = n0 + 4 * lb.nq;
-        if (lb.kq == 0 && c < N) *reinterpret_cast<float4*>(Pc + (long)split * N + c) = csum;
+        if (lb.kq == 0 && c < N) *reinterpret_cast<f32x4*>(Pc + (long)split * N + c) = csum;
     }
 }
 
@@ -369,12 +393,13 @@ struct Rows16Plan {
     int splits, k_per_split;
 };
 
-// One tile shape; small-M problems (Dense layers) are split along K until ~3 workgroups per CU exist.
+// One tile shape; small-M problems (Dense layers) are split along K until ~2 workgroups per CU (the resident
+// count: ~190 VGPRs with two tiles in flight) exist.
 Rows16Plan plan_rows16(long M, int N, int K, size_t ws_bytes) {
     const long tiles = lbx_cdiv(M, BT) * lbx_cdiv(N, BT);
     Rows16Plan best{1, K};
     if (tiles >= 2 * NUM_CU) return best;
-    long s = lbx_cdiv(3 * NUM_CU, tiles);
+    long s = (2 * NUM_CU) / tiles;
     const long max_s = K / (2 * BK);                 // at least two K-steps per split
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
@@ -393,7 +418,7 @@ struct Tn16Plan {
 
 Tn16Plan plan_tn16(long M, int K1, int N) {
     const long tiles = lbx_cdiv(K1, BT) * lbx_cdiv(N, BT);
-    long s = lbx_cdiv(3 * NUM_CU, tiles);
+    long s = (2 * NUM_CU) / tiles;                   // whole rounds only: one workgroup too many costs a full round
     const long max_s = lbx_cdiv(M, 4 * BK);          // at least four K-steps per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;

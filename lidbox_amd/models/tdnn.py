@@ -51,21 +51,24 @@ def _rows(t_ptr, batch_stride, row_stride, batch, rpb):
 
 class _GemmFamily:
     """The C-ABI entry points of one GEMM family: fp32 MFMA (gemm.hip) or bf16 MFMA with fp32 storage and
-    accumulation (gemm_bf16.hip, BASELINE config 5).  Same signatures, separate workspace sizing."""
+    accumulation (gemm_bf16.hip, BASELINE config 5).  Same signatures, separate workspace sizing.  Entry points
+    are looked up on nv.lib at call time (profiling tools wrap them there)."""
+
+    _PREFIX = {"float32": "lidbox_gemm_", "bfloat16": "lidbox_gemm_bf16_"}
 
     def __init__(self, compute_dtype):
-        lib = nv.lib
         if compute_dtype in ("float32", "fp32", "f32", torch.float32):
             self.name = "float32"
-            self.nn, self.nt, self.tn = lib.lidbox_gemm_nn, lib.lidbox_gemm_nt, lib.lidbox_gemm_tn
-            self.rows_workspace, self.tn_workspace = lib.lidbox_gemm_rows_workspace, lib.lidbox_gemm_tn_workspace
         elif compute_dtype in ("bfloat16", "bf16", torch.bfloat16):
             self.name = "bfloat16"
-            self.nn, self.nt, self.tn = lib.lidbox_gemm_bf16_nn, lib.lidbox_gemm_bf16_nt, lib.lidbox_gemm_bf16_tn
-            self.rows_workspace = lib.lidbox_gemm_bf16_rows_workspace
-            self.tn_workspace = lib.lidbox_gemm_bf16_tn_workspace
         else:
             raise ValueError("compute_dtype must be 'float32' or 'bfloat16', got %r" % (compute_dtype,))
+        self._prefix = self._PREFIX[self.name]
+
+    def __getattr__(self, op):          # nn, nt, tn, rows_workspace, tn_workspace
+        if op.startswith("_"):
+            raise AttributeError(op)
+        return getattr(nv.lib, self._prefix + op)
 
 
 class _Workspace:
