@@ -142,8 +142,10 @@ def pmc_traffic(kernel_key):
         name = "gemm_rows_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), "true" if m.group(3) == "NT" else "false")
     elif kernel_key.startswith("gemm_tn_kernel<"):
         name = kernel_key[:-1] + ", true>"
-    else:
+    elif kernel_key == "fused_feat512_kernel":
         name = "fused_feat512_kernel<2, true, true>"
+    else:
+        return None                                            # no PMC pass committed for this kernel
     v = kern.get(name)
     return int(v["hbm_bytes_per_launch"]) if v else None
 
