@@ -150,7 +150,9 @@ enum {
     LIDBOX_EPI_BIAS_RELU = 2,   /* relu(. + bias[n])                          (frame_layer/segment_layer) */
     LIDBOX_EPI_RELU_MASK = 3,   /* . * (mask[m,n] > 0)   backward through ReLU; mask has C's layout */
     LIDBOX_EPI_ACCUM     = 4,   /* C += .                                                          */
-    LIDBOX_EPI_ACCUM_RELU_MASK = 5 /* C += . * (mask > 0)                                          */
+    LIDBOX_EPI_ACCUM_RELU_MASK = 5, /* C += . * (mask > 0)                                         */
+    LIDBOX_EPI_ACCUM_RELU = 6,  /* C = relu(C + .)       last tap of a dilated Conv1D (bias added by the first tap) */
+    LIDBOX_EPI_RELU      = 7    /* relu(.)               Dense(use_bias=False, activation="relu"), clstm.py:35 */
 };
 
 /* Which decomposition the cost model picks (for profiling tools: it names the kernel instantiation a
@@ -228,6 +230,17 @@ int lidbox_avg_pool_fwd(const float* x, int B, int T, int C, long batch_stride, 
                         float* out, lidbox_stream_t stream);
 int lidbox_avg_pool_bwd(const float* x, const float* dout, int B, int T, int C, long batch_stride,
                         long row_stride, int relu_mask, float* dx, lidbox_stream_t stream);
+
+/* lidbox/models/clstm.py:36-42 frequency_attention as used by xvector_freq_attention.py:29, on `rows` = B*T
+ * frames of C channels (dense [rows, C]); d_f <= 64 bins of C/d_f consecutive channels.
+ * fwd: F_out [rows, d_f] = softmax(logits) (may alias logits); Hw[r, c] = H[r, c] * F_out[r, c / (C/d_f)].
+ * bwd: dlogits = F * (dF - sum_f F*dF), dF[r, f] = sum_{c in bin f} dHw*H;  dH = dHw * F[bin]
+ *      (times (H > 0) when relu_mask != 0: H is the post-ReLU output of the last frame layer).  The
+ *      contribution through the Dense layers that produced the logits is added by the caller. */
+int lidbox_freq_attention_fwd(const float* H, const float* logits, long rows, int C, int d_f,
+                              float* F_out, float* Hw, lidbox_stream_t stream);
+int lidbox_freq_attention_bwd(const float* H, const float* F, const float* dHw, long rows, int C, int d_f,
+                              int relu_mask, float* dlogits, float* dH, lidbox_stream_t stream);
 
 /* tf.nn.log_softmax (xvector.py:65) over rows of z [B,N] */
 int lidbox_log_softmax_fwd(const float* z, int B, int N, float* logp, lidbox_stream_t stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblidbox_hip.so")
 ABI_VERSION = 1
 
 FEAT_SPECTROGRAM, FEAT_MEL, FEAT_LOGMEL, FEAT_MFCC = 0, 1, 2, 3
-EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_ACCUM_RELU_MASK = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_ACCUM_RELU_MASK, EPI_ACCUM_RELU, EPI_RELU = range(8)
 
 
 class LidboxHipError(RuntimeError):
@@ -81,6 +81,8 @@ _SIGS = {
     "lidbox_stats_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
     "lidbox_avg_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_avg_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
+    "lidbox_freq_attention_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp, _vp]),
+    "lidbox_freq_attention_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp]),
     "lidbox_log_softmax_fwd": (_i, [_vp, _i, _i, _vp, _vp]),
     "lidbox_nll_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "lidbox_l2_normalize_fwd": (_i, [_vp, _i, _i, _vp, _vp]),

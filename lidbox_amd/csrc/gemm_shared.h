@@ -46,6 +46,8 @@ __device__ __forceinline__ float apply_epi(float v, int epi, float bias, const f
         case LIDBOX_EPI_RELU_MASK: return aux[idx] > 0.f ? v : 0.f;
         case LIDBOX_EPI_ACCUM: return v + *dst;
         case LIDBOX_EPI_ACCUM_RELU_MASK: return *dst + (aux[idx] > 0.f ? v : 0.f);
+        case LIDBOX_EPI_ACCUM_RELU: return fmaxf(*dst + v, 0.f);
+        case LIDBOX_EPI_RELU: return fmaxf(v, 0.f);
         default: return v;
     }
 }
@@ -61,9 +63,9 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
     const int h = lane >> 5, l = lane & 31;
     const bool partial = gridDim.y > 1;
     const bool has_bias = !partial && (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU);
-    const bool do_relu = !partial && epi == LIDBOX_EPI_BIAS_RELU;
+    const bool do_relu = !partial && (epi == LIDBOX_EPI_BIAS_RELU || epi == LIDBOX_EPI_ACCUM_RELU || epi == LIDBOX_EPI_RELU);
     const bool has_mask = !partial && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
-    const bool accum = !partial && (epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    const bool accum = !partial && (epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU);
     int col[NJ];
     bool colok[NJ];
     float bias[NJ];
@@ -165,7 +167,7 @@ int validate_rows_call(const char* fn, const lidbox_rows_t& A, const float* Bm, 
     const char* msg = nullptr;
     if (!Bm || K < 1 || N < 0 || ldb < ldb_min) msg = "B != NULL, K >= 1, N >= 0, ldb large enough";
     else if ((long)A.batch * A.rows_per_batch != (long)C.batch * C.rows_per_batch) msg = "A and C row counts differ";
-    else if (epilogue < LIDBOX_EPI_NONE || epilogue > LIDBOX_EPI_ACCUM_RELU_MASK) msg = "epilogue";
+    else if (epilogue < LIDBOX_EPI_NONE || epilogue > LIDBOX_EPI_RELU) msg = "epilogue";
     else if (needs_aux && !aux) msg = "aux required by this epilogue";
     if (msg) {
         lidbox_set_error("%s: invalid argument: %s", fn, msg);

@@ -27,8 +27,32 @@ from .. import _native as nv
 
 
 class ConvSpec:
-    def __init__(self, name, filters, kernel_size, strides, relu=True):
+    """Keras Conv1D(filters, kernel_size, strides, padding="causal", dilation_rate).  The reference only ever sets
+    strides (xvector.py:38-39); dilation_rate is this build's opt-in and, as in Keras, excludes
+    strides > 1.  A dilated layer runs as k accumulating single-tap GEMMs over row-shifted views."""
+
+    def __init__(self, name, filters, kernel_size, strides, relu=True, dilation_rate=1):
         self.name, self.filters, self.k, self.s, self.relu = name, int(filters), int(kernel_size), int(strides), relu
+        self.d = int(dilation_rate) if int(kernel_size) > 1 else 1      # a single tap has nothing to dilate
+        if self.d < 1 or self.k < 1 or self.s < 1:
+            raise ValueError("kernel_size, strides and dilation_rate must be >= 1")
+        if self.d > 1 and self.s > 1:
+            raise ValueError("strides > 1 not supported in conjunction with dilation_rate > 1 (Keras Conv1D)")
+
+    @property
+    def pad(self):
+        """causal left padding in rows"""
+        return (self.k - 1) * self.d
+
+
+class FreqAttentionSpec:
+    """clstm.frequency_attention(H, d_a, d_f) (reference clstm.py:31-42) between the last frame layer and the
+    pooling: Dense(d_a, relu, no bias) "Wf_1" -> Dense(d_f, softmax, no bias) "Wf_2" -> bin-wise scaling."""
+
+    def __init__(self, d_a=64, d_f=16):
+        self.d_a, self.d_f = int(d_a), int(d_f)
+        if not 1 <= self.d_f <= 64:
+            raise ValueError("frequency attention supports 1 <= d_f <= 64 bins")
 
 
 class DenseSpec:
@@ -83,11 +107,20 @@ class _Workspace:
         for c in convs:
             self.Ts.append(conv_out_len(self.Ts[-1], c.s))
         chans = [model.input_dim] + [c.filters for c in convs]
-        self.pads = [c.k - 1 for c in convs] + [0]
+        self.pads = [c.pad for c in convs] + [0]
         # activations (zero-initialised once: the pad rows stay zero forever)
         self.act = [torch.zeros((B, self.pads[i] + self.Ts[i], chans[i]), **f32) for i in range(len(chans))]
         self.dact = [None] + [torch.zeros_like(a) for a in self.act[1:]]
         C_last = chans[-1]
+        att = model.attention
+        if att is not None:
+            n = B * self.Ts[-1]
+            self.fa_x1 = torch.zeros((n, att.d_a), **f32)            # relu(H Wf_1)
+            self.fa_F = torch.zeros((n, att.d_f), **f32)             # logits, then softmax in place
+            self.hw = torch.zeros_like(self.act[-1])                 # attention output = pooling input
+            self.d_hw = torch.zeros_like(self.act[-1])
+            self.d_logit = torch.zeros((n, att.d_f), **f32)
+            self.d_x1 = torch.zeros((n, att.d_a), **f32)
         P = 2 * C_last if model.pool == "stats" else C_last
         self.pooled = torch.zeros((B, P), **f32)
         self.dpooled = torch.zeros((B, P), **f32)
@@ -103,9 +136,14 @@ class _Workspace:
         for i, c in enumerate(convs):
             M = B * self.Ts[i + 1]
             if M > 0:
-                ws_bytes = max(ws_bytes, g.tn_workspace(M, c.k * cin, c.filters),
-                               g.rows_workspace(M, c.filters, c.k * cin), g.rows_workspace(M, c.k * cin, c.filters))
+                kk = cin if c.d > 1 else c.k * cin               # dilated layers run one tap per GEMM
+                ws_bytes = max(ws_bytes, g.tn_workspace(M, kk, c.filters),
+                               g.rows_workspace(M, c.filters, kk), g.rows_workspace(M, kk, c.filters))
             cin = c.filters
+        if att is not None and B * self.Ts[-1] > 0:
+            n = B * self.Ts[-1]
+            for (kk, nn_) in ((C_last, att.d_a), (att.d_a, att.d_f)):
+                ws_bytes = max(ws_bytes, g.tn_workspace(n, kk, nn_), g.rows_workspace(n, nn_, kk), g.rows_workspace(n, kk, nn_))
         din = P
         for d in model.denses:
             ws_bytes = max(ws_bytes, g.tn_workspace(B, din, d.units), g.rows_workspace(B, d.units, din),
@@ -123,7 +161,7 @@ class SequentialTDNN:
     """convs -> pool -> denses -> log_softmax, parameters in one flat buffer."""
 
     def __init__(self, input_shape, convs, pool, denses, name="tdnn", output_activation="log_softmax",
-                 channel_dropout_rate=0.0, seed=None, device=None, compute_dtype="float32"):
+                 channel_dropout_rate=0.0, seed=None, device=None, compute_dtype="float32", attention=None):
         if not torch.cuda.is_available():
             raise nv.LidboxHipError("lidbox_amd models need a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -131,7 +169,12 @@ class SequentialTDNN:
         self.input_shape = tuple(input_shape)
         self.input_dim = int(input_shape[-1])
         self.convs, self.pool, self.denses = list(convs), pool, list(denses)
+        self.attention = attention
         assert pool in ("stats", "avg")
+        if attention is not None and self.convs[-1].filters % attention.d_f:
+            # clstm.py:32
+            raise ValueError("amount of frequency channels (%d) must be evenly divisible by the amount of frequency "
+                             "attention bins (d_f=%d)" % (self.convs[-1].filters, attention.d_f))
         if output_activation not in ("log_softmax", None):
             raise ValueError("output_activation must be 'log_softmax' or None")
         self.output_activation = output_activation
@@ -143,6 +186,8 @@ class SequentialTDNN:
         self.compute_dtype = self.gemm.name
         if self.compute_dtype == "bfloat16":
             widths = [self.input_dim] + [c.filters for c in self.convs] + [d.units for d in self.denses]
+            if attention is not None:
+                widths += [attention.d_a, attention.d_f]
             if any(w % 4 for w in widths):
                 raise ValueError("bfloat16 compute needs channel / unit counts that are multiples of 4, got %s" % widths)
         # ---- flat parameter layout
@@ -153,6 +198,9 @@ class SequentialTDNN:
             self.layout[c.name + ".W"] = (off, (c.k, cin, c.filters)); off = _align4(off + c.k * cin * c.filters)
             self.layout[c.name + ".b"] = (off, (c.filters,)); off = _align4(off + c.filters)
             cin = c.filters
+        if attention is not None:                      # bias-free Dense kernels, Keras names Wf_1 / Wf_2 (clstm.py:35-36)
+            self.layout["Wf_1.W"] = (off, (cin, attention.d_a)); off = _align4(off + cin * attention.d_a)
+            self.layout["Wf_2.W"] = (off, (attention.d_a, attention.d_f)); off = _align4(off + attention.d_a * attention.d_f)
         din = 2 * cin if pool == "stats" else cin
         for d in self.denses:
             self.layout[d.name + ".W"] = (off, (din, d.units)); off = _align4(off + din * d.units)
@@ -226,6 +274,16 @@ class SequentialTDNN:
         Tp, C = a.shape[1], a.shape[2]
         return _rows(a.data_ptr(), Tp * C, c.s * C, ws.B, ws.Ts[i + 1])
 
+    def _tap_rows(self, buf, ws, i, j):
+        """rows of act[i] / dact[i] that tap j of dilated conv i touches: padded rows j*d + [0, T_out)."""
+        c = self.convs[i]
+        Tp, C = buf.shape[1], buf.shape[2]
+        return _rows(buf.data_ptr() + 4 * j * c.d * C, Tp * C, C, ws.B, ws.Ts[i + 1])
+
+    def _tap_weight(self, c, cin, j, grad=False):
+        """[C_in, C_out] block of tap j inside the Keras kernel [k, C_in, C_out]"""
+        return ctypes.c_void_p(self._p(c.name + ".W", grad).value + 4 * j * cin * c.filters)
+
     def _rows_out(self, buf, ws, i):
         """rows of act[i] / dact[i] behind the pad (what the producing layer writes)."""
         Tp, C = buf.shape[1], buf.shape[2]
@@ -237,14 +295,38 @@ class SequentialTDNN:
         lib = nv.lib
         cin = self.input_dim
         for i, c in enumerate(self.convs):
-            if ws.B * ws.Ts[i + 1] > 0:
+            if ws.B * ws.Ts[i + 1] > 0 and c.d == 1:
                 nv.check(self.gemm.nn(self._conv_rows_in(ws, i), self._p(c.name + ".W"), c.filters,
                                             self._rows_out(ws.act[i + 1], ws, i + 1), c.k * cin, c.filters,
                                             nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
                                             nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
+            elif ws.B * ws.Ts[i + 1] > 0:
+                # dilated: tap j reads rows shifted by j*d; the first tap adds the bias, the last applies the ReLU
+                out = self._rows_out(ws.act[i + 1], ws, i + 1)
+                for j in range(c.k):
+                    if j == 0:
+                        epi = nv.EPI_BIAS
+                    elif j < c.k - 1 or not c.relu:
+                        epi = nv.EPI_ACCUM
+                    else:
+                        epi = nv.EPI_ACCUM_RELU
+                    nv.check(self.gemm.nn(self._tap_rows(ws.act[i], ws, i, j), self._tap_weight(c, cin, j), c.filters,
+                                          out, cin, c.filters, epi, self._p(c.name + ".b") if j == 0 else None,
+                                          nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
             cin = c.filters
         last = ws.act[-1]
         T, C = last.shape[1], last.shape[2]
+        att = self.attention
+        if att is not None and ws.B * T > 0:
+            n = ws.B * T
+            gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
+            nv.check(self.gemm.nn(_rows(last.data_ptr(), 0, C, 1, n), self._p("Wf_1.W"), att.d_a,
+                                  _rows(ws.fa_x1.data_ptr(), 0, att.d_a, 1, n), C, att.d_a, nv.EPI_RELU, None, gws, gws_n, st))
+            nv.check(self.gemm.nn(_rows(ws.fa_x1.data_ptr(), 0, att.d_a, 1, n), self._p("Wf_2.W"), att.d_f,
+                                  _rows(ws.fa_F.data_ptr(), 0, att.d_f, 1, n), att.d_a, att.d_f, nv.EPI_NONE, None, gws, gws_n, st))
+            nv.check(lib.lidbox_freq_attention_fwd(nv.ptr(last), nv.ptr(ws.fa_F), n, C, att.d_f, nv.ptr(ws.fa_F),
+                                                   nv.ptr(ws.hw), st))
+            last = ws.hw
         fn = lib.lidbox_stats_pool_fwd if self.pool == "stats" else lib.lidbox_avg_pool_fwd
         nv.check(fn(nv.ptr(last), ws.B, T, C, T * C, C, nv.ptr(ws.pooled), st))
         x, din = ws.pooled, ws.pooled.shape[1]
@@ -309,15 +391,36 @@ class SequentialTDNN:
                                         nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE,
                                         nv.ptr(x) if relu_prev else None, gws, gws_n, st))
         # ---- pooling (fused with the ReLU backward of the last conv)
-        last = ws.act[-1]
+        att = self.attention
+        last = ws.act[-1] if att is None else ws.hw
+        dlast = ws.dact[-1] if att is None else ws.d_hw
         T, C = last.shape[1], last.shape[2]
         relu_last = 1 if self.convs[-1].relu else 0
+        pool_mask = relu_last if att is None else 0          # with attention the pooling input is not a ReLU output
         if self.pool == "stats":
             nv.check(lib.lidbox_stats_pool_bwd(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
-                                               relu_last, nv.ptr(ws.dact[-1]), st))
+                                               pool_mask, nv.ptr(dlast), st))
         else:
-            nv.check(lib.lidbox_avg_pool_bwd(nv.ptr(last), nv.ptr(ws.dpooled), B, T, C, T * C, C, relu_last,
-                                             nv.ptr(ws.dact[-1]), st))
+            nv.check(lib.lidbox_avg_pool_bwd(nv.ptr(last), nv.ptr(ws.dpooled), B, T, C, T * C, C, pool_mask,
+                                             nv.ptr(dlast), st))
+        if att is None or B * T == 0:
+            return
+        # ---- frequency attention (clstm.py:31-42): dact[-1] = mask(H) * (d_hw * F[bin] + d_x1 Wf_1^T)
+        n = B * T
+        H = ws.act[-1]
+        nv.check(lib.lidbox_freq_attention_bwd(nv.ptr(H), nv.ptr(ws.fa_F), nv.ptr(ws.d_hw), n, C, att.d_f, relu_last,
+                                               nv.ptr(ws.d_logit), nv.ptr(ws.dact[-1]), st))
+        x1r, dlr = _rows(ws.fa_x1.data_ptr(), 0, att.d_a, 1, n), _rows(ws.d_logit.data_ptr(), 0, att.d_f, 1, n)
+        Hr, dx1r = _rows(H.data_ptr(), 0, C, 1, n), _rows(ws.d_x1.data_ptr(), 0, att.d_a, 1, n)
+        self._launch_wgrad(ws, lambda w, n_, s_: nv.check(self.gemm.tn(
+            x1r, dlr, self._p("Wf_2.W", True), att.d_f, att.d_a, att.d_f, 0, None, w, n_, s_)))
+        nv.check(self.gemm.nt(dlr, self._p("Wf_2.W"), att.d_f, dx1r, att.d_f, att.d_a, nv.EPI_RELU_MASK,
+                              nv.ptr(ws.fa_x1), gws, gws_n, st))
+        self._launch_wgrad(ws, lambda w, n_, s_: nv.check(self.gemm.tn(
+            Hr, dx1r, self._p("Wf_1.W", True), att.d_a, C, att.d_a, 0, None, w, n_, s_)))
+        nv.check(self.gemm.nt(dx1r, self._p("Wf_1.W"), att.d_a, _rows(ws.dact[-1].data_ptr(), 0, C, 1, n), att.d_a, C,
+                              nv.EPI_ACCUM_RELU_MASK if relu_last else nv.EPI_ACCUM, nv.ptr(H) if relu_last else None,
+                              gws, gws_n, st))
 
     def backward_conv_ws(self, ws, i):
         """wgrad / bias grad of conv i and (i > 0) dgrad into dact[i]; dact[i+1] must be final."""
@@ -334,6 +437,9 @@ class SequentialTDNN:
             self.param(c.name + ".b", True).zero_()
             return
         dy = self._rows_out(ws.dact[i + 1], ws, i + 1)
+        if c.d > 1:
+            self._backward_dilated(ws, i, dy)
+            return
         A_rows = self._conv_rows_in(ws, i)
         self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
             A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
@@ -361,6 +467,34 @@ class SequentialTDNN:
             else:
                 epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
             nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+
+    def _backward_dilated(self, ws, i, dy):
+        """dilated conv i (strides 1): per tap j, dW[j] = act[i][rows + j*d]^T dY and
+        dact[i][rows + j*d] += mask * dY W[j]^T; the bias gradient comes with tap 0."""
+        st = nv.current_stream()
+        gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
+        c = self.convs[i]
+        cin = self.input_dim if i == 0 else self.convs[i - 1].filters
+        for j in range(c.k):
+            A_rows = self._tap_rows(ws.act[i], ws, i, j)
+            self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, j=j: nv.check(self.gemm.tn(
+                A_rows, dy, self._tap_weight(c, cin, j, True), c.filters, cin, c.filters, 0,
+                self._p(c.name + ".b", True) if j == 0 else None, w, n, s_)))
+        if i == 0:
+            return
+        dprev, aprev = ws.dact[i], ws.act[i]
+        relu_prev = self.convs[i - 1].relu
+        To = ws.Ts[i + 1]
+        if To < dprev.shape[1]:
+            dprev[:, To:, :].zero_()                        # rows tap 0 does not overwrite
+        for j in range(c.k):
+            mask = ctypes.c_void_p(aprev.data_ptr() + 4 * j * c.d * cin) if relu_prev else None
+            if j == 0:
+                epi = nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE
+            else:
+                epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
+            nv.check(self.gemm.nt(dy, self._tap_weight(c, cin, j), c.filters, self._tap_rows(dprev, ws, i, j), c.filters,
+                                  cin, epi, mask, gws, gws_n, st))
 
     # ------------------------------------------------------------------ public call
     def _load_input(self, ws, x, training):

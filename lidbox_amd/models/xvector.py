@@ -11,13 +11,14 @@ TIME_AXIS = 1
 STDDEV_SQRT_MIN_CLIP = 1e-10     # reference xvector.py:22 (applied inside lidbox_stats_pool_fwd)
 
 
-def frame_layer(filters, kernel_size, strides, padding="causal", activation="relu", name="frame"):
-    """reference xvector.py:38-39"""
+def frame_layer(filters, kernel_size, strides, padding="causal", activation="relu", name="frame", dilation_rate=1):
+    """reference xvector.py:38-39.  dilation_rate is not in the reference (its third argument is Keras `strides`);
+    it is this build's opt-in for Kaldi-style dilated TDNN contexts and follows Keras Conv1D(dilation_rate=...)."""
     if padding != "causal":
         raise ValueError("only padding='causal' is supported")
     if activation not in ("relu", None):
         raise ValueError("activation must be 'relu' or None")
-    return ConvSpec(name, filters, kernel_size, strides, relu=(activation == "relu"))
+    return ConvSpec(name, filters, kernel_size, strides, relu=(activation == "relu"), dilation_rate=dilation_rate)
 
 
 def segment_layer(units, activation="relu", name="segment"):

@@ -28,41 +28,44 @@ def conv1d_out_len(T, stride):
     return (T - 1) // stride + 1 if T > 0 else 0
 
 
-def im2col_causal(x, k, s):
-    """x [B,T,C] -> col [B,T_out,k*C] with col[b,t,j*C+c] = xpad[b, t*s+j, c],
-    xpad = (k-1) zero rows then x.  (Keras causal padding, lidbox/models/xvector.py:38-39.)"""
+def im2col_causal(x, k, s, d=1):
+    """x [B,T,C] -> col [B,T_out,k*C] with col[b,t,j*C+c] = xpad[b, t*s+j*d, c],
+    xpad = (k-1)*d zero rows then x.  (Keras causal padding, lidbox/models/xvector.py:38-39;
+    d = Conv1D dilation_rate -- the reference never sets it (SURVEY 8f.1 "opt-in dilation"), Keras
+    requires s == 1 when d > 1.)"""
     B, T, C = x.shape
+    assert d == 1 or s == 1, "Keras Conv1D: strides > 1 not supported together with dilation_rate > 1"
     To = conv1d_out_len(T, s)
-    xp = np.concatenate([np.zeros((B, k - 1, C), x.dtype), x], axis=1)
-    idx = np.arange(To)[:, None] * s + np.arange(k)[None, :]
+    xp = np.concatenate([np.zeros((B, (k - 1) * d, C), x.dtype), x], axis=1)
+    idx = np.arange(To)[:, None] * s + np.arange(k)[None, :] * d
     return xp[:, idx, :].reshape(B, To, k * C)
 
 
-def conv1d_causal_fwd(x, W, b, s, relu=True):
+def conv1d_causal_fwd(x, W, b, s, relu=True, d=1):
     """W [k,C_in,C_out] (Keras kernel layout), b [C_out]."""
     k, Ci, Co = W.shape
-    col = im2col_causal(x, k, s)
+    col = im2col_causal(x, k, s, d)
     y = col @ W.reshape(k * Ci, Co) + b
     return np.maximum(y, 0) if relu else y
 
 
-def conv1d_causal_bwd(x, W, y, dy, s, relu=True, need_dx=True):
+def conv1d_causal_bwd(x, W, y, dy, s, relu=True, need_dx=True, d=1):
     """Returns (dx, dW, db).  y is the post-activation output."""
     k, Ci, Co = W.shape
     B, T, _ = x.shape
     if relu:
         dy = dy * (y > 0)
-    col = im2col_causal(x, k, s)
+    col = im2col_causal(x, k, s, d)
     To = col.shape[1]
     dW = (col.reshape(-1, k * Ci).T @ dy.reshape(-1, Co)).reshape(k, Ci, Co)
     db = dy.reshape(-1, Co).sum(axis=0)
     dx = None
     if need_dx:
         dcol = (dy @ W.reshape(k * Ci, Co).T).reshape(B, To, k, Ci)
-        dxp = np.zeros((B, T + k - 1, Ci), x.dtype)
+        dxp = np.zeros((B, T + (k - 1) * d, Ci), x.dtype)
         for j in range(k):
-            dxp[:, np.arange(To) * s + j, :] += dcol[:, :, j, :]
-        dx = dxp[:, k - 1:, :]
+            dxp[:, np.arange(To) * s + j * d, :] += dcol[:, :, j, :]
+        dx = dxp[:, (k - 1) * d:, :]
     return dx, dW, db
 
 
@@ -222,6 +225,44 @@ def cnn_fwd(p, x, embedding=False):
     h = dense_fwd(h, p["fc_1.W"], p["fc_1.b"])
     h = dense_fwd(h, p["fc_2.W"], p["fc_2.b"])
     return log_softmax(dense_fwd(h, p["output.W"], p["output.b"], relu=False))
+
+
+# ------------------------------------------------------------------ 8f.1 frequency attention
+def softmax(z):
+    e = np.exp(z - z.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def freq_attention_fwd(H, Wf1, Wf2, return_cache=False):
+    """lidbox/models/clstm.py:31-42 as used by xvector_freq_attention.py:29: H [B,T,d_h];
+    x1 = relu(H Wf_1) (Dense d_a, no bias, :35); F_A = softmax(x1 Wf_2) over d_f bins (:36);
+    the d_h channels are partitioned into d_f consecutive bins of d_h/d_f channels (:39) and bin f is
+    scaled by F_A[..., f] (:38-40)."""
+    B, T, C = H.shape
+    d_f = Wf2.shape[1]
+    assert C % d_f == 0                                                              # clstm.py:32
+    x1 = np.maximum(H @ Wf1, 0)
+    F = softmax(x1 @ Wf2)
+    Hw = (H.reshape(B, T, d_f, C // d_f) * F[..., None]).reshape(B, T, C)
+    if return_cache:
+        return Hw, dict(x1=x1, F=F)
+    return Hw
+
+
+def freq_attention_bwd(H, Wf1, Wf2, cache, dHw):
+    """Returns (dH, dWf1, dWf2) of freq_attention_fwd (dH excludes any activation mask on H)."""
+    B, T, C = H.shape
+    d_f = Wf2.shape[1]
+    x1, F = cache["x1"], cache["F"]
+    dHw_b = dHw.reshape(B, T, d_f, C // d_f)
+    dF = (dHw_b * H.reshape(B, T, d_f, C // d_f)).sum(axis=-1)
+    dH = (dHw_b * F[..., None]).reshape(B, T, C)
+    dlogit = F * (dF - (F * dF).sum(axis=-1, keepdims=True))
+    dWf2 = x1.reshape(-1, x1.shape[-1]).T @ dlogit.reshape(-1, d_f)
+    dx1 = (dlogit @ Wf2.T) * (x1 > 0)
+    dWf1 = H.reshape(-1, C).T @ dx1.reshape(-1, x1.shape[-1])
+    dH = dH + dx1 @ Wf1.T
+    return dH, dWf1, dWf2
 
 
 # ------------------------------------------------------------------ a19 Adam (Keras)

@@ -382,3 +382,44 @@ def test_cavg_demo_known_answers():
     s = mo.SparseAverageDetectionCost(3, th)
     s.update_state(true_pos.argmax(1), pred)
     assert abs(s.result() - 0.375) < 1e-7
+
+
+# ------------------------------------------------------------------ SURVEY 8f.1 variants
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_oracle_dilated_conv_matches_torch_autograd(d):
+    """Keras Conv1D(padding="causal", dilation_rate=d) restated in model_np vs torch conv1d + autograd"""
+    import torch
+    import torch.nn.functional as F
+    from oracle import model_np as mo
+    rng = np.random.default_rng(d)
+    x, W, b = rng.standard_normal((2, 17, 5)), rng.standard_normal((3, 5, 4)) * 0.3, rng.standard_normal(4)
+    y = mo.conv1d_causal_fwd(x, W, b, 1, relu=True, d=d)
+    xt, Wt, bt = (torch.tensor(v, requires_grad=True) for v in (x, W, b))
+    yt = torch.relu(F.conv1d(F.pad(xt.transpose(1, 2), (2 * d, 0)), Wt.permute(2, 1, 0), bt, dilation=d)).transpose(1, 2)
+    assert np.abs(y - yt.detach().numpy()).max() < 1e-12
+    dy = rng.standard_normal(y.shape)
+    yt.backward(torch.tensor(dy))
+    dx, dW, db = mo.conv1d_causal_bwd(x, W, y, dy, 1, d=d)
+    for got, ref in ((dx, xt.grad), (dW, Wt.grad), (db, bt.grad)):
+        assert np.abs(got - ref.numpy()).max() < 1e-12
+
+
+def test_oracle_frequency_attention_matches_torch_autograd():
+    """clstm.py:31-42 restated in model_np.freq_attention_fwd/_bwd vs a torch transcription + autograd"""
+    import torch
+    from oracle import model_np as mo
+    rng = np.random.default_rng(5)
+    H = np.abs(rng.standard_normal((2, 7, 12)))
+    W1, W2 = rng.standard_normal((12, 5)) * 0.4, rng.standard_normal((5, 4)) * 0.4
+    Hw, cache = mo.freq_attention_fwd(H, W1, W2, True)
+    Ht, W1t, W2t = (torch.tensor(v, requires_grad=True) for v in (H, W1, W2))
+    FA = torch.softmax(torch.relu(Ht @ W1t) @ W2t, -1)
+    Hwt = (Ht.reshape(2, 7, 4, 3) * FA[..., None]).reshape(2, 7, 12)
+    assert np.abs(Hw - Hwt.detach().numpy()).max() < 1e-12
+    assert np.allclose(cache["F"].sum(-1), 1.0)
+    d = rng.standard_normal(Hw.shape)
+    Hwt.backward(torch.tensor(d))
+    for got, ref in zip(mo.freq_attention_bwd(H, W1, W2, cache, d), (Ht.grad, W1t.grad, W2t.grad)):
+        assert np.abs(got - ref.numpy()).max() < 1e-12
+    with pytest.raises(AssertionError):                     # clstm.py:32: channels must divide into the bins
+        mo.freq_attention_fwd(H, W1, rng.standard_normal((5, 5)))
