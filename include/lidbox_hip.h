@@ -214,6 +214,56 @@ size_t lidbox_colsum_workspace(long M, int N);
 int lidbox_colsum(lidbox_rows_t A, int N, float* out, int accumulate, void* workspace,
                   size_t workspace_bytes, lidbox_stream_t stream);
 
+/* ------------------------------------------------------------------ signal steps ahead of the features (8f.3)
+ * Ragged batches: utterance b = signals[starts[b] .. starts[b] + lengths[b]), `starts` / `lengths` = B int64
+ * each in DEVICE memory (gaps between utterances are allowed, e.g. 16-byte alignment of every start).
+ * Frames / chunks of all utterances are numbered consecutively; frame_offsets / chunk_offsets (B+1 int64, device,
+ * CSR) give each utterance's first one.  All entry points are stream-ordered; data-dependent sizes come back as
+ * counters for the caller to size the next buffer (the reference's eager tensors do the same). */
+
+/* data/steps.py:586-588,604-614 in float32 like the reference's tf.cast chain:
+ * out4 = {chunk_length, chunk_step, padded signal length, number of chunks} (host only) */
+int lidbox_signal_chunk_plan(long num_samples, int sample_rate, int length_ms, int step_ms, int max_pad_ms,
+                             long* out4);
+/* features/audio.py:314-317: RMS of every non-overlapping frame of frame_len samples (the tail is dropped):
+ * frame_rms[frame_offsets[b] + f] */
+int lidbox_frame_rms(const float* signals, const int64_t* starts, const int64_t* frame_offsets, int B,
+                     long total_frames, int frame_len, float* frame_rms, lidbox_stream_t stream);
+/* features/audio.py:318-326: per utterance threshold = strength * max(min_rms_threshold, mean frame RMS);
+ * decisions = rms > threshold (uint8 0/1); runs of 0 shorter than min_non_speech_frames are set to 1
+ * (invert_too_short_consecutive_false, :289-297).  Also returns slots[f] = number of speech frames before f in
+ * its utterance and counts[b] = speech frames of utterance b (inputs of lidbox_apply_vad).  thresholds: [B]. */
+int lidbox_vad_decisions(const float* frame_rms, const int64_t* frame_offsets, int B, long total_frames,
+                         float strength, float min_rms_threshold, int min_non_speech_frames,
+                         uint8_t* decisions, int32_t* slots, int32_t* counts, float* thresholds,
+                         lidbox_stream_t stream);
+/* slots / counts (as above) for decisions that came from elsewhere (data/steps.py:191-198 takes them as given) */
+int lidbox_vad_scan(const uint8_t* decisions, const int64_t* frame_offsets, int B, int32_t* slots, int32_t* counts,
+                    lidbox_stream_t stream);
+/* data/steps.py:191-198 (also features/audio.py:351-353): out[out_starts[b] + slot*frame_len ..] = speech frames */
+int lidbox_apply_vad(const float* signals, const int64_t* starts, const int64_t* frame_offsets,
+                     const uint8_t* decisions, const int32_t* slots, const int64_t* out_starts, int B,
+                     long total_frames, int frame_len, float* out, lidbox_stream_t stream);
+/* data/steps.py:611-614: out [total_chunks, chunk_len]; chunk c of utterance b = samples [c*step, c*step + len),
+ * zero past the utterance's end (the bounded padding of :611-612 is part of the plan that sized chunk_offsets) */
+int lidbox_signal_chunks(const float* signals, const int64_t* starts, const int64_t* lengths,
+                         const int64_t* chunk_offsets, int B, long total_chunks, int chunk_len, int chunk_step,
+                         float* out, lidbox_stream_t stream);
+/* features/audio.py:57-59: out = 10^(dBFS/20) * x / max|x| per utterance (same ragged layout as signals) */
+int lidbox_peak_normalize(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
+                          float dBFS, float* out, lidbox_stream_t stream);
+/* features/audio.py:266-270: out_rms[b] = sqrt(mean(x^2)) per utterance */
+int lidbox_signal_rms(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
+                      float* out_rms, lidbox_stream_t stream);
+/* features/audio.py:128-148 on B dense pairs [B, N]; snr_db [B]; three outputs [B, N] */
+int lidbox_snr_mixer(const float* clean, const float* noise, const float* snr_db, int B, long N,
+                     float* clean_norm, float* noise_new, float* noisy, lidbox_stream_t stream);
+
+/* lidbox/util.py:41-57 merge_chunk_predictions with the default stack_and_average: x [rows, D] sorted so that
+ * the rows of segment s are segment_offsets[s] .. segment_offsets[s+1] (int64, device); out [num_segments, D]. */
+int lidbox_segment_mean(const float* x, const int64_t* segment_offsets, int num_segments, int D, float* out,
+                        lidbox_stream_t stream);
+
 /* ------------------------------------------------------------------ pooling / losses / optimiser */
 
 /* lidbox/models/xvector.py:25-35 GlobalMeanStddevPooling1D: x [B,T,C] (batch_stride, row_stride

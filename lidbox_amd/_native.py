@@ -81,6 +81,16 @@ _SIGS = {
     "lidbox_stats_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
     "lidbox_avg_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_avg_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
+    "lidbox_signal_chunk_plan": (_i, [_l, _i, _i, _i, _i, _vp]),
+    "lidbox_frame_rms": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp, _vp]),
+    "lidbox_vad_decisions": (_i, [_vp, _vp, _i, _l, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "lidbox_vad_scan": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "lidbox_segment_mean": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "lidbox_apply_vad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp, _vp]),
+    "lidbox_signal_chunks": (_i, [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp, _vp]),
+    "lidbox_peak_normalize": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
+    "lidbox_signal_rms": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "lidbox_snr_mixer": (_i, [_vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp]),
     "lidbox_freq_attention_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp, _vp]),
     "lidbox_freq_attention_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp]),
     "lidbox_log_softmax_fwd": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -2,8 +2,9 @@
 Counterpart of lidbox/features/audio.py for the hot path: the same function names, argument
 names and defaults as the reference (cited per function, file:line relative to the lidbox
 checkout), over torch tensors on the HIP device.  All arithmetic runs in liblidbox_hip.so.
-File decoding, VAD, resampling and augmentation helpers of the reference module are out of
-scope.
+The energy VAD, silence removal, peak normalisation, RMS and SNR-mixer helpers run on the
+ragged-batch kernels of csrc/signal.hip through `signal_ops`; file decoding, resampling, WebRTC VAD and the
+random FIR augmentation stay out of scope (host libraries).
 """
 import math
 import threading
@@ -11,7 +12,7 @@ import threading
 import torch
 
 from .. import _native as nv
-from . import mel_ops
+from . import mel_ops, signal_ops
 
 _plans = {}
 _plan_lock = threading.Lock()
@@ -149,3 +150,60 @@ def db_to_power(S):
 def fft_frequencies(sample_rate, n_fft):
     """reference lidbox/features/audio.py:151-159 (host constant)."""
     return torch.linspace(0.0, float(int(sample_rate) // 2), 1 + int(n_fft) // 2)
+
+
+# ------------------------------------------------------------------ signal helpers (SURVEY 8f.3)
+def dBFS_to_linear(level):
+    """reference lidbox/features/audio.py:49-51"""
+    return 10.0 ** (float(_scalar(level)) / 20.0)
+
+
+def _one(signal):
+    x = nv.require_gpu_tensor(signal, "signal", torch.float32)
+    if x.dim() != 1:
+        raise ValueError("signal must be rank 1")
+    return signal_ops.RaggedSignals.from_list([x], device=x.device)
+
+
+def peak_normalize(signal, dBFS=0):
+    """reference lidbox/features/audio.py:57-59"""
+    r = signal_ops.peak_normalize(_one(signal), float(_scalar(dBFS)))
+    return r.split()[0].clone()
+
+
+def root_mean_square(x, axis=-1):
+    """reference lidbox/features/audio.py:266-270 for a rank-2 input reduced over its last axis"""
+    x = nv.require_gpu_tensor(x, "x", torch.float32)
+    if x.dim() != 2 or axis not in (-1, 1):
+        raise ValueError("root_mean_square expects [rows, samples] reduced over the last axis")
+    return signal_ops.signal_rms(signal_ops.RaggedSignals.from_dense(x))
+
+
+def framewise_rms_energy_vad_decisions(signal, sample_rate, frame_step_ms, min_non_speech_ms=0, strength=0.05,
+                                       min_rms_threshold=1e-3, time_axis=0):
+    """reference lidbox/features/audio.py:308-329 -> bool [num_frames]"""
+    if time_axis != 0:
+        raise ValueError("only time_axis=0 (rank-1 signals) is supported")
+    sample_rate = int(_scalar(sample_rate))
+    frame_step = ms_to_frames(sample_rate, frame_step_ms)
+    min_frames = int(ms_to_frames(sample_rate, min_non_speech_ms) / frame_step)                    # :325
+    vad = signal_ops.vad_decisions(_one(signal), frame_step, min_frames, strength, min_rms_threshold)
+    return vad["decisions"].to(torch.bool)
+
+
+def remove_silence(signal, rate, window_ms=10, min_non_speech_ms=300):
+    """reference lidbox/features/audio.py:337-353"""
+    rate = int(_scalar(rate))
+    window_frames = (int(window_ms) * rate) // 1000                                                # :341
+    frame_step = ms_to_frames(rate, window_ms)
+    if frame_step != window_frames:
+        raise ValueError("window_ms * rate must be a whole number of samples")     # the reference would fail at frames[vad_1]
+    r = _one(signal)
+    min_frames = int(ms_to_frames(rate, min_non_speech_ms) / frame_step)
+    vad = signal_ops.vad_decisions(r, frame_step, min_frames, strength=0.1)                        # :344-349
+    return signal_ops.apply_vad(r, vad).split()[0].clone()
+
+
+def snr_mixer(clean, noise, snr):
+    """reference lidbox/features/audio.py:128-148 (rank-1 signals; `signal_ops.snr_mixer` takes batches)"""
+    return signal_ops.snr_mixer(clean, noise, snr)
