@@ -145,11 +145,21 @@ def chunk_plan(num_samples, sample_rate, length_ms, step_ms, max_pad_ms=0):
     return tuple(int(v) for v in out)
 
 
+def chunk_counts(lengths, L, S, max_pad):
+    """steps.py:607-614 for an array of signal lengths (pure integer arithmetic; L, S, max_pad in samples)"""
+    n = np.asarray(lengths, np.int64)
+    full = np.maximum(0, 1 + (n - L) // S)                       # numpy // floors like tf's
+    last = n - full * S
+    n = np.where((last < L) & (L <= last + max_pad), n + L - last, n)
+    return np.where(n >= L, 1 + (n - L) // S, 0).astype(np.int64)
+
+
 def signal_chunks(r, sample_rate, length_ms, step_ms, max_pad_ms=0):
     """steps.py:600-614 for the whole batch -> (chunks [total_chunks, L] dense, chunks per utterance)"""
     dev = r.flat.device
     L, S = chunk_plan(0, sample_rate, length_ms, step_ms, max_pad_ms)[:2]
-    nch = np.array([chunk_plan(n, sample_rate, length_ms, step_ms, max_pad_ms)[3] for n in r.lengths_host], np.int64)
+    P = int(np.float32(sample_rate) * np.float32(1e-3 * max_pad_ms))                        # float32 cast chain of :588,606
+    nch = chunk_counts(r.lengths_host, L, S, P)
     co_h, co_d = _csr(nch, dev)
     total = int(co_h[-1])
     out = torch.empty((total, L), dtype=torch.float32, device=dev)
