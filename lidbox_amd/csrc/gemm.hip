@@ -45,6 +45,19 @@ namespace {
 #define LBX_GEMM_PRIO 3                    // s_setprio level of the MFMA phase (0 = leave the default)
 #endif
 constexpr int BK = LBX_GEMM_BK;           // K depth of one LDS tile (tuning aid: -DLBX_GEMM_BK=32)
+#ifndef LBX_GEMM_WAVES_HINT
+#define LBX_GEMM_WAVES_HINT 0              // 1: occupancy hint per tile shape (128x128 then fits 4 waves/SIMD in one unified
+                                           // register file).  Same-process A/B (tools/ab_gemm.py): 2355 vs 2360 us per step -- no gain
+#endif
+#ifndef LBX_GEMM_MASK_PREFETCH
+#define LBX_GEMM_MASK_PREFETCH 0           // 1: fetch the ReLU mask as bits inside the K loop (A/B: 2375 vs 2355 us -- the mask
+                                           // costs bandwidth / issue slots, not epilogue latency)
+#endif
+#if LBX_GEMM_WAVES_HINT
+#define LBX_ROWS_BOUNDS(BM, BN) __launch_bounds__(256, ((BM) * (BN) >= 16384 ? 3 : ((BM) * (BN) >= 8192 ? 6 : 8)))
+#else
+#define LBX_ROWS_BOUNDS(BM, BN) __launch_bounds__(256)
+#endif
 
 // ---- K-inner operand (contraction index contiguous in HBM): ROWS x BK tile, transposed into
 //      LDS [BK][ROWS + 2].  Each thread keeps one source pointer per pass and bumps it by BK.
@@ -216,7 +229,7 @@ __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int w
 // P[split][M][N] and rows_reduce_kernel finishes.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool B_KINNER, bool ALIGNED>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
+__global__ LBX_ROWS_BOUNDS(BM, BN) void gemm_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
                                                         RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K,
                                                         int N, int epi, const float* __restrict__ aux,
                                                         int tiles_n, unsigned ntiles, int k_per_split) {
@@ -267,11 +280,33 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
     }
     __syncthreads();
 
+    // Backward epilogues multiply by the ReLU mask (aux > 0, aux = the forward activation, C's layout).  Reading
+    // it in the epilogue costs one dependent HBM round trip per output row while the workgroup holds its slot
+    // without issuing MFMAs (PMC: 31 % of wave cycles parked in the NT launches vs 18 % in NN).  Instead every
+    // lane fetches its 16*MI*NJ mask values two per K-step, ahead of that step's tile loads (so they are back
+    // when the tile is), and keeps them as bits: the epilogue is store-only.
+    constexpr int NPRE = 16 * MI * NJ;
+    const bool pre_mask = LBX_GEMM_MASK_PREFETCH && gridDim.y == 1 &&
+                          (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    unsigned long long mbits = 0ull;
+    auto mask_ptr = [&](int idx) -> const float* {
+        const int r = idx & 15, blk = idx >> 4, bj = blk % NJ, bi = blk / NJ;
+        const long row = m0 + wm * (32 * MI) + bi * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+        const int col = n0 + wn * (32 * NJ) + bj * 32 + (lane & 31);
+        return aux + ((row < M && col < N) ? row_offset(Cd, (unsigned)row) + col : 0);
+    };
+
     // The prefetch of step kt targets tile kt+1; only the LAST tile can be partial, so interior
     // prefetches carry no predicates (a wave-uniform scalar branch picks the variant).  One MMA
     // site keeps the accumulators in place.
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+        const bool mload = pre_mask && 2 * kt < NPRE;        // wave-uniform
+        float mv0 = 0.f, mv1 = 0.f;
+        if (mload) {
+            mv0 = *mask_ptr(2 * kt);
+            mv1 = *mask_ptr(2 * kt + 1);
+        }
         if (kt + 2 < nk) {
             la.template load<false>(kend);
             if (B_KINNER) lbi.template load<false>(kend);
@@ -287,10 +322,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(RowsD A, const float* __
             if (B_KINNER) lbi.store(Bs[cur ^ 1]);
             else lbo.store(Bs[cur ^ 1]);
         }
+        if (mload)
+            mbits |= ((unsigned long long)(mv0 > 0.f) << (2 * kt)) | ((unsigned long long)(mv1 > 0.f) << (2 * kt + 1));
         __syncthreads();
     }
+    if (pre_mask)                                            // short K: the values no K-step fetched
+        for (int idx = 2 * nk; idx < NPRE; ++idx) mbits |= (unsigned long long)(*mask_ptr(idx) > 0.f) << idx;
 
-    store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split);
+    store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, mbits, pre_mask);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -58,7 +58,8 @@ __device__ __forceinline__ float apply_epi(float v, int epi, float bias, const f
 template <int MI, int NJ>
 __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], long m0, int n0, int wm, int wn, int lane,
                                                 long m_beg, long M, int N, int epi, const float* __restrict__ aux,
-                                                const RowsOutD& Cd, float* __restrict__ P, int split) {
+                                                const RowsOutD& Cd, float* __restrict__ P, int split,
+                                                unsigned long long mask_bits = 0ull, bool have_mask_bits = false) {
     // Epilogue kind as four uniform flags (no per-element switch); bias and column state hoisted.
     const int h = lane >> 5, l = lane & 31;
     const bool partial = gridDim.y > 1;
@@ -97,7 +98,12 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
                 if (!colok[bj]) continue;
                 float* dst = out_base + off + col[bj];
                 float v = acc[bi][bj][r] + bias[bj];
-                if (has_mask) v = aux[off + col[bj]] > 0.f ? v : 0.f;
+                if (has_mask) {
+                    // have_mask_bits: the caller read the mask during its K loop; bit (bi*NJ + bj)*16 + r
+                    const bool keep = have_mask_bits ? ((mask_bits >> ((bi * NJ + bj) * 16 + r)) & 1ull) != 0
+                                                     : aux[off + col[bj]] > 0.f;
+                    v = keep ? v : 0.f;
+                }
                 if (accum) v += *dst;
                 if (do_relu) v = fmaxf(v, 0.f);
                 *dst = v;

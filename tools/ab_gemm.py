@@ -1,0 +1,90 @@
+"""Same-process A/B timing of GEMM library variants built by tools/ab_build.py: every x-vector GEMM launch
+(B = 256) is timed alternately on each library, several rounds, medians reported.
+usage: python tools/ab_gemm.py tools/ab/libA.so tools/ab/libB.so [...]"""
+import ctypes as C
+import os
+import statistics
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lidbox_amd import _native as nv
+
+B, REPS, ROUNDS = 256, 10, 7
+
+
+def load(path):
+    lib = C.CDLL(os.path.abspath(path))
+    for name, (res, args) in nv._SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def rows(t, bs, rs, batch, rpb, off=0):
+    return nv.Rows(t.data_ptr() + 4 * off, bs, rs, batch, rpb)
+
+
+def timeit(fn):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / REPS * 1e3
+
+
+def main():
+    libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
+    st = nv.current_stream()
+    rws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    RW, RN = nv.ptr(rws), rws.numel()
+    cases = []
+    layers = [("frame1", 198, 40, 5, 1, 512), ("frame2", 198, 512, 3, 2, 512), ("frame3", 99, 512, 3, 3, 512),
+              ("frame4", 33, 512, 1, 1, 512), ("frame5", 33, 512, 1, 1, 1500)]
+    keep = []
+    for name, T, Cc, k, s, Co in layers:
+        To, Tp = (T - 1) // s + 1, T + k - 1
+        x = torch.randn(B, Tp, Cc, device="cuda"); W = torch.randn(k * Cc, Co, device="cuda") * 0.05
+        bias = torch.randn(Co, device="cuda"); y = torch.zeros(B, To, Co, device="cuda")
+        dy = torch.randn(B, To, Co, device="cuda"); dx = torch.zeros(B, Tp, Cc, device="cuda")
+        dW = torch.zeros(k * Cc, Co, device="cuda")
+        keep += [x, W, bias, y, dy, dx, dW]
+        M, K = B * To, k * Cc
+        A, Y, DY = rows(x, Tp * Cc, s * Cc, B, To), rows(y, To * Co, Co, B, To), rows(dy, To * Co, Co, B, To)
+        cases.append((name + " fwd", 2.0 * M * K * Co,
+                      lambda lib, A=A, W=W, Co=Co, Y=Y, K=K, bias=bias: lib.lidbox_gemm_nn(A, nv.ptr(W), Co, Y, K, Co, nv.EPI_BIAS_RELU, nv.ptr(bias), RW, RN, st)))
+        wsb = nv.lib.lidbox_gemm_tn_workspace(M, K, Co)
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda"); keep.append(ws)
+        cases.append((name + " wgrad", 2.0 * M * K * Co,
+                      lambda lib, A=A, DY=DY, dW=dW, Co=Co, K=K, bias=bias, ws=ws, wsb=wsb: lib.lidbox_gemm_tn(A, DY, nv.ptr(dW), Co, K, Co, 0, nv.ptr(bias), nv.ptr(ws), wsb, st)))
+        if name != "frame1":
+            for g in range((k + s - 1) // s):
+                nt = min(s, k - g * s)
+                Cd = rows(dx, Tp * Cc, s * Cc, B, To, off=g * s * Cc)
+                Wg = C.c_void_p(W.data_ptr() + 4 * g * s * Cc * Co)
+                mask = C.c_void_p(x.data_ptr() + 4 * g * s * Cc)
+                epi = nv.EPI_RELU_MASK if g == 0 else nv.EPI_ACCUM_RELU_MASK
+                cases.append(("%s dgrad%d" % (name, g), 2.0 * M * Co * nt * Cc,
+                              lambda lib, DY=DY, Wg=Wg, Co=Co, Cd=Cd, n=nt * Cc, epi=epi, mask=mask: lib.lidbox_gemm_nt(DY, Wg, Co, Cd, Co, n, epi, mask, RW, RN, st)))
+    totals = {n: 0.0 for n, _ in libs}
+    print("%-16s" % "launch" + "".join("%22s" % n for n, _ in libs))
+    for cname, fl, fn in cases:
+        t = {n: [] for n, _ in libs}
+        for n, lib in libs:
+            nv.check(fn(lib))
+        torch.cuda.synchronize()
+        for _ in range(ROUNDS):
+            for n, lib in libs:
+                t[n].append(timeit(lambda: fn(lib)))
+        line = "%-16s" % cname
+        for n, _ in libs:
+            med = statistics.median(t[n])
+            totals[n] += med
+            line += "%12.1f us %5.1f TF" % (med, fl / med / 1e6)
+        print(line, flush=True)
+    print("%-16s" % "TOTAL" + "".join("%12.1f us         " % totals[n] for n, _ in libs))
+
+
+if __name__ == "__main__":
+    main()

@@ -47,5 +47,27 @@ def main():
               (M, K, N, p, us_nn, fl / us_nn / 1e6, us_nt, fl / us_nt / 1e6), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--epilogues" not in sys.argv:
     main()
+
+
+def epilogues():
+    """cost of the backward epilogues at frame2's dgrad shape (dense operands)"""
+    st = nv.current_stream()
+    rws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    RW, RN = nv.ptr(rws), rws.numel()
+    for M, K, N in [(25344, 512, 1024), (25344, 512, 512), (8448, 512, 1536)]:
+        a = torch.randn(M, K, device="cuda")
+        b = torch.randn(N, K, device="cuda")
+        c = torch.zeros(M, N, device="cuda")
+        mask = torch.randn(M, N, device="cuda")
+        fl = 2.0 * M * K * N
+        A, Cd = rows(a, K, M), rows(c, N, M)
+        for name, epi, aux in [("none", nv.EPI_NONE, None), ("relu_mask", nv.EPI_RELU_MASK, nv.ptr(mask)),
+                               ("accum", nv.EPI_ACCUM, None), ("accum_relu_mask", nv.EPI_ACCUM_RELU_MASK, nv.ptr(mask))]:
+            us = timeit(lambda: nv.check(nv.lib.lidbox_gemm_nt(A, nv.ptr(b), K, Cd, K, N, epi, aux, RW, RN, st)))
+            print("NT M=%6d K=%5d N=%5d  %-16s %7.1f us %6.1f TF/s" % (M, K, N, name, us, fl / us / 1e6), flush=True)
+
+
+if __name__ == "__main__" and "--epilogues" in sys.argv:
+    epilogues()
