@@ -1,0 +1,152 @@
+"""
+BASELINE.json's FULL sizes on the GPU, checked through size-independent properties (the oracle is too slow at
+these sizes; it pins the same kernels at small sizes in the other test modules):
+
+  configs[1]  bs 256 x (16 kHz x 2 s), 4 languages, fp32            -- feature kernel + x-vector train step
+  configs[2]  bs 2048 = 8 x 256 sharded data-parallel                -- shard-mean gradient == global gradient
+  configs[4]  bs 4096 = 8 x 512, 100 languages, AP loss + C_avg      -- per-GPU shard of 512: counter identities
+
+Properties: batch independence and shift equivariance of the fused feature kernel (bit-exact), Parseval's
+identity of the STFT against the waveform, power scaling of the mel spectrogram, probability normalisation of
+the log-softmax output, data-parallel gradient equivalence (rel 1e-5), exact integer identities of
+the C_avg counters.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SR, N_SAMPLES, T, MEL = 16000, 32000, 198, 40
+
+
+def _batch(B, langs=4, seed=1234):
+    from lidbox_amd.testutil import synthetic_batch
+    sig, y = synthetic_batch(B, langs, SR, 2.0, seed=seed)
+    return torch.from_numpy(sig).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+
+
+def test_feature_kernel_full_batch_properties():
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    sig, _ = _batch(256)
+    plan = audio.get_plan(SR, 400, 160)
+    logmel = plan.run(nv.FEAT_LOGMEL, sig)
+    assert logmel.shape == (256, T, MEL) and bool(torch.isfinite(logmel).all())
+    # (1) batch independence, bit for bit: an utterance's features do not depend on its neighbours or position
+    for b in (0, 1, 100, 255):
+        assert torch.equal(plan.run(nv.FEAT_LOGMEL, sig[b:b + 1])[0], logmel[b])
+    perm = torch.randperm(256, device="cuda")
+    assert torch.equal(plan.run(nv.FEAT_LOGMEL, sig[perm].contiguous()), logmel[perm])
+    # (2) shift equivariance, bit for bit: dropping one hop of samples drops the first frame
+    shifted = plan.run(nv.FEAT_LOGMEL, sig[:, 160:].contiguous())
+    assert shifted.shape == (256, T - 1, MEL) and torch.equal(shifted, logmel[:, 1:])
+    # (3) Parseval for the 512-point real FFT of every windowed frame:
+    #     sum_k c_k |X_k|^2 = 512 * sum_n (w_n x_n)^2, c_0 = c_256 = 1, else 2
+    spec = plan.run(nv.FEAT_SPECTROGRAM, sig).double()
+    c = torch.full((257,), 2.0, dtype=torch.float64, device="cuda")
+    c[0] = c[256] = 1.0
+    lhs = (spec * c).sum(-1)
+    n = torch.arange(400, dtype=torch.float64, device="cuda")
+    w = 0.5 - 0.5 * torch.cos(2 * np.pi * n / 400)                  # periodic Hann
+    frames = sig.double().unfold(1, 400, 160)
+    rhs = 512.0 * ((frames * w) ** 2).sum(-1)
+    assert lhs.shape == rhs.shape == (256, T)
+    assert float(((lhs - rhs).abs() / rhs).max()) < 2e-5
+    # (4) power scaling: mel(a x) = a^2 mel(x); exact for a power of two (scaling by 2^k commutes with every
+    #     rounding of the FFT / |.|^2 / mel chain)
+    mel = plan.run(nv.FEAT_MEL, sig)
+    assert torch.equal(plan.run(nv.FEAT_MEL, 4.0 * sig), 16.0 * mel)
+    # (5) log-mel is the log of the mel kernel's output (fused epilogue == separate op)
+    assert float((logmel - torch.log(mel + 1e-6)).abs().max()) < 1e-5
+
+
+def test_config2_sharded_gradient_equals_global_gradient():
+    """BASELINE configs[2]: global batch 2048 = 8 shards of 256.  mean over shards of the shard-mean gradients
+    == gradient of the global-batch mean loss (what all-reduce(sum) x 1/world gives), SURVEY 8e rel 1e-5 -- here
+    relative to each tensor's largest entry, fp32 summation order being the only difference."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer, shard_bounds
+    sig, y = _batch(2048)
+    m = xvector.create((T, MEL), 4, seed=0)
+    tr = Trainer(m, feature=dict(plan=audio.get_plan(SR, 400, 160), kind=nv.FEAT_LOGMEL), use_graph=False)
+    loss_g, grad_g = tr.loss_and_grads(sig, y)
+    loss_g, grad_g = float(loss_g), grad_g.clone()
+    # probabilities: exp(logp) sums to one for every utterance of the full batch
+    logp = m.workspace(2048, T).logp
+    assert float((torch.exp(logp.double()).sum(-1) - 1).abs().max()) < 1e-5
+    acc = torch.zeros_like(grad_g, dtype=torch.float64)
+    losses = []
+    for r in range(8):
+        lo, hi = shard_bounds(2048, r, 8)
+        assert hi - lo == 256
+        l, g = tr.loss_and_grads(sig[lo:hi], y[lo:hi])
+        losses.append(float(l))
+        acc += g.double()
+    acc /= 8
+    assert abs(np.mean(losses) - loss_g) <= 1e-5 * abs(loss_g)
+    for name, (off, shape) in m.layout.items():
+        n = int(np.prod(shape))
+        a, b = acc[off:off + n], grad_g[off:off + n].double()
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-12, name
+    rel = float((acc - grad_g.double()).norm() / grad_g.double().norm())
+    assert rel < 1e-5, rel
+
+
+def test_config1_train_step_full_size_runs_and_learns():
+    """BASELINE configs[1] exactly as bench.py runs it: graph-captured step from waveforms, bs 256"""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer
+    sig, y = _batch(256)
+    m = xvector.create((T, MEL), 4, seed=0)
+    w0 = m.flat.clone()
+    tr = Trainer(m, feature=dict(plan=audio.get_plan(SR, 400, 160), kind=nv.FEAT_LOGMEL), use_graph=True)
+    l0 = float(tr.train_step(sig, y))
+    assert abs(l0 - np.log(4.0)) < 0.5                      # near-uniform predictions at initialisation
+    for _ in range(30):
+        l1 = float(tr.train_step(sig, y))
+    assert np.isfinite(l1) and l1 < 0.5 * l0
+    assert tr.step_count == 31
+    moved = (m.flat - w0).abs()
+    assert float(moved.max()) <= 31 * 1e-3 * 1.01           # Adam moves a weight by at most ~lr per step
+    assert float(moved.max()) > 1e-3
+
+
+def test_config5_shard_counter_identities_100_languages():
+    """BASELINE configs[4], one GPU's shard (512 utterances, 100 languages): AP loss + C_avg.  For every class
+    l, other class m and threshold: tp + fn == #utterances of l, fp_pairs + tn_pairs == #utterances of l (m != l)
+    and 0 on the diagonal -- exact integers, whatever the scores are."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.losses import SparseAngularProximity
+    from lidbox_amd.metrics import SparseAverageDetectionCost
+    from lidbox_amd.models import xvector
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    from lidbox_amd.train import Trainer
+    N, D, B = 100, 512, 512
+    sig, y = _batch(B, langs=N, seed=99)
+    convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
+             xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
+             xvector.frame_layer(1500, 1, 1, name="frame5")]
+    for dtype in ("float32", "bfloat16"):
+        m = SequentialTDNN((T, MEL), convs, "stats", [DenseSpec("segment1", D, relu=False)], output_activation=None,
+                           seed=0, compute_dtype=dtype)
+        metric = SparseAverageDetectionCost(N, np.linspace(-np.pi, 0, 100))
+        tr = Trainer(m, loss=SparseAngularProximity(N, D), feature=dict(plan=audio.get_plan(SR, 400, 160), kind=nv.FEAT_LOGMEL),
+                     use_graph=True, metric=metric)
+        steps = 3
+        for _ in range(steps):
+            loss = float(tr.train_step(sig, y))
+        assert np.isfinite(loss)
+        counts = torch.bincount(y.long(), minlength=N).float() * steps
+        assert torch.equal(metric.tp + metric.fn, counts[:, None].expand(N, 100))
+        pairs = metric.fp_pairs + metric.tn_pairs
+        expect = counts[:, None, None].expand(N, N, 100).clone()
+        expect[torch.arange(N), torch.arange(N)] = 0
+        assert torch.equal(pairs, expect)
+        c = float(metric.result())
+        assert 0.0 <= c <= 1.0
