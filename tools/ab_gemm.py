@@ -67,6 +67,18 @@ def main():
                 epi = nv.EPI_RELU_MASK if g == 0 else nv.EPI_ACCUM_RELU_MASK
                 cases.append(("%s dgrad%d" % (name, g), 2.0 * M * Co * nt * Cc,
                               lambda lib, DY=DY, Wg=Wg, Co=Co, Cd=Cd, n=nt * Cc, epi=epi, mask=mask: lib.lidbox_gemm_nt(DY, Wg, Co, Cd, Co, n, epi, mask, RW, RN, st)))
+    for name, K, N in [("segment1", 3000, 512), ("segment2", 512, 512), ("outputs", 512, 4)]:
+        x = torch.randn(B, K, device="cuda"); W = torch.randn(K, N, device="cuda") * 0.05
+        bias = torch.randn(N, device="cuda"); y = torch.zeros(B, N, device="cuda")
+        dy = torch.randn(B, N, device="cuda"); dx = torch.zeros(B, K, device="cuda"); dW = torch.zeros(K, N, device="cuda")
+        keep += [x, W, bias, y, dy, dx, dW]
+        A, Y, DY, DX = rows(x, 0, K, 1, B), rows(y, 0, N, 1, B), rows(dy, 0, N, 1, B), rows(dx, 0, K, 1, B)
+        fl = 2.0 * B * K * N
+        cases.append((name + " fwd", fl, lambda lib, A=A, W=W, N=N, Y=Y, K=K, bias=bias: lib.lidbox_gemm_nn(A, nv.ptr(W), N, Y, K, N, nv.EPI_BIAS_RELU, nv.ptr(bias), RW, RN, st)))
+        wsb = max(16, max(lib.lidbox_gemm_tn_workspace(B, K, N) for _, lib in libs))
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda"); keep.append(ws)
+        cases.append((name + " wgrad", fl, lambda lib, A=A, DY=DY, dW=dW, N=N, K=K, bias=bias, ws=ws, wsb=wsb: lib.lidbox_gemm_tn(A, DY, nv.ptr(dW), N, K, N, 0, nv.ptr(bias), nv.ptr(ws), wsb, st)))
+        cases.append((name + " dgrad", fl, lambda lib, DY=DY, W=W, N=N, DX=DX, K=K, x=x: lib.lidbox_gemm_nt(DY, nv.ptr(W), N, DX, N, K, nv.EPI_RELU_MASK, nv.ptr(x), RW, RN, st)))
     totals = {n: 0.0 for n, _ in libs}
     print("%-16s" % "launch" + "".join("%22s" % n for n, _ in libs))
     for cname, fl, fn in cases:
