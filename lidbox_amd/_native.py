@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblidbox_hip.so")
+# LIDBOX_HIP_LIB: debugging aid only (instrumented builds from tools/ab_build.py); the product loads the in-tree library
+LIB_PATH = os.environ.get("LIDBOX_HIP_LIB") or os.path.join(_HERE, "csrc", "liblidbox_hip.so")
 
 ABI_VERSION = 1
 

@@ -253,6 +253,12 @@ extern "C" int lidbox_feat_plan_channels(const lidbox_feat_plan* p, int kind) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+#ifndef LBX_FEAT_LOAD_BATCH
+#define LBX_FEAT_LOAD_BATCH 8               // sample loads in flight per lane and batch (16 = the whole frame at once)
+#endif
+#ifndef LBX_FEAT_WAVES
+#define LBX_FEAT_WAVES 3                    // waves per SIMD the register allocator aims for
+#endif
 constexpr float LOG_EPS = 1e-6f;           // tf_utils.py:178
 constexpr int EXCH_ROW = 144;              // bytes: 8 x (2 complex) + 16 pad  -> conflict-free b128
 constexpr int EXCH_FRAME = 8 * EXCH_ROW;   // 1152 B per frame per half pass
@@ -279,7 +285,22 @@ struct FusedArgs {
     long ntiles;                // B * tiles_per_utt
     int iters;                  // tiles per wave
     unsigned nwg;
+#ifdef LBX_FEAT_TIMING
+    long long* stamps;          // [nwg*4][12] s_memtime samples of each wave's first tile (debug builds only)
+#endif
 };
+
+#ifdef LBX_FEAT_TIMING
+#define LBX_STAMP(i)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (it == LBX_FEAT_TIMING && lane == 0 && a.stamps)                                       \
+            a.stamps[((long)blockIdx.x * 4 + wave) * 12 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define LBX_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -330,7 +351,7 @@ __device__ __forceinline__ void untangle(float2 zk, float2 zm, float2 w, float& 
 }
 
 template <int KIND, bool VEC4, bool POW2>
-__global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS carve: tables, then one scratch block per wave
     float* s_win = reinterpret_cast<float*>(smem);                    // 2048 B
@@ -387,7 +408,34 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
         //         per load makes the compiler wait for each one before issuing the next: 13 serialized
         //         HBM round trips per tile): lanes whose samples lie outside the frame / utterance read
         //         signals[0..3] instead and are zeroed by a select.
+        LBX_STAMP(0);
         float2 za[16], zb[16];
+#if LBX_FEAT_LOAD_BATCH == 16
+        {
+            float4 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int idx = 32 * j + 4 * q;
+                if (VEC4) {
+                    x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : a.signals);
+                } else {
+                    const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : a.signals;
+                    const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : a.signals;
+                    const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : a.signals;
+                    const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : a.signals;
+                    x[j] = make_float4(*p0, *p1, *p2, *p3);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int idx = 32 * n1 + 4 * q;
+                const float4 w = *reinterpret_cast<const float4*>(s_win + idx);      // zero beyond L
+                za[n1] = make_float2((valid && idx + 0 < a.L) ? x[n1].x * w.x : 0.f, (valid && idx + 1 < a.L) ? x[n1].y * w.y : 0.f);
+                zb[n1] = make_float2((valid && idx + 2 < a.L) ? x[n1].z * w.z : 0.f, (valid && idx + 3 < a.L) ? x[n1].w * w.w : 0.f);
+            }
+        }
+#else
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             float4 x[8];
@@ -414,10 +462,13 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
 
+        LBX_STAMP(1);
         // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
         dft16(za);
         dft16(zb);
+        LBX_STAMP(2);
         // ---- 3. twiddle by W256^(n2*k1)
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) {
@@ -426,6 +477,7 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
             zb[R16(k1)] = cmul(zb[R16(k1)], make_float2(w.z, w.w));
         }
 
+        LBX_STAMP(3);
         // ---- 4. exchange through LDS in two half passes; lane q ends with
         //         ua = A[0..15][k1 = q], ub = A[0..15][k1 = (16 - q) % 16, or 8 for q = 0]
         float2 ua[16], ub[16];
@@ -455,11 +507,13 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
             ub[2 * j] = make_float2(v.x, v.y);
             ub[2 * j + 1] = make_float2(v.z, v.w);
         }
+        LBX_STAMP(4);
         // ---- 5. pass 2: DFT16 over n2 -> Z'[k1 + 16*k2] in reg R16(k2)
         dft16(ua);
         dft16(ub);
         wave_lds_sync();                                 // exchange reads done before P overwrites
 
+        LBX_STAMP(5);
         // ---- 6. untangle conjugate pairs, |.|^2, into the per-frame power buffer.
         //   q != 0 : slot s pairs ua[k2=s] (bin q+16s) with ub[k2=15-s] (bin 256-q-16s)
         //   q == 0 : slots 0..8 pair ua[s] with ua[(16-s)%16] (bins 16s, 256-16s);
@@ -501,6 +555,7 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
         }
         wave_lds_sync();
 
+        LBX_STAMP(6);
         const int nvalid = min(8, a.T - t0);             // frames of this tile inside the utterance
         if (KIND == LIDBOX_FEAT_SPECTROGRAM) {
             float* dst = a.out + (long)b * a.out_bs + (long)t0 * 257;
@@ -522,6 +577,7 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
                 s_stage[f * a.M + m] = acc;
             }
             wave_lds_sync();
+            LBX_STAMP(7);
             if (KIND == LIDBOX_FEAT_MFCC) {
                 float* s_coef = s_stage + 8 * a.M;
                 for (int c = q; c < a.ncoef; c += 8) {
@@ -539,6 +595,7 @@ __global__ __launch_bounds__(256, 3) void fused_feat512_kernel(const FusedArgs a
                 for (int i = lane; i < total; i += 64) dst[i] = s_stage[i];
             }
         }
+        LBX_STAMP(8);
     }
 }
 
@@ -654,6 +711,9 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.win512 = p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
         a.mel_start = p->d_mel_start; a.mel_cnt = p->d_mel_cnt; a.mel_off = p->d_mel_off;
         a.mel_w = p->d_mel_w; a.dct = p->d_dct; a.out = out; a.out_bs = out_batch_stride;
+#ifdef LBX_FEAT_TIMING
+        a.stamps = (workspace && workspace_bytes >= (size_t)768 * 4 * 12 * 8) ? (long long*)workspace : nullptr;
+#endif
         a.tiles_per_utt = (T + 7) / 8;
         a.ntiles = (long)B * a.tiles_per_utt;
         // LDS: tables + 4 wave scratch blocks (must mirror the carve in the kernel)
@@ -664,7 +724,7 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
         const size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
         // persistent-ish grid: <= 3 workgroups per CU worth of waves, equal tile counts per wave
-        const long max_wg = 256 * 3;
+        const long max_wg = 256 * LBX_FEAT_WAVES;
         const long wg_needed = lbx_cdiv(a.ntiles, 4);
         a.iters = (int)lbx_cdiv(wg_needed, max_wg);
         a.nwg = (unsigned)lbx_cdiv(a.ntiles, 4L * a.iters);

@@ -1,10 +1,12 @@
-"""Debug (library built with -DLBX_FEAT_TIMING): per-phase cycle breakdown of the fused feature kernel."""
+"""Debug: per-phase s_memtime breakdown of the fused feature kernel.  Needs a library built with
+`python tools/ab_build.py feattiming features.hip -DLBX_FEAT_TIMING`; run as
+`LIDBOX_HIP_LIB=tools/ab/libfeattiming.so python tools/feat_phases.py [B]`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lidbox_amd.features import audio
 from lidbox_amd import _native as nv
-B = 2048
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 x = torch.randn(B, 32000, device="cuda") * 0.1
 plan = audio.get_plan(16000, 400, 160)
 out = torch.empty(B, 198, 40, device="cuda")
