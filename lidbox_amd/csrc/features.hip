@@ -253,8 +253,8 @@ extern "C" int lidbox_feat_plan_channels(const lidbox_feat_plan* p, int kind) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-#ifndef LBX_FEAT_LOAD_BATCH
-#define LBX_FEAT_LOAD_BATCH 8               // sample loads in flight per lane and batch (16 = the whole frame at once)
+#ifndef LBX_FEAT_FAST_INTERIOR
+#define LBX_FEAT_FAST_INTERIOR 1            // 0: always take the guarded sample-load path (A/B aid)
 #endif
 #ifndef LBX_FEAT_WAVES
 #define LBX_FEAT_WAVES 3                    // waves per SIMD the register allocator aims for
@@ -410,32 +410,28 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
         //         signals[0..3] instead and are zeroed by a select.
         LBX_STAMP(0);
         float2 za[16], zb[16];
-#if LBX_FEAT_LOAD_BATCH == 16
-        {
-            float4 x[16];
+        // Interior tiles (every read of the tile's 8 frames, up to sample 511 of the last one, stays inside the
+        // utterance -- wave-uniform test; 24 of 25 tiles at 2 s): one base address per lane and immediate offsets,
+        // no per-load address selects and no window guards: the samples after a frame are the utterance's own
+        // later samples and the window table is zero there.  The guarded path below handles an utterance's last tile.
+        const bool interior = VEC4 && LBX_FEAT_FAST_INTERIOR && (long)(t0 + 7) * a.S + 512 <= a.N;
+        if (interior) {
+            const float* base = src + 4 * q;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int idx = 32 * j + 4 * q;
-                if (VEC4) {
-                    x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : a.signals);
-                } else {
-                    const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : a.signals;
-                    const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : a.signals;
-                    const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : a.signals;
-                    const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : a.signals;
-                    x[j] = make_float4(*p0, *p1, *p2, *p3);
+            for (int half = 0; half < 2; ++half) {
+                float4 x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4*>(base + 32 * (8 * half + j));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n1 = 8 * half + j;
+                    const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);
+                    za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
+                    zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int idx = 32 * n1 + 4 * q;
-                const float4 w = *reinterpret_cast<const float4*>(s_win + idx);      // zero beyond L
-                za[n1] = make_float2((valid && idx + 0 < a.L) ? x[n1].x * w.x : 0.f, (valid && idx + 1 < a.L) ? x[n1].y * w.y : 0.f);
-                zb[n1] = make_float2((valid && idx + 2 < a.L) ? x[n1].z * w.z : 0.f, (valid && idx + 3 < a.L) ? x[n1].w * w.w : 0.f);
-            }
-        }
-#else
+        } else
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             float4 x[8];
@@ -462,7 +458,6 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
 
         LBX_STAMP(1);
         // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
