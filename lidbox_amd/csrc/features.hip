@@ -26,6 +26,7 @@
 // Generic path (any fft_length / frame_length): plain DFT against a twiddle table, one
 // workgroup per frame, spectrogram through a caller-provided workspace.  Correct, not fast.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -105,6 +106,10 @@ struct lidbox_feat_plan {
     int*    d_mel_cnt;       // [M]
     int*    d_mel_off;       // [M]
     float*  d_mel_w;         // [nnz]
+    int*    d_seg_meta;      // [3][64]: band (-1 = unused lane), first bin, index-in-band | segments-of-band << 8   (fused)
+    float*  d_seg_w;         // [seg_len][64] weights of lane's segment, zero padded                             (fused)
+    int     seg_len, seg_steps;   // bins per segment; shuffle steps that combine a band's segments
+    bool    seg_ok;          // the bands split into <= 64 segments of <= 32 bins
     float*  d_dct;           // [M][ncoef]
     void*   d_block;         // single allocation backing all of the above
 };
@@ -154,6 +159,39 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     p->nnz = (int)wts.size();
     if (wts.empty()) wts.push_back(0.0f);
 
+    // Segmented form for the fused kernel: every band is cut into ceil(cnt / seg_len) runs of consecutive bins,
+    // one wave lane per run (all 8 frames of a tile), with the smallest seg_len that fits the 64 lanes.
+    std::vector<int> seg_meta(3 * 64, 0);
+    std::vector<float> seg_w;
+    p->seg_ok = false;
+    for (int sl = 1; sl <= 32 && !p->seg_ok; ++sl) {
+        int total = 0, max_ns = 1;
+        for (int m = 0; m < M; ++m) {
+            const int ns = cnt[m] > 0 ? (cnt[m] + sl - 1) / sl : 1;
+            total += ns;
+            if (ns > max_ns) max_ns = ns;
+        }
+        if (total > 64) continue;
+        p->seg_ok = true;
+        p->seg_len = sl;
+        p->seg_steps = 0;
+        while ((1 << p->seg_steps) < max_ns) ++p->seg_steps;
+        seg_w.assign((size_t)sl * 64, 0.0f);
+        for (int i = 0; i < 64; ++i) seg_meta[i] = -1;
+        int lane = 0;
+        for (int m = 0; m < M; ++m) {
+            const int ns = cnt[m] > 0 ? (cnt[m] + sl - 1) / sl : 1;
+            for (int i = 0; i < ns; ++i, ++lane) {
+                const int b0 = start[m] + i * sl;
+                seg_meta[lane] = m;
+                seg_meta[64 + lane] = b0;
+                seg_meta[128 + lane] = i | (ns << 8);
+                for (int j = 0; j < sl && i * sl + j < cnt[m]; ++j) seg_w[(size_t)j * 64 + lane] = wts[off[m] + i * sl + j];
+            }
+        }
+    }
+    if (seg_w.empty()) seg_w.assign(64, 0.0f);
+
     // window
     std::vector<float> win(L), win512(512, 0.0f);
     lidbox_hann_window(L, win.data());
@@ -194,7 +232,9 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     size_t o_mo = o_mc + al((size_t)M * 4);
     size_t o_mw = o_mo + al((size_t)M * 4);
     size_t o_dct = o_mw + al(wts.size() * 4);
-    size_t total = o_dct + al(dct.size() * 4);
+    size_t o_sm = o_dct + al(dct.size() * 4);
+    size_t o_sw = o_sm + al(seg_meta.size() * 4);
+    size_t total = o_sw + al(seg_w.size() * 4);
     char* blk = nullptr;
     if (hipMalloc((void**)&blk, total) != hipSuccess) {
         lidbox_set_error("lidbox_feat_plan_create: hipMalloc(%zu) failed", total);
@@ -218,6 +258,8 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     LBX_UP(o_mo, off.data(), (size_t)M * 4);
     LBX_UP(o_mw, wts.data(), wts.size() * 4);
     LBX_UP(o_dct, dct.data(), dct.size() * 4);
+    LBX_UP(o_sm, seg_meta.data(), seg_meta.size() * 4);
+    LBX_UP(o_sw, seg_w.data(), seg_w.size() * 4);
 #undef LBX_UP
     p->d_win512 = (float*)(blk + o_win512);
     p->d_tw256 = (float2*)(blk + o_tw256);
@@ -229,6 +271,8 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     p->d_mel_off = (int*)(blk + o_mo);
     p->d_mel_w = (float*)(blk + o_mw);
     p->d_dct = (float*)(blk + o_dct);
+    p->d_seg_meta = (int*)(blk + o_sm);
+    p->d_seg_w = (float*)(blk + o_sw);
 
     // fused path limits: LDS tables must leave room for >= 2 workgroups per CU
     p->fused_ok = (nfft == 512) && (L <= 512) && (M <= 64) && (p->nnz <= 1024) &&
@@ -253,6 +297,15 @@ extern "C" int lidbox_feat_plan_channels(const lidbox_feat_plan* p, int kind) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+#ifndef LBX_FEAT_UNTANGLE_FENCE
+#define LBX_FEAT_UNTANGLE_FENCE 0           // n > 0: scheduling fence after every n untangle slots (register-pressure experiment)
+#endif
+#ifndef LBX_FEAT_NO_HOIST
+#define LBX_FEAT_NO_HOIST 1                  // keep the untangle's per-lane addresses out of loop-invariant registers
+#endif
+#ifndef LBX_FEAT_SEGMEL
+#define LBX_FEAT_SEGMEL 1                   // 0: always use the per-band CSR mel loop (A/B aid)
+#endif
 #ifndef LBX_FEAT_FAST_INTERIOR
 #define LBX_FEAT_FAST_INTERIOR 1            // 0: always take the guarded sample-load path (A/B aid)
 #endif
@@ -263,7 +316,8 @@ constexpr float LOG_EPS = 1e-6f;           // tf_utils.py:178
 constexpr int EXCH_ROW = 144;              // bytes: 8 x (2 complex) + 16 pad  -> conflict-free b128
 constexpr int EXCH_FRAME = 8 * EXCH_ROW;   // 1152 B per frame per half pass
 constexpr int P_STRIDE = 264;              // floats per frame in the power buffer (>= 257, = 8 mod 32)
-constexpr int WAVE_SCRATCH = 8 * EXCH_FRAME;   // 9216 B >= 8*264*4 = 8448 B (power buffer aliases it)
+constexpr int PT_ROWS = 257 + (256 >> 3) + 1; // transposed power buffer: row(bin) = bin + bin/8 (one skew row every 8 bins)
+constexpr int WAVE_SCRATCH = PT_ROWS * 32;     // 9280 B >= 8 * EXCH_FRAME = 9216 B >= 8*264*4 (the power buffers alias the exchange)
 
 struct FusedArgs {
     const float* signals;
@@ -271,6 +325,9 @@ struct FusedArgs {
     int B, N, T, L, S;
     float power_half;           // power / 2 (only used when power != 2)
     int M, ncoef, nnz;
+    int seg_len, seg_steps;     // segmented mel (SEGMEL kernels)
+    const int* seg_meta;
+    const float* seg_w;
     const float* win512;
     const float2* tw256;
     const float2* tw512;
@@ -350,19 +407,27 @@ __device__ __forceinline__ void untangle(float2 zk, float2 zm, float2 w, float& 
     pm = br * br + bi * bi;
 }
 
-template <int KIND, bool VEC4, bool POW2>
+// size of the mel tables in LDS (floats): CSR form [3M + nnz] or segmented form [3*64 + seg_len*64]
+__host__ __device__ inline int mel_table_floats(bool segmel, int M, int nnz, int seg_len) {
+    return segmel ? 3 * 64 + seg_len * 64 : 3 * M + nnz;
+}
+
+template <int KIND, bool VEC4, bool POW2, bool SEGMEL>
 __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS carve: tables, then one scratch block per wave
     float* s_win = reinterpret_cast<float*>(smem);                    // 2048 B
     float2* s_tw256 = reinterpret_cast<float2*>(smem + 2048);         // 2048 B
     float2* s_tw512 = reinterpret_cast<float2*>(smem + 4096);         // 2048 B
-    int* s_mstart = reinterpret_cast<int*>(smem + 6144);
+    int* s_mstart = reinterpret_cast<int*>(smem + 6144);             // CSR: start / cnt / off [M], weights [nnz]
     int* s_mcnt = s_mstart + a.M;
     int* s_moff = s_mcnt + a.M;
     float* s_mw = reinterpret_cast<float*>(s_moff + a.M);
-    float* s_dct = s_mw + a.nnz;
-    const int table_floats = 1536 + 3 * a.M + a.nnz + (KIND == LIDBOX_FEAT_MFCC ? a.M * a.ncoef : 0);
+    int* s_segmeta = reinterpret_cast<int*>(smem + 6144);            // SEGMEL: [3][64], weights [seg_len][64]
+    float* s_segw = reinterpret_cast<float*>(s_segmeta + 192);
+    const int mel_floats = mel_table_floats(SEGMEL, a.M, a.nnz, a.seg_len);
+    float* s_dct = reinterpret_cast<float*>(smem + 6144) + mel_floats;
+    const int table_floats = 1536 + mel_floats + (KIND == LIDBOX_FEAT_MFCC ? a.M * a.ncoef : 0);
     const int table_bytes = (table_floats * 4 + 15) & ~15;
     const int stage_floats = (KIND == LIDBOX_FEAT_SPECTROGRAM) ? 0 : 8 * a.M + (KIND == LIDBOX_FEAT_MFCC ? 8 * a.ncoef : 0);
     const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
@@ -372,12 +437,17 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
     s_tw256[tid] = a.tw256[tid];
     s_tw512[tid] = a.tw512[tid];
     if (KIND != LIDBOX_FEAT_SPECTROGRAM) {
-        for (int i = tid; i < a.M; i += 256) {
-            s_mstart[i] = a.mel_start[i];
-            s_mcnt[i] = a.mel_cnt[i];
-            s_moff[i] = a.mel_off[i];
+        if (SEGMEL) {
+            if (tid < 192) s_segmeta[tid] = a.seg_meta[tid];
+            for (int i = tid; i < a.seg_len * 64; i += 256) s_segw[i] = a.seg_w[i];
+        } else {
+            for (int i = tid; i < a.M; i += 256) {
+                s_mstart[i] = a.mel_start[i];
+                s_mcnt[i] = a.mel_cnt[i];
+                s_moff[i] = a.mel_off[i];
+            }
+            for (int i = tid; i < a.nnz; i += 256) s_mw[i] = a.mel_w[i];
         }
-        for (int i = tid; i < a.nnz; i += 256) s_mw[i] = a.mel_w[i];
         if (KIND == LIDBOX_FEAT_MFCC)
             for (int i = tid; i < a.M * a.ncoef; i += 256) s_dct[i] = a.dct[i];
     }
@@ -387,7 +457,7 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
     const int q = lane & 7;          // lane within the frame
     const int f = lane >> 3;         // frame slot within the wave
     char* wbuf = smem + table_bytes + wave * wave_bytes;
-    float* s_P = reinterpret_cast<float*>(wbuf);                         // [8][P_STRIDE], aliases exchange
+    float* s_P = reinterpret_cast<float*>(wbuf);                         // [8][P_STRIDE] or (SEGMEL) [PT_ROWS][8]; aliases exchange
     float* s_stage = reinterpret_cast<float*>(wbuf + WAVE_SCRATCH);      // [8][M] (+ [8][ncoef])
 
     const unsigned chunk = xcd_chunk_id(blockIdx.x, a.nwg);
@@ -513,8 +583,22 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
         //   q != 0 : slot s pairs ua[k2=s] (bin q+16s) with ub[k2=15-s] (bin 256-q-16s)
         //   q == 0 : slots 0..8 pair ua[s] with ua[(16-s)%16] (bins 16s, 256-16s);
         //            slots 9..16 pair ub[s-9] with ub[24-s]   (bins 8+16(s-9), 248-16(s-9))
+        // The per-lane bins / LDS addresses of this section depend only on q, so the compiler hoists them out of
+        // the tile loop as ~15 live registers -- and, at the 168-VGPR cap of 3 waves/SIMD, spills them to scratch and
+        // reloads them here every tile (15 dependent scratch loads in the busiest phase of the kernel).  An opaque
+        // copy of q keeps their (cheap) computation inside the loop instead.
+        int qv = q;
+#if LBX_FEAT_NO_HOIST
+        asm volatile("" : "+v"(qv));
+#endif
         float* Pf = s_P + f * P_STRIDE;
-        const bool q0 = (q == 0);
+        // SEGMEL: transposed [bin][frame] with one skew row per 8 bins, so that the mel lanes (one per run of bins,
+        // runs <= seg_len apart) read their 32-byte rows from different banks
+        auto P_store = [&](int bin, float v) {
+            if (SEGMEL) s_P[(bin + (bin >> 3)) * 8 + f] = v;
+            else Pf[bin] = v;
+        };
+        const bool q0 = (qv == 0);
 #pragma unroll
         for (int s = 0; s < 17; ++s) {
             float2 zk, zm;
@@ -524,13 +608,13 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                 const float2 alt = ua[R16((16 - s) & 15)];
                 const float2 gen = ub[R16(15 - s)];
                 zm = make_float2(q0 ? alt.x : gen.x, q0 ? alt.y : gen.y);
-                bin = q + 16 * s;
+                bin = qv + 16 * s;
             } else if (s < 16) {
                 const float2 g1 = ua[R16(s)], a1 = ub[R16(s - 9)];
                 const float2 g2 = ub[R16(15 - s)], a2 = ub[R16(24 - s)];
                 zk = make_float2(q0 ? a1.x : g1.x, q0 ? a1.y : g1.y);
                 zm = make_float2(q0 ? a2.x : g2.x, q0 ? a2.y : g2.y);
-                bin = q0 ? 8 + 16 * (s - 9) : q + 16 * s;
+                bin = q0 ? 8 + 16 * (s - 9) : qv + 16 * s;
             } else {
                 zk = ub[R16(7)];
                 zm = ub[R16(8)];
@@ -544,9 +628,12 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                     pk = __powf(pk, a.power_half);
                     pm = __powf(pm, a.power_half);
                 }
-                Pf[bin] = pk;
-                Pf[256 - bin] = pm;
+                P_store(bin, pk);
+                P_store(256 - bin, pm);
             }
+#if LBX_FEAT_UNTANGLE_FENCE
+            if ((s % LBX_FEAT_UNTANGLE_FENCE) == LBX_FEAT_UNTANGLE_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         wave_lds_sync();
 
@@ -562,6 +649,42 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                 }
             }
         } else {
+            if (SEGMEL) {
+                // ---- 7. banded mel, segmented: lane = one run of <= seg_len consecutive bins of one band, for all
+                //         8 frames of the tile (two 16-byte reads per bin); runs are zero-padded to seg_len so the
+                //         loop is uniform.  A band's partial sums sit in consecutive lanes and are combined in a
+                //         fixed order with wave shuffles; the band's first lane finishes (log) and stages.
+                const int sband = s_segmeta[lane], bin0 = s_segmeta[64 + lane], sinfo = s_segmeta[128 + lane];
+                float acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+                for (int j = 0; j < a.seg_len; ++j) {
+                    const float w = s_segw[j * 64 + lane];
+                    const int bin = min(bin0 + j, 256);
+                    const float* row = s_P + (bin + (bin >> 3)) * 8;
+                    const float4 p0 = *reinterpret_cast<const float4*>(row);
+                    const float4 p1 = *reinterpret_cast<const float4*>(row + 4);
+                    acc[0] = fmaf(p0.x, w, acc[0]); acc[1] = fmaf(p0.y, w, acc[1]);
+                    acc[2] = fmaf(p0.z, w, acc[2]); acc[3] = fmaf(p0.w, w, acc[3]);
+                    acc[4] = fmaf(p1.x, w, acc[4]); acc[5] = fmaf(p1.y, w, acc[5]);
+                    acc[6] = fmaf(p1.z, w, acc[6]); acc[7] = fmaf(p1.w, w, acc[7]);
+                }
+                const int sidx = sinfo & 255, sns = sinfo >> 8;
+                for (int st = 0; st < a.seg_steps; ++st) {
+                    const int d = 1 << st;
+                    const bool take = sidx + d < sns;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float t = __shfl_down(acc[i], d, 64);
+                        acc[i] += take ? t : 0.f;
+                    }
+                }
+                if (sband >= 0 && sidx == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        s_stage[i * a.M + sband] = (KIND != LIDBOX_FEAT_MEL) ? __logf(acc[i] + LOG_EPS) : acc[i];
+                }
+            } else {
             // ---- 7. banded mel: lane (f, q) owns bands q, q+8, ...
             for (int m = q; m < a.M; m += 8) {
                 const int st = s_mstart[m], cn = s_mcnt[m];
@@ -570,6 +693,7 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                 for (int j = 0; j < cn; ++j) acc = fmaf(Pf[st + j], wv[j], acc);
                 if (KIND != LIDBOX_FEAT_MEL) acc = __logf(acc + LOG_EPS);
                 s_stage[f * a.M + m] = acc;
+            }
             }
             wave_lds_sync();
             LBX_STAMP(7);
@@ -653,14 +777,21 @@ __global__ void generic_dct_kernel(const float* __restrict__ logmel, long nframe
 }
 
 template <int KIND>
-int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, size_t lds, hipStream_t st) {
+int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool segmel, size_t lds, hipStream_t st) {
     const bool pow2 = (p->power == 2.0f);
-#define LBX_FUSED(V, P2)                                                                          \
-    hipLaunchKernelGGL((fused_feat512_kernel<KIND, V, P2>), dim3(a.nwg), dim3(256), lds, st, a)
-    if (vec4 && pow2) LBX_FUSED(true, true);
-    else if (vec4) LBX_FUSED(true, false);
-    else if (pow2) LBX_FUSED(false, true);
-    else LBX_FUSED(false, false);
+#define LBX_FUSED(V, P2, SG)                                                                          \
+    hipLaunchKernelGGL((fused_feat512_kernel<KIND, V, P2, SG>), dim3(a.nwg), dim3(256), lds, st, a)
+    if (segmel && KIND != LIDBOX_FEAT_SPECTROGRAM) {
+        if (vec4 && pow2) LBX_FUSED(true, true, (KIND != LIDBOX_FEAT_SPECTROGRAM));
+        else if (vec4) LBX_FUSED(true, false, (KIND != LIDBOX_FEAT_SPECTROGRAM));
+        else if (pow2) LBX_FUSED(false, true, (KIND != LIDBOX_FEAT_SPECTROGRAM));
+        else LBX_FUSED(false, false, (KIND != LIDBOX_FEAT_SPECTROGRAM));
+    } else {
+        if (vec4 && pow2) LBX_FUSED(true, true, false);
+        else if (vec4) LBX_FUSED(true, false, false);
+        else if (pow2) LBX_FUSED(false, true, false);
+        else LBX_FUSED(false, false, false);
+    }
 #undef LBX_FUSED
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
@@ -703,6 +834,9 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.signals = signals; a.sig_stride = sig_stride; a.B = B; a.N = N; a.T = T;
         a.L = p->L; a.S = p->S; a.power_half = 0.5f * p->power;
         a.M = p->M; a.ncoef = p->ncoef; a.nnz = p->nnz;
+        a.seg_len = p->seg_len; a.seg_steps = p->seg_steps; a.seg_meta = p->d_seg_meta; a.seg_w = p->d_seg_w;
+        static const bool no_segmel = getenv("LIDBOX_FEAT_NO_SEGMEL") != nullptr;      // A/B aid
+        const bool segmel = LBX_FEAT_SEGMEL && p->seg_ok && !no_segmel && kind != LIDBOX_FEAT_SPECTROGRAM;
         a.win512 = p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
         a.mel_start = p->d_mel_start; a.mel_cnt = p->d_mel_cnt; a.mel_off = p->d_mel_off;
         a.mel_w = p->d_mel_w; a.dct = p->d_dct; a.out = out; a.out_bs = out_batch_stride;
@@ -712,7 +846,8 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.tiles_per_utt = (T + 7) / 8;
         a.ntiles = (long)B * a.tiles_per_utt;
         // LDS: tables + 4 wave scratch blocks (must mirror the carve in the kernel)
-        const int table_floats = 1536 + 3 * p->M + p->nnz + (kind == LIDBOX_FEAT_MFCC ? p->M * p->ncoef : 0);
+        const int table_floats = 1536 + mel_table_floats(segmel, p->M, p->nnz, p->seg_len) +
+                                 (kind == LIDBOX_FEAT_MFCC ? p->M * p->ncoef : 0);
         const int table_bytes = (table_floats * 4 + 15) & ~15;
         const int stage_floats = (kind == LIDBOX_FEAT_SPECTROGRAM) ? 0
                                  : 8 * p->M + (kind == LIDBOX_FEAT_MFCC ? 8 * p->ncoef : 0);
@@ -727,10 +862,10 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         const bool vec4 = (((uintptr_t)signals & 15) == 0) && (sig_stride % 4 == 0) &&
                           (p->S % 4 == 0) && (p->L % 4 == 0);
         switch (kind) {
-            case LIDBOX_FEAT_SPECTROGRAM: return launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, lds, st);
-            case LIDBOX_FEAT_MEL: return launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, lds, st);
-            case LIDBOX_FEAT_LOGMEL: return launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, lds, st);
-            default: return launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, lds, st);
+            case LIDBOX_FEAT_SPECTROGRAM: return launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, false, lds, st);
+            case LIDBOX_FEAT_MEL: return launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, segmel, lds, st);
+            case LIDBOX_FEAT_LOGMEL: return launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st);
+            default: return launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, segmel, lds, st);
         }
     }
 

@@ -35,7 +35,7 @@ def main():
             torch.cuda.synchronize()
             if ref is None:
                 ref = out.clone()
-            assert torch.equal(out, ref), n
+            assert float((out - ref).abs().max()) < 1e-4, (n, float((out - ref).abs().max()))
         for _ in range(9):
             for n, lib in libs:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
