@@ -658,16 +658,27 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                 float acc[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-                for (int j = 0; j < a.seg_len; ++j) {
-                    const float w = s_segw[j * 64 + lane];
-                    const int bin = min(bin0 + j, 256);
-                    const float* row = s_P + (bin + (bin >> 3)) * 8;
-                    const float4 p0 = *reinterpret_cast<const float4*>(row);
-                    const float4 p1 = *reinterpret_cast<const float4*>(row + 4);
-                    acc[0] = fmaf(p0.x, w, acc[0]); acc[1] = fmaf(p0.y, w, acc[1]);
-                    acc[2] = fmaf(p0.z, w, acc[2]); acc[3] = fmaf(p0.w, w, acc[3]);
-                    acc[4] = fmaf(p1.x, w, acc[4]); acc[5] = fmaf(p1.y, w, acc[5]);
-                    acc[6] = fmaf(p1.z, w, acc[6]); acc[7] = fmaf(p1.w, w, acc[7]);
+                // chunks of 4 bins: the 12 LDS reads of a chunk are issued before its 32 FMAs (the FFT registers are
+                // dead here, so the operands cost nothing); one LDS round trip per chunk instead of one per bin
+                for (int j0 = 0; j0 < a.seg_len; j0 += 4) {
+                    float w[4];
+                    float4 p0[4], p1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + u;
+                        w[u] = (j < a.seg_len) ? s_segw[min(j, a.seg_len - 1) * 64 + lane] : 0.f;
+                        const int bin = min(bin0 + j, 256);
+                        const float* row = s_P + (bin + (bin >> 3)) * 8;
+                        p0[u] = *reinterpret_cast<const float4*>(row);
+                        p1[u] = *reinterpret_cast<const float4*>(row + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[0] = fmaf(p0[u].x, w[u], acc[0]); acc[1] = fmaf(p0[u].y, w[u], acc[1]);
+                        acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
+                        acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
+                        acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
+                    }
                 }
                 const int sidx = sinfo & 255, sns = sinfo >> 8;
                 for (int st = 0; st < a.seg_steps; ++st) {
@@ -711,7 +722,18 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
             } else {
                 float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.M;
                 const int total = nvalid * a.M;
-                for (int i = lane; i < total; i += 64) dst[i] = s_stage[i];
+                if ((total & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+                    // 8 x M <= 512 floats (M <= 64 on this path): two float4 per lane cover the tile; both reads are
+                    // issued before the stores
+                    const int i0 = 4 * lane, i1 = 256 + 4 * lane;
+                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                    if (i0 < total) v0 = *reinterpret_cast<const float4*>(s_stage + i0);
+                    if (i1 < total) v1 = *reinterpret_cast<const float4*>(s_stage + i1);
+                    if (i0 < total) *reinterpret_cast<float4*>(dst + i0) = v0;
+                    if (i1 < total) *reinterpret_cast<float4*>(dst + i1) = v1;
+                } else {
+                    for (int i = lane; i < total; i += 64) dst[i] = s_stage[i];
+                }
             }
         }
         LBX_STAMP(8);
@@ -853,10 +875,13 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                                  : 8 * p->M + (kind == LIDBOX_FEAT_MFCC ? 8 * p->ncoef : 0);
         const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
         const size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
-        // persistent-ish grid: <= 3 workgroups per CU worth of waves, equal tile counts per wave
+        // grid: about four dispatch rounds of resident workgroups, equal tile counts per wave.  One tile per wave
+        // while that holds (B <= ~490 at 2 s): the dispatcher then balances the tail; measured 35 vs 39 us at B = 256
+        // against three tiles per wave on two thirds of the slots, and no difference at B = 2048.
         const long max_wg = 256 * LBX_FEAT_WAVES;
         const long wg_needed = lbx_cdiv(a.ntiles, 4);
-        a.iters = (int)lbx_cdiv(wg_needed, max_wg);
+        a.iters = (int)lbx_cdiv(wg_needed, 4 * max_wg);
+        if (const char* e = getenv("LIDBOX_FEAT_ITERS")) { const int v = atoi(e); if (v >= 1) a.iters = v; }   // tuning aid
         a.nwg = (unsigned)lbx_cdiv(a.ntiles, 4L * a.iters);
         // float4 loads need 16-byte aligned frames
         const bool vec4 = (((uintptr_t)signals & 15) == 0) && (sig_stride % 4 == 0) &&
