@@ -217,3 +217,28 @@ def test_bucket_plan_is_contiguous_partition():
     assert bounds[0] == 0 and bounds[-1] == 4510176 and len(bounds) == 3
     assert bounds[1] == 889856 and split == 2          # frame1+frame2 form the late (small) bucket
     assert plan_buckets(FakeModel(), 1) == ([0, 4510176], None)
+
+
+def test_host_signal_chunk_plan_matches_oracle(nv):
+    """lidbox_signal_chunk_plan (host-only entry point; reference steps.py:586-588,604-614) against the oracle's
+    restatement over a grid of lengths / sample rates / chunkings, and the vectorised count used by signal_ops"""
+    import ctypes
+    from oracle import signal_np as so
+    from lidbox_amd.features import signal_ops as sg
+    rng = np.random.default_rng(0)
+    out = (ctypes.c_long * 4)()
+    for sr in (8000, 16000, 22050, 44100):
+        for length_ms, step_ms, pad_ms in ((1000, 500, 0), (1000, 500, 400), (2000, 1500, 500), (250, 100, 250),
+                                           (10, 25, 10), (3, 1, 0), (30, 30, 29)):
+            ns = [0, 1, 2] + [int(v) for v in rng.integers(0, 5 * sr, size=20)]
+            L, S, _, _ = so.signal_chunk_plan(0, sr, length_ms, step_ms, pad_ms)
+            ns += [L - 1, L, L + 1, L + S - 1, L + S, 3 * L]
+            P = int(np.float32(sr) * np.float32(1e-3 * pad_ms))
+            counts = sg.chunk_counts(np.array(ns), L, S, P)
+            for n, c in zip(ns, counts):
+                nv.check(nv.lib.lidbox_signal_chunk_plan(n, sr, length_ms, step_ms, pad_ms, out))
+                ref = so.signal_chunk_plan(n, sr, length_ms, step_ms, pad_ms)
+                assert tuple(out) == ref, (sr, length_ms, step_ms, pad_ms, n)
+                assert c == ref[3]
+    with pytest.raises(ValueError):
+        nv.check(nv.lib.lidbox_signal_chunk_plan(100, 16000, 0, 10, 0, out))      # zero-length chunks
