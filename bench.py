@@ -143,7 +143,7 @@ def pmc_traffic(kernel_key):
     elif kernel_key.startswith("gemm_tn_kernel<"):
         name = kernel_key[:-1] + ", true>"
     elif kernel_key == "fused_feat512_kernel":
-        name = "fused_feat512_kernel<2, true, true>"
+        name = "fused_feat512_kernel<2, true, true, true>"
     else:
         return None                                            # no PMC pass committed for this kernel
     v = kern.get(name)
