@@ -11,6 +11,7 @@
 // Reductions over time run inside one workgroup (time is at most a few hundred frames);
 // row-wise ops give each row to one wave64 and reduce with wavefront shuffles.
 #include <float.h>
+#include <stdint.h>
 
 #include "common.h"
 
@@ -54,31 +55,69 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     }
 }
 
-// thread per (b, t, c), c fastest
-template <bool STATS>
-__global__ void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
-                                const float* __restrict__ dout, int B, int T, int C, long bs, long rs,
-                                int relu_mask, float* __restrict__ dx) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * T * C) return;
-    const int c = (int)(i % C);
-    const long bt = i / C;
-    const int t = (int)(bt % T);
-    const long b = bt / T;
-    const long off = b * bs + (long)t * rs + c;
-    const float xv = x[off];
-    float g;
-    if (STATS) {
-        const float mean = pooled[b * 2 * C + c], sd = pooled[b * 2 * C + C + c];
-        const float dmean = dout[b * 2 * C + c], dsd = dout[b * 2 * C + C + c];
-        // clip_by_value passes gradient only inside [1e-10, max]; sd == sqrt(1e-10) <=> clipped
-        const float dvar = sd > 1.0000001e-5f ? dsd / (2.f * sd) : 0.f;
-        g = (dmean + dvar * 2.f * (xv - mean)) / (float)T;
-    } else {
-        g = dout[b * C + c] / (float)T;
+// grid (ceil(C / (64*V)), B, time splits), one wave per block: a lane owns V consecutive channels of one utterance, loads
+// their pooling statistics once and streams its share of the T rows: dx = a + k * (x - mean), a = dmean / T,
+// k = 2 dvar / T  (no per-element index division, 16-byte accesses when C, the strides and the bases allow V = 4)
+template <bool STATS, int V>
+__global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
+                                                      const float* __restrict__ dout, int T, int C, long bs, long rs,
+                                                      int relu_mask, float* __restrict__ dx) {
+    const int c = (blockIdx.x * 64 + threadIdx.x) * V;
+    if (c >= C) return;
+    const long b = blockIdx.y;
+    const float invT = 1.f / (float)T;
+    float a[V], k[V], mean[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        if (STATS) {
+            const float sd = pooled[b * 2 * C + C + c + v], dsd = dout[b * 2 * C + C + c + v];
+            // clip_by_value passes gradient only inside [1e-10, max]; sd == sqrt(1e-10) <=> clipped
+            const float dvar = sd > 1.0000001e-5f ? dsd / (2.f * sd) : 0.f;
+            mean[v] = pooled[b * 2 * C + c + v];
+            a[v] = dout[b * 2 * C + c + v] * invT;
+            k[v] = dvar * 2.f * invT;
+        } else {
+            mean[v] = 0.f;
+            a[v] = dout[b * C + c + v] * invT;
+            k[v] = 0.f;
+        }
     }
-    if (relu_mask && !(xv > 0.f)) g = 0.f;
-    dx[off] = g;
+    const float* xp = x + b * bs + c;
+    float* dp = dx + b * bs + c;
+    for (int t = blockIdx.z; t < T; t += gridDim.z) {
+        float xv[V], g[V];
+        if (V == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(xp + (long)t * rs);
+            xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) xv[v] = xp[(long)t * rs + v];
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            g[v] = STATS ? fmaf(k[v], xv[v] - mean[v], a[v]) : a[v];
+            if (relu_mask && !(xv[v] > 0.f)) g[v] = 0.f;
+        }
+        if (V == 4) {
+            *reinterpret_cast<float4*>(dp + (long)t * rs) = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) dp[(long)t * rs + v] = g[v];
+        }
+    }
+}
+
+template <bool STATS>
+void launch_pool_bwd(const float* x, const float* pooled, const float* dout, int B, int T, int C, long bs, long rs,
+                     int relu_mask, float* dx, hipStream_t st) {
+    const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0;
+    const int V = vec ? 4 : 1;
+    unsigned zs = (unsigned)(T < 8 ? T : 8);                 // time splits: more waves for the small-batch case
+    dim3 grid((unsigned)lbx_cdiv(C, 64 * V), (unsigned)B, zs);
+    if (vec)
+        hipLaunchKernelGGL((pool_bwd_kernel<STATS, 4>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx);
+    else
+        hipLaunchKernelGGL((pool_bwd_kernel<STATS, 1>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx);
 }
 
 // one wave per row
@@ -363,8 +402,8 @@ extern "C" int lidbox_stats_pool_bwd(const float* x, const float* pooled, const 
     LBX_ARG(x && pooled && dout && dx && T >= 1 && C >= 1, "pointers != NULL; T, C >= 1");
     const long total = (long)B * T * C;
     if (total == 0) return LIDBOX_OK;
-    hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3((unsigned)lbx_cdiv(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, pooled, dout, B, T, C, bs, rs, relu_mask, dx);
+    LBX_ARG(B <= 65535, "B <= 65535");
+    launch_pool_bwd<true>(x, pooled, dout, B, T, C, bs, rs, relu_mask, dx, (hipStream_t)stream);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
@@ -374,8 +413,8 @@ extern "C" int lidbox_avg_pool_bwd(const float* x, const float* dout, int B, int
     LBX_ARG(x && dout && dx && T >= 1 && C >= 1, "pointers != NULL; T, C >= 1");
     const long total = (long)B * T * C;
     if (total == 0) return LIDBOX_OK;
-    hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3((unsigned)lbx_cdiv(total, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, (const float*)nullptr, dout, B, T, C, bs, rs, relu_mask, dx);
+    LBX_ARG(B <= 65535, "B <= 65535");
+    launch_pool_bwd<false>(x, nullptr, dout, B, T, C, bs, rs, relu_mask, dx, (hipStream_t)stream);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
