@@ -130,7 +130,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     LBX_ARG(power > 0.0f, "power > 0");
     if (coef_begin < 0) coef_begin = 0;
     if (coef_end > M) coef_end = M;
-    LBX_ARG(coef_end > coef_begin, "coef_end > coef_begin");
+    if (coef_end < coef_begin) coef_end = coef_begin;      // empty MFCC slice: only the MFCC kind is unavailable on this plan
 
     lidbox_feat_plan* p = new lidbox_feat_plan();
     memset(p, 0, sizeof(*p));
@@ -212,7 +212,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
         twN[j] = make_float2((float)cos(a), (float)sin(a));
     }
     // DCT rows: c_k = sqrt(2/M) sum_n x_n cos(pi k (2n+1) / (2M)), k in [coef_begin, coef_end)
-    std::vector<float> dct((size_t)M * p->ncoef);
+    std::vector<float> dct((size_t)M * p->ncoef + (p->ncoef == 0 ? 1 : 0));
     for (int n = 0; n < M; ++n)
         for (int c = 0; c < p->ncoef; ++c) {
             const int k = coef_begin + c;
@@ -843,6 +843,7 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                                            size_t workspace_bytes, lidbox_stream_t stream) {
     LBX_ARG(p && signals && out, "plan, signals, out != NULL");
     LBX_ARG(kind >= LIDBOX_FEAT_SPECTROGRAM && kind <= LIDBOX_FEAT_MFCC, "kind");
+    LBX_ARG(kind != LIDBOX_FEAT_MFCC || p->ncoef > 0, "the plan's MFCC slice [coef_begin, coef_end) is empty");
     LBX_ARG(B >= 0 && N >= 0 && sig_stride >= N, "B >= 0, N >= 0, sig_stride >= N");
     hipStream_t st = (hipStream_t)stream;
     const int T = lidbox_num_frames(N, p->L, p->S);
