@@ -193,7 +193,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     if (seg_w.empty()) seg_w.assign(64, 0.0f);
 
     // window
-    std::vector<float> win(L), win512(512, 0.0f);
+    std::vector<float> win(L), win512(516, 0.0f);      // [512..515] stay zero: the load target of masked lanes
     lidbox_hann_window(L, win.data());
     for (int i = 0; i < Leff && i < 512; ++i) win512[i] = 0.5f * win[i];
     // twiddles (double -> float)
@@ -223,7 +223,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     // one device block, 256-byte aligned pieces
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o_win512 = 0;
-    size_t o_tw256 = o_win512 + al(512 * 4);
+    size_t o_tw256 = o_win512 + al(516 * 4);
     size_t o_tw512 = o_tw256 + al(256 * 8);
     size_t o_win = o_tw512 + al(256 * 8);
     size_t o_twN = o_win + al((size_t)L * 4);
@@ -248,7 +248,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
         lidbox_feat_plan_destroy(p);                                                        \
         return LIDBOX_E_LAUNCH;                                                             \
     }
-    LBX_UP(o_win512, win512.data(), 512 * 4);
+    LBX_UP(o_win512, win512.data(), 516 * 4);
     LBX_UP(o_tw256, tw256.data(), 256 * 8);
     LBX_UP(o_tw512, tw512.data(), 256 * 8);
     LBX_UP(o_win, win.data(), (size_t)L * 4);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
         //         The loads are issued in two batches of 8 with NO control flow around them (a branch
         //         per load makes the compiler wait for each one before issuing the next: 13 serialized
         //         HBM round trips per tile): lanes whose samples lie outside the frame / utterance read
-        //         signals[0..3] instead and are zeroed by a select.
+        //         four zeros instead.
         LBX_STAMP(0);
         float2 za[16], zb[16];
         // Interior tiles (every read of the tile's 8 frames, up to sample 511 of the last one, stays inside the
@@ -508,23 +508,25 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int idx = 32 * (8 * half + j) + 4 * q;
+                // masked lanes read four zeros that sit behind the window table (finite whatever the signal holds),
+                // so the products below need no guards and the lane masks die here
+                const float* zero4 = a.win512 + 512;
                 if (VEC4) {
-                    x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : a.signals);
+                    x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : zero4);
                 } else {
-                    const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : a.signals;
-                    const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : a.signals;
-                    const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : a.signals;
-                    const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : a.signals;
+                    const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : zero4;
+                    const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : zero4;
+                    const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : zero4;
+                    const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : zero4;
                     x[j] = make_float4(*p0, *p1, *p2, *p3);
                 }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int n1 = 8 * half + j;
-                const int idx = 32 * n1 + 4 * q;
-                const float4 w = *reinterpret_cast<const float4*>(s_win + idx);      // zero beyond L
-                za[n1] = make_float2((valid && idx + 0 < a.L) ? x[j].x * w.x : 0.f, (valid && idx + 1 < a.L) ? x[j].y * w.y : 0.f);
-                zb[n1] = make_float2((valid && idx + 2 < a.L) ? x[j].z * w.z : 0.f, (valid && idx + 3 < a.L) ? x[j].w * w.w : 0.f);
+                const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);      // zero beyond L
+                za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
+                zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
