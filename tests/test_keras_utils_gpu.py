@@ -1,0 +1,100 @@
+"""
+GPU test of lidbox_amd.models.keras_utils (counterpart of reference lidbox/models/keras_utils.py:98-214): an
+experiment config drives model / optimizer / loss / metric / callback construction, `fit` runs the train step over
+a dataset of batches, checkpoints follow the reference's naming rule and the best one feeds the embedding extractor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(cache, key="xvector", loss=None, metrics=None, callbacks=None, kwargs=None):
+    return {"experiment": {
+        "cache_directory": cache, "name": "exp1", "model": {"key": key, "kwargs": kwargs or {"seed": 3}},
+        "input_shape": [50, 24], "output_shape": [4],
+        "optimizer": {"cls": "Adam", "kwargs": {"learning_rate": 3e-4}},
+        "loss": loss or {"cls": "SparseCategoricalCrossentropy", "kwargs": {"from_logits": True}},
+        "metrics": metrics if metrics is not None else [
+            {"cls": "SparseAverageDetectionCost", "N": 4, "threshold_linspace": {"start": -6.0, "stop": 0.0, "num": 25}},
+            {"cls": "SparseCategoricalAccuracy"}],
+        "callbacks": callbacks if callbacks is not None else [{"cls": "ModelCheckpoint"}, {"cls": "TensorBoard"}]}}
+
+
+MEANS = np.random.default_rng(123).standard_normal((4, 24)) * 1.5      # class centres shared by train and validation
+
+
+def _dataset(rng, n_batches, B=16, N=4):
+    means = MEANS
+    out = []
+    for _ in range(n_batches):
+        y = rng.integers(0, N, size=B)
+        x = rng.standard_normal((B, 50, 24)) * 0.5 + means[y][:, None, :]
+        out.append((torch.from_numpy(x.astype(np.float32)), torch.from_numpy(y.astype(np.int32))))
+    return out
+
+
+def test_from_config_fit_checkpoints_and_extractor(tmp_path):
+    from lidbox_amd.models import keras_utils as ku
+    from lidbox_amd.models import xvector
+    rng = np.random.default_rng(0)
+    cfg = _config(str(tmp_path))
+    w = ku.KerasWrapper.from_config(cfg)
+    assert w.model_key == "xvector" and w.count_params() == xvector.create((50, 24), 4).count_params()
+    assert "frame1.W" in str(w) and "Total params" in str(w)
+    train, val = _dataset(rng, 6), _dataset(rng, 2)
+    hist = w.fit(train, val, {"epochs": 4, "verbose": 0})
+    h = hist["history"]
+    assert hist["epoch"] == [0, 1, 2, 3] and len(h["loss"]) == 4
+    assert h["loss"][-1] < h["loss"][0] and h["val_loss"][-1] < h["val_loss"][0]
+    assert 0.0 <= h["val_C_avg"][-1] <= 1.0 and 0.0 <= h["val_sparse_categorical_accuracy"][-1] <= 1.0
+    # checkpoints: epoch{epoch:06d}__val_loss{val_loss:.12f} (reference keras_utils.py:58), best = lowest val_loss
+    ckdir = os.path.join(ku.experiment_cache_from_config(cfg), "checkpoints")
+    names = sorted(os.listdir(ckdir))
+    assert names == ["epoch%06d__val_loss%.12f.npz" % (e + 1, v) for e, v in enumerate(h["val_loss"])]
+    best = ku.KerasWrapper.get_best_checkpoint_path(ckdir, key="val_loss", mode="min")
+    assert os.path.basename(best) == names[int(np.argmin(h["val_loss"]))]
+    assert ku.KerasWrapper.get_best_checkpoint_path(ckdir) == os.path.join(ckdir, names[-1])      # key None -> greatest epoch
+    assert ku.best_model_checkpoint_from_config(cfg) == os.path.join(ckdir, names[-1])
+    assert ku.parse_checkpoint_value(best, "val_loss") == "%.12f" % min(h["val_loss"])
+    # resume: load_weights sets initial_epoch (reference :186-188) and fit continues from there
+    w2 = ku.KerasWrapper.from_config(cfg)
+    w2.load_weights(os.path.join(ckdir, names[1]))
+    assert w2.initial_epoch == 2
+    hist2 = w2.fit(train, val, {"epochs": 3, "verbose": 0})
+    assert hist2["epoch"] == [2]
+    # embedding extractor from the best checkpoint (reference :151-173)
+    ex_cfg = {"cache_directory": str(tmp_path), "model": cfg["experiment"]["model"], "experiment_name": "exp1",
+              "input_shape": [50, 24], "output_shape": [4], "best_checkpoint": {"monitor": "val_loss", "mode": "min"}}
+    extractor = ku.KerasWrapper.from_config_as_embedding_extractor_fn(ex_cfg)
+    x = val[0][0].cuda()
+    emb = extractor(x)
+    ref_model = xvector.create((50, 24), 4, seed=99)
+    ref_model.set_weights(dict(np.load(best)))
+    assert emb.shape == (16, 512) and torch.equal(emb, ref_model.embed(x))
+    assert os.path.exists(w.to_disk(str(tmp_path / "final")))
+
+
+def test_angular_proximity_config_early_stopping_and_errors(tmp_path):
+    from lidbox_amd.models import keras_utils as ku
+    from lidbox_amd.models.tdnn import SequentialTDNN
+    rng = np.random.default_rng(1)
+    with pytest.raises(ValueError):           # log-softmax outputs need from_logits=True
+        ku.KerasWrapper.from_config(_config(str(tmp_path), loss={"cls": "SparseCategoricalCrossentropy"}))
+    with pytest.raises(ValueError):
+        ku.KerasWrapper.from_config(_config(str(tmp_path), loss={"cls": "Huber"}))
+    cfg = _config(str(tmp_path), key="xvector_freq_attention",
+                  kwargs={"seed": 5, "output_activation": None, "freq_attention_bins": 60},
+                  loss={"cls": "SparseAngularProximity", "kwargs": {"N": 4, "D": 4}},
+                  metrics=[{"cls": "SparseAverageDetectionCost", "N": 4,
+                            "threshold_linspace": {"start": -3.2, "stop": 0.0, "num": 20}}],
+                  callbacks=[{"cls": "EarlyStopping", "kwargs": {"monitor": "val_loss", "patience": 0, "min_delta": 10.0}}])
+    w = ku.KerasWrapper.from_config(cfg)
+    assert isinstance(w.keras_model, SequentialTDNN) and w.keras_model.attention is not None
+    hist = w.fit(_dataset(rng, 3), _dataset(rng, 1), {"epochs": 5, "verbose": 0})
+    # min_delta = 10 can never be met: training stops after patience + 1 non-improving epochs (epoch 0 sets the best)
+    assert hist["epoch"] == [0, 1]
+    assert np.isfinite(hist["history"]["loss"]).all() and "val_C_avg" in hist["history"]
