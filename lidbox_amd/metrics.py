@@ -59,8 +59,20 @@ class AverageDetectionCost:
         return (out[0], c) if return_per_threshold else out[0]
 
     def counters(self):
-        """the four state tensors, e.g. for an all-reduce(sum) across data-parallel ranks"""
+        """the four state tensors"""
         return [self.tp, self.fn, self.fp_pairs, self.tn_pairs]
+
+    def sync_counters(self, group=None):
+        """Data parallelism: every rank counts its own shard; one all-reduce(sum) of the counters
+        ([N,Th] x 2 + [N,N,Th] x 2, 8 MB at N = Th = 100) before `result()` gives the global metric.  Counts are
+        integers held in float32, so the sum is exact and independent of the reduction order.  No-op without an
+        initialised process group.  Call it once per evaluation, then `reset_states()`."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        for t in self.counters():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return self
 
 
 class SparseAverageDetectionCost(AverageDetectionCost):

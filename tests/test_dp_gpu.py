@@ -31,6 +31,7 @@ _WORKER = textwrap.dedent("""
     from lidbox_amd.models import xvector
     from lidbox_amd.testutil import synthetic_batch
     from lidbox_amd.train import Trainer, init_distributed, shard_bounds
+    from lidbox_amd.metrics import SparseAverageDetectionCost
 
     use_graph = bool(int(sys.argv[1]))
     out_path = sys.argv[2]
@@ -55,8 +56,15 @@ _WORKER = textwrap.dedent("""
     if world > 1:
         dist.all_reduce(l)
         l /= world
+    # C_avg over the GLOBAL batch: each rank counts its shard, one all-reduce(sum) of the counters (SURVEY 8e)
+    metric = SparseAverageDetectionCost(4, np.linspace(-6.0, 0.0, 30))
+    feats = plan.run(nv.FEAT_LOGMEL, sd)
+    metric.update_state(yd, model(feats, training=False))
+    metric.sync_counters()
+    cavg, per_th = metric.result(return_per_threshold=True)
     if rank == 0:
-        np.savez(out_path, flat=model.flat.cpu().numpy(), losses=l.numpy())
+        np.savez(out_path, flat=model.flat.cpu().numpy(), losses=l.numpy(), cavg=float(cavg), per_th=per_th.cpu().numpy(),
+                 tp=metric.tp.cpu().numpy(), fn=metric.fn.cpu().numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -103,6 +111,12 @@ def test_two_rank_step_equals_single_process_step(tmp_path, use_graph):
     assert np.median(diff) <= 1e-6, np.median(diff)
     assert (diff > 2e-4).mean() <= 1e-3, (diff > 2e-4).mean()
     assert diff.max() <= 3 * 2e-3 + 1e-6                       # never more than 3 steps of +-lr apart
+    # metric counters: the two shards' counts, all-reduced, cover the global batch exactly (tp + fn = utterances per
+    # class at every threshold); the weights differ by ~1e-6, so individual threshold decisions may flip, C_avg barely
+    assert np.array_equal(single["tp"] + single["fn"], dual["tp"] + dual["fn"])
+    assert (single["tp"] + single["fn"]).sum(axis=0).max() == 12
+    assert abs(float(single["cavg"]) - float(dual["cavg"])) <= 0.05
+    assert np.abs(single["per_th"] - dual["per_th"]).max() <= 0.1
 
 
 def test_rccl_backend_between_graph_segments_world1():
