@@ -19,40 +19,92 @@ namespace {
 
 constexpr float STDDEV_SQRT_MIN_CLIP = 1e-10f;    // xvector.py:22
 
-// grid (ceil(C/64), B); 256 threads = 64 channels x 4 time groups
-template <bool STATS>
+// grid (ceil(C / (16*V)), B); 256 threads = 16 channel groups of V channels x 16 time groups.  Two passes over the
+// utterance's [T, C] block (the second one hits L2): mean, then mean((x - mean)^2) -- the reference's two-pass
+// population variance (xvector.py:31-33).  The 16 time groups are combined through LDS in a fixed order.
+template <bool STATS, int V>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x, int T, int C,
                                                        long bs, long rs, float* __restrict__ out) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
-    const int c = blockIdx.x * 64 + col;
+    __shared__ float red[16][16 * V + 1];
+    const int tid = threadIdx.x, cg = tid & 15, g = tid >> 4;
+    const int c = (blockIdx.x * 16 + cg) * V;
     const int b = blockIdx.y;
     const bool active = c < C;
     const float* xp = x + (long)b * bs + c;
-    float s = 0.f;
+    float s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.f;
     if (active)
-        for (int t = g; t < T; t += 4) s += xp[(long)t * rs];
-    red[tid] = s;
+        for (int t = g; t < T; t += 16) {
+            if (V == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(xp + (long)t * rs);
+                s[0] += q.x; s[1] += q.y; s[2] += q.z; s[3] += q.w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) s[v] += xp[(long)t * rs + v];
+            }
+        }
+#pragma unroll
+    for (int v = 0; v < V; ++v) red[g][cg * V + v] = s[v];
     __syncthreads();
-    const float mean = (red[col] + red[col + 64] + red[col + 128] + red[col + 192]) / (float)T;
+    float mean[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m += red[k][cg * V + v];
+        mean[v] = m / (float)T;
+    }
     if (!STATS) {
-        if (active && g == 0) out[(long)b * C + c] = mean;
+        if (active && g == 0)
+#pragma unroll
+            for (int v = 0; v < V; ++v) out[(long)b * C + c + v] = mean[v];
         return;
     }
     __syncthreads();
-    float v = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.f;
     if (active)
-        for (int t = g; t < T; t += 4) {
-            const float d = xp[(long)t * rs] - mean;
-            v = fmaf(d, d, v);
+        for (int t = g; t < T; t += 16) {
+            float xv[V];
+            if (V == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(xp + (long)t * rs);
+                xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) xv[v] = xp[(long)t * rs + v];
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float d = xv[v] - mean[v];
+                s[v] = fmaf(d, d, s[v]);
+            }
         }
-    red[tid] = v;
+#pragma unroll
+    for (int v = 0; v < V; ++v) red[g][cg * V + v] = s[v];
     __syncthreads();
     if (active && g == 0) {
-        const float var = (red[col] + red[col + 64] + red[col + 128] + red[col + 192]) / (float)T;
-        out[(long)b * 2 * C + c] = mean;
-        out[(long)b * 2 * C + C + c] = sqrtf(fminf(fmaxf(var, STDDEV_SQRT_MIN_CLIP), FLT_MAX));
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float var = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) var += red[k][cg * V + v];
+            var /= (float)T;
+            out[(long)b * 2 * C + c + v] = mean[v];
+            out[(long)b * 2 * C + C + c + v] = sqrtf(fminf(fmaxf(var, STDDEV_SQRT_MIN_CLIP), FLT_MAX));
+        }
     }
+}
+
+template <bool STATS>
+void launch_pool_fwd(const float* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
+    const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && (((uintptr_t)x) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL((pool_fwd_kernel<STATS, 4>), dim3((unsigned)lbx_cdiv(C, 64), (unsigned)B), dim3(256), 0, st, x, T,
+                           C, bs, rs, out);
+    else
+        hipLaunchKernelGGL((pool_fwd_kernel<STATS, 1>), dim3((unsigned)lbx_cdiv(C, 16), (unsigned)B), dim3(256), 0, st, x, T,
+                           C, bs, rs, out);
 }
 
 // grid (ceil(C / (64*V)), B, time splits), one wave per block: a lane owns V consecutive channels of one utterance, loads
@@ -379,8 +431,7 @@ extern "C" int lidbox_stats_pool_fwd(const float* x, int B, int T, int C, long b
     LBX_ARG(x && out && B >= 0 && T >= 1 && C >= 1, "x, out != NULL; T, C >= 1");
     if (B == 0) return LIDBOX_OK;
     LBX_ARG(B <= 65535, "B <= 65535");
-    hipLaunchKernelGGL(pool_fwd_kernel<true>, dim3((unsigned)lbx_cdiv(C, 64), B), dim3(256), 0,
-                       (hipStream_t)stream, x, T, C, bs, rs, out);
+    launch_pool_fwd<true>(x, B, T, C, bs, rs, out, (hipStream_t)stream);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
@@ -390,8 +441,7 @@ extern "C" int lidbox_avg_pool_fwd(const float* x, int B, int T, int C, long bs,
     LBX_ARG(x && out && B >= 0 && T >= 1 && C >= 1, "x, out != NULL; T, C >= 1");
     if (B == 0) return LIDBOX_OK;
     LBX_ARG(B <= 65535, "B <= 65535");
-    hipLaunchKernelGGL(pool_fwd_kernel<false>, dim3((unsigned)lbx_cdiv(C, 64), B), dim3(256), 0,
-                       (hipStream_t)stream, x, T, C, bs, rs, out);
+    launch_pool_fwd<false>(x, B, T, C, bs, rs, out, (hipStream_t)stream);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
