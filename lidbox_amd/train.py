@@ -103,10 +103,14 @@ class GradSync:
 
 
 def plan_buckets(model, num_buckets=2):
-    """Split the flat gradient into `num_buckets` contiguous buckets at conv-layer boundaries so
-    that the high bucket (reduced first, overlapped with the rest of backward) holds roughly the
-    upper half of the parameters.  Returns (bounds, split_conv_index): bucket 1 is complete once
-    backward_conv_ws(split_conv_index) has been enqueued."""
+    """Split the flat gradient into `num_buckets` contiguous buckets at conv-layer boundaries.  Backward fills the
+    flat buffer from its HIGH end, so the highest bucket is complete first and is reduced while the lower layers'
+    backward GEMMs still run; the lowest bucket is the only one whose reduction is exposed, so it is kept small.
+    The first split is the conv boundary closest to a quarter of the parameters (for the x-vector: frame1 + frame2
+    below, 3.6 MB); further buckets peel single conv layers off the low end (three buckets: frame1 | frame2 | rest,
+    exposed all-reduce 0.4 MB).  Returns (bounds, splits): bounds = element offsets [0, ..., numel]; splits =
+    ascending conv indices, bucket j+1 is complete once backward_conv_ws(splits[j]) has been enqueued; for two
+    buckets `splits` is the single index itself (None when there is one bucket)."""
     if num_buckets < 2 or len(model.convs) < 2:
         return [0, model.num_flat], None
     total = model.num_flat
@@ -116,7 +120,13 @@ def plan_buckets(model, num_buckets=2):
         score = abs(off - total * 0.25)          # lower layers finish last: keep the tail bucket small
         if best is None or score < best:
             best, best_i = score, i
-    return [0, model.layout[model.convs[best_i].name + ".W"][0], total], best_i
+    splits = [best_i]
+    i = best_i - 1
+    while len(splits) < num_buckets - 1 and i >= 1:
+        splits.insert(0, i)
+        i -= 1
+    bounds = [0] + [model.layout[model.convs[i].name + ".W"][0] for i in splits] + [total]
+    return bounds, (splits[0] if num_buckets == 2 else splits)
 
 
 # ------------------------------------------------------------------ trainer
@@ -156,7 +166,9 @@ class Trainer:
         self.m = torch.zeros(model.num_flat, **f32)
         self.v = torch.zeros(model.num_flat, **f32)
         self.adam_state = torch.zeros(16, dtype=torch.uint8, device=self.device)     # {int64 step, float lr_t}
-        bounds, self.split_conv = plan_buckets(model, num_buckets)
+        bounds, splits = plan_buckets(model, num_buckets)
+        self.splits = [] if splits is None else ([splits] if isinstance(splits, int) else list(splits))   # ascending conv indices
+        self.split_conv = self.splits[-1] if self.splits else None
         self.sync = GradSync(model.flat_grad, bounds, group)
         # overlap_wgrad: run wgrad GEMMs on a second stream concurrently with the dgrad chain.  Measured neutral
         # (96.1k vs 97.1k utt/s at bs 256): both are bound by the same matrix pipes.  Off by default.
@@ -218,20 +230,30 @@ class Trainer:
             ws.ap_per = torch.zeros(ws.B, dtype=torch.float32, device=self.device)
         return ws.ap_zn, ws.ap_dzn, ws.ap_per
 
-    def _backward_hi(self, ws):
-        """backward down to (and including) the split conv layer: bucket 1 is then complete"""
-        self.model.backward_head_ws(ws)
-        lo = self.split_conv if self.split_conv is not None else 0
-        for i in range(len(self.model.convs) - 1, lo - 1, -1):
-            self.model.backward_conv_ws(ws, i)
-        self.model.join_wgrad()                # bucket 1's gradients are complete on the current stream
-
-    def _backward_lo(self, ws):
-        if self.split_conv is None:
-            return
-        for i in range(self.split_conv - 1, -1, -1):
+    def _backward_stage(self, ws, k):
+        """Stage k of backward (k = 0 first).  Stage 0: dense head + pooling + the conv layers down to the highest
+        split; stage j: the conv layers between two splits; the last stage ends at conv 0.  After stage k the
+        gradient bucket (num_buckets - 1 - k) is complete on the current stream."""
+        convs = self.model.convs
+        hi_edges = [len(convs)] + self.splits[::-1]              # exclusive upper conv index of every stage
+        lo_edges = self.splits[::-1] + [0]
+        if k == 0:
+            self.model.backward_head_ws(ws)
+        for i in range(hi_edges[k] - 1, lo_edges[k] - 1, -1):
             self.model.backward_conv_ws(ws, i)
         self.model.join_wgrad()
+
+    @property
+    def num_stages(self):
+        return len(self.splits) + 1
+
+    def _backward_hi(self, ws):
+        """two-bucket view kept for callers / tests: everything down to the highest split"""
+        self._backward_stage(ws, 0)
+
+    def _backward_lo(self, ws):
+        for k in range(1, self.num_stages):
+            self._backward_stage(ws, k)
 
     def _adam(self):
         o = self.opt
@@ -257,10 +279,13 @@ class Trainer:
         B = inputs.shape[0]
         T = self.feature["plan"].num_frames(inputs.shape[1]) if self.feature is not None else inputs.shape[1]
         ws = self.model.workspace(B, T)
-        seg_a = lambda: (self._forward_loss(ws, inputs, labels), self._backward_hi(ws))     # noqa: E731
-        seg_b = lambda: self._backward_lo(ws)                                               # noqa: E731
-        seg_c = self._adam
-        entry = dict(ws=ws, inputs=inputs, labels=labels, eager=(seg_a, seg_b, seg_c), graphs=None)
+        # segment 0 = forward + loss + backward stage 0; segment k = backward stage k; last segment = Adam.  With
+        # gradient sync active a bucket's all-reduce is launched between two segments.
+        segs = [lambda: (self._forward_loss(ws, inputs, labels), self._backward_stage(ws, 0))]
+        for k in range(1, self.num_stages):
+            segs.append(lambda k=k: self._backward_stage(ws, k))
+        segs.append(self._adam)
+        entry = dict(ws=ws, inputs=inputs, labels=labels, eager=tuple(segs), graphs=None)
         if self.use_graph:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -268,16 +293,16 @@ class Trainer:
                 # warm-up on a side stream (required before capture); keeps optimizer and metric state untouched
                 self._warming = True
                 try:
-                    seg_a()
-                    seg_b()
+                    for seg in segs[:-1]:
+                        seg()
                 finally:
                     self._warming = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(self.device)
             if self.sync.active:
-                entry["graphs"] = (self._capture(seg_a), self._capture(seg_b), self._capture(seg_c))
+                entry["graphs"] = tuple(self._capture(seg) for seg in segs)
             else:
-                entry["graphs"] = (self._capture(lambda: (seg_a(), seg_b(), seg_c())),)
+                entry["graphs"] = (self._capture(lambda: [seg() for seg in segs]),)
         return entry
 
     # ---------------------------------------------------------------- public API
@@ -299,26 +324,17 @@ class Trainer:
                 entry = self._build(inputs, labels)
                 self._graphs[key] = entry
             ws = entry["ws"]
-            if entry["graphs"] is None:
-                a, b, c = entry["eager"]
-                a()
-                self.sync.launch(self.sync.num_buckets - 1)
-                b()
-                if self.sync.num_buckets > 1:
-                    self.sync.launch(0)
-                self.sync.wait()
-                c()
-            elif len(entry["graphs"]) == 1:
+            if entry["graphs"] is not None and len(entry["graphs"]) == 1:
                 entry["graphs"][0].replay()
             else:
-                ga, gb, gc = entry["graphs"]
-                ga.replay()
-                self.sync.launch(self.sync.num_buckets - 1)
-                gb.replay()
-                if self.sync.num_buckets > 1:
-                    self.sync.launch(0)
+                run = entry["eager"] if entry["graphs"] is None else [g.replay for g in entry["graphs"]]
+                nb = self.sync.num_buckets
+                for k in range(self.num_stages):
+                    run[k]()
+                    if k < nb:
+                        self.sync.launch(nb - 1 - k)              # bucket (nb-1-k) is complete after stage k
                 self.sync.wait()
-                gc.replay()
+                run[-1]()                                         # Adam
             return ws.loss[0]
 
     def loss_and_grads(self, inputs, labels):

@@ -217,6 +217,10 @@ def test_bucket_plan_is_contiguous_partition():
     assert bounds[0] == 0 and bounds[-1] == 4510176 and len(bounds) == 3
     assert bounds[1] == 889856 and split == 2          # frame1+frame2 form the late (small) bucket
     assert plan_buckets(FakeModel(), 1) == ([0, 4510176], None)
+    # three buckets: frame1 | frame2 | everything above; more than the conv boundaries allow degrades gracefully
+    assert plan_buckets(FakeModel(), 3) == ([0, 102912, 889856, 4510176], [1, 2])
+    b9, s9 = plan_buckets(FakeModel(), 9)
+    assert s9 == [1, 2] and b9 == [0, 102912, 889856, 4510176]
 
 
 def test_host_signal_chunk_plan_matches_oracle(nv):

@@ -35,6 +35,7 @@ _WORKER = textwrap.dedent("""
 
     use_graph = bool(int(sys.argv[1]))
     out_path = sys.argv[2]
+    num_buckets = int(sys.argv[3])
     os.environ["LOCAL_RANK"] = "0"                       # both ranks on the only GPU
     rank, world, _ = init_distributed(backend="gloo")
     torch.cuda.set_device(0)
@@ -45,8 +46,8 @@ _WORKER = textwrap.dedent("""
     yd = torch.from_numpy(y[lo:hi].astype(np.int32)).cuda()
     model = xvector.create((48, 40), 4, seed=0)
     plan = audio.get_plan(16000, 400, 160)
-    tr = Trainer(model, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=use_graph)
-    assert tr.sync.active == (world > 1) and tr.sync.num_buckets == 2
+    tr = Trainer(model, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=use_graph, num_buckets=num_buckets)
+    assert tr.sync.active == (world > 1) and tr.sync.num_buckets == num_buckets == tr.num_stages
     losses = []
     for _ in range(3):
         losses.append(float(tr.train_step(sd, yd)))
@@ -79,13 +80,13 @@ def _free_port():
     return p
 
 
-def _run(script, world, use_graph, out):
+def _run(script, world, use_graph, out, num_buckets=2):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script), str(int(use_graph)), str(out)], env=env,
+        procs.append(subprocess.Popen([sys.executable, str(script), str(int(use_graph)), str(out), str(num_buckets)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for rank, p in enumerate(procs):
         try:
@@ -97,12 +98,12 @@ def _run(script, world, use_graph, out):
     return np.load(out)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_rank_step_equals_single_process_step(tmp_path, use_graph):
+@pytest.mark.parametrize("use_graph,num_buckets", [(False, 2), (True, 2), (False, 3), (True, 3)])
+def test_two_rank_step_equals_single_process_step(tmp_path, use_graph, num_buckets):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % {"root": ROOT})
-    single = _run(script, 1, use_graph, tmp_path / "single.npz")
-    dual = _run(script, 2, use_graph, tmp_path / "dual.npz")
+    single = _run(script, 1, use_graph, tmp_path / "single.npz", num_buckets)
+    dual = _run(script, 2, use_graph, tmp_path / "dual.npz", num_buckets)
     # same loss trajectory and the same weights after 3 Adam steps, to fp32 summation-order tolerance
     assert np.allclose(single["losses"], dual["losses"], rtol=1e-5, atol=1e-6), (single["losses"], dual["losses"])
     # Adam normalises each update to ~lr, so a weight whose gradient is ~0 can legitimately flip sign on a

@@ -56,7 +56,7 @@ def test_from_config_fit_checkpoints_and_extractor(tmp_path):
     names = sorted(os.listdir(ckdir))
     assert names == ["epoch%06d__val_loss%.12f.npz" % (e + 1, v) for e, v in enumerate(h["val_loss"])]
     best = ku.KerasWrapper.get_best_checkpoint_path(ckdir, key="val_loss", mode="min")
-    assert os.path.basename(best) == names[int(np.argmin(h["val_loss"]))]
+    assert os.path.basename(best) in names          # ties at 12 decimals are possible: compare the parsed value below
     assert ku.KerasWrapper.get_best_checkpoint_path(ckdir) == os.path.join(ckdir, names[-1])      # key None -> greatest epoch
     assert ku.best_model_checkpoint_from_config(cfg) == os.path.join(ckdir, names[-1])
     assert ku.parse_checkpoint_value(best, "val_loss") == "%.12f" % min(h["val_loss"])
