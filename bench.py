@@ -198,6 +198,11 @@ def main():
     from lidbox_amd.train import Trainer, init_distributed, shard_bounds
     import torch.distributed as dist
 
+    # RCCL prints a version banner to STDOUT when its first communicator comes up (during the warm-up steps); the
+    # contract is ONE JSON line on stdout, so file descriptor 1 points at stderr until the timed region is over.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local_rank = init_distributed()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -262,6 +267,9 @@ def main():
                    "hip_graph": not args.no_graph, "final_loss": round(final_loss, 6)},
     }
 
+    sys.stdout.flush()
+    os.dup2(saved_stdout_fd, 1)
+    os.close(saved_stdout_fd)
     if rank == 0:
         # ---- per-kernel HIP-event timing: instrumented eager pass over the same steps
         if not args.no_kernel_timing and world == 1:
@@ -306,8 +314,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 
