@@ -31,8 +31,10 @@ class ConvSpec:
     strides (xvector.py:38-39); dilation_rate is this build's opt-in and, as in Keras, excludes
     strides > 1.  A dilated layer runs as k accumulating single-tap GEMMs over row-shifted views."""
 
-    def __init__(self, name, filters, kernel_size, strides, relu=True, dilation_rate=1):
+    def __init__(self, name, filters, kernel_size, strides, relu=True, dilation_rate=1, dense_kernel=False):
         self.name, self.filters, self.k, self.s, self.relu = name, int(filters), int(kernel_size), int(strides), relu
+        # a Keras Dense applied to [B, T, C] is a pointwise conv; dense_kernel keeps its kernel shape [in, out]
+        self.dense_kernel = bool(dense_kernel) and int(kernel_size) == 1
         self.d = int(dilation_rate) if int(kernel_size) > 1 else 1      # a single tap has nothing to dilate
         if self.d < 1 or self.k < 1 or self.s < 1:
             raise ValueError("kernel_size, strides and dilation_rate must be >= 1")
@@ -195,7 +197,8 @@ class SequentialTDNN:
         off = 0
         cin = self.input_dim
         for c in self.convs:
-            self.layout[c.name + ".W"] = (off, (c.k, cin, c.filters)); off = _align4(off + c.k * cin * c.filters)
+            self.layout[c.name + ".W"] = (off, (cin, c.filters) if c.dense_kernel else (c.k, cin, c.filters))
+            off = _align4(off + c.k * cin * c.filters)
             self.layout[c.name + ".b"] = (off, (c.filters,)); off = _align4(off + c.filters)
             cin = c.filters
         if attention is not None:                      # bias-free Dense kernels, Keras names Wf_1 / Wf_2 (clstm.py:35-36)

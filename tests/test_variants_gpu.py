@@ -174,3 +174,42 @@ def test_dilated_causal_conv_matches_oracle(d):
     for name, ref in g.items():
         gotg = m.param(name, grad=True).cpu().numpy()
         assert np.abs(gotg - ref).max() <= 1e-3 * max(1e-12, np.abs(ref).max()), name
+
+
+def test_dnn_matches_oracle_forward_and_backward():
+    """reference dnn.py:13-22: time-distributed Dense x4 -> GlobalAveragePooling1D -> Dense -> log_softmax"""
+    from lidbox_amd.models import dnn
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(50)
+    B, T, C, N = 5, 41, 24, 6
+    x = rng.standard_normal((B, T, C))
+    y = rng.integers(0, N, size=B).astype(np.int32)
+    m = dnn.create((T, C), N, seed=2)
+    w = m.get_weights()
+    assert [w["fc_%d.W" % i].shape for i in (1, 2, 3, 4)] == [(24, 200), (200, 400), (400, 600), (600, 800)]   # Dense kernels
+    assert w["output.W"].shape == (800, N) and m.count_params() == 24 * 200 + 200 + 200 * 400 + 400 + 400 * 600 + 600 + 600 * 800 + 800 + 800 * N + N
+    rb = np.random.default_rng(51)
+    m.set_weights({k: rb.standard_normal(v.shape) * 0.1 for k, v in w.items() if k.endswith(".b")})
+    p = _oracle_params(m)
+    acts, h = [x], x
+    for i in (1, 2, 3, 4):
+        h = mo.dense_fwd(h, p["fc_%d.W" % i], p["fc_%d.b" % i])
+        acts.append(h)
+    pooled = mo.global_avg_pool_fwd(h)
+    z = mo.dense_fwd(pooled, p["output.W"], p["output.b"], relu=False)
+    logp = mo.log_softmax(z)
+    assert np.abs(m(_dev(x)).cpu().numpy() - logp).max() < 1e-4
+    ref_loss = mo.sparse_ce_from_logits(logp, y)
+    dz = mo.sparse_ce_from_logits_grad(logp, y)
+    g = {}
+    dh, g["output.W"], g["output.b"] = mo.dense_bwd(pooled, p["output.W"], z, dz, relu=False)
+    dh = np.repeat(dh[:, None, :], T, axis=1) / T                     # GlobalAveragePooling1D backward
+    for i in (4, 3, 2, 1):
+        a_in, a_out = acts[i - 1].reshape(-1, acts[i - 1].shape[-1]), acts[i].reshape(-1, acts[i].shape[-1])
+        dx, g["fc_%d.W" % i], g["fc_%d.b" % i] = mo.dense_bwd(a_in, p["fc_%d.W" % i], a_out, dh.reshape(-1, dh.shape[-1]))
+        dh = dx.reshape(B, T, -1)
+    loss, _ = Trainer(m, use_graph=False).loss_and_grads(_dev(x), _dev(y, np.int32))
+    assert abs(float(loss) - ref_loss) <= 1e-4 * abs(ref_loss)
+    for name, ref in g.items():
+        gotg = m.param(name, grad=True).cpu().numpy()
+        assert np.abs(gotg - ref).max() <= 1e-3 * max(1e-12, np.abs(ref).max()), name
