@@ -213,3 +213,19 @@ def test_dnn_matches_oracle_forward_and_backward():
     for name, ref in g.items():
         gotg = m.param(name, grad=True).cpu().numpy()
         assert np.abs(gotg - ref).max() <= 1e-3 * max(1e-12, np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 8), (3, 7, 20), (2, 198, 40), (4, 50, 12)])
+def test_variant_models_valid_output_any_shape(shape):
+    """reference tests/test_models.py:30-35 (`_assert_valid_model_output`) for the model modules added under SURVEY 8f:
+    output [B, num_outputs], no NaN, training in {False, True}"""
+    from lidbox_amd.models import dnn, xvector_extended, xvector_freq_attention
+    rng = np.random.default_rng(9)
+    x = _dev(rng.uniform(-1e3, 1e3, size=shape))
+    for module in (dnn, xvector_extended, xvector_freq_attention):
+        for n_out in (1, 100):
+            m = module.create(shape[1:], n_out, seed=1)
+            assert module.loader is module.create
+            for t in (False, True):
+                yv = m(x, training=t).cpu().numpy()
+                assert yv.shape == (shape[0], n_out) and not np.isnan(yv).any(), (module.__name__, t)
