@@ -296,9 +296,12 @@ class Trainer:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(self.device)
             if self.sync.active:
-                entry["graphs"] = tuple(self._capture(seg) for seg in segs)
+                # the optimizer segment is two small kernels behind the last collective: launched directly unless
+                # LIDBOX_ADAM_GRAPH is set (a graph launch costs more than it saves there)
+                adam_seg = self._capture(segs[-1]).replay if os.environ.get("LIDBOX_ADAM_GRAPH") else segs[-1]
+                entry["graphs"] = tuple(self._capture(seg).replay for seg in segs[:-1]) + (adam_seg,)
             else:
-                entry["graphs"] = (self._capture(lambda: [seg() for seg in segs]),)
+                entry["graphs"] = (self._capture(lambda: [seg() for seg in segs]).replay,)
         return entry
 
     # ---------------------------------------------------------------- public API
@@ -321,9 +324,9 @@ class Trainer:
                 self._graphs[key] = entry
             ws = entry["ws"]
             if entry["graphs"] is not None and len(entry["graphs"]) == 1:
-                entry["graphs"][0].replay()
+                entry["graphs"][0]()
             else:
-                run = entry["eager"] if entry["graphs"] is None else [g.replay for g in entry["graphs"]]
+                run = entry["eager"] if entry["graphs"] is None else entry["graphs"]      # callables: graph replays
                 nb = self.sync.num_buckets
                 for k in range(self.num_stages):
                     run[k]()
