@@ -252,6 +252,10 @@ int lidbox_signal_chunks(const float* signals, const int64_t* starts, const int6
 /* features/audio.py:57-59: out = 10^(dBFS/20) * x / max|x| per utterance (same ragged layout as signals) */
 int lidbox_peak_normalize(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
                           float dBFS, float* out, lidbox_stream_t stream);
+/* same result; the caller states the longest utterance and whether every start is a multiple of 4 samples (both known on
+ * the host): utterances of up to 65536 samples are then normalised from registers with a single read of the signal */
+int lidbox_peak_normalize_max(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
+                              float dBFS, long max_length, int aligned16, float* out, lidbox_stream_t stream);
 /* features/audio.py:266-270: out_rms[b] = sqrt(mean(x^2)) per utterance */
 int lidbox_signal_rms(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
                       float* out_rms, lidbox_stream_t stream);

@@ -90,6 +90,7 @@ _SIGS = {
     "lidbox_apply_vad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp, _vp]),
     "lidbox_signal_chunks": (_i, [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp, _vp]),
     "lidbox_peak_normalize": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
+    "lidbox_peak_normalize_max": (_i, [_vp, _vp, _vp, _i, _f, _l, _i, _vp, _vp]),
     "lidbox_signal_rms": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "lidbox_snr_mixer": (_i, [_vp, _vp, _vp, _i, _l, _vp, _vp, _vp, _vp]),
     "lidbox_freq_attention_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp, _vp]),

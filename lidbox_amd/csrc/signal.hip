@@ -20,6 +20,7 @@
 // the data (speech frames per utterance) are returned as counters, the host sizes the next buffer from them
 // exactly as the reference's eager tensors do.  No atomics on floats: results are deterministic.
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -272,6 +273,118 @@ __global__ __launch_bounds__(256) void snr_mixer_kernel(const float* __restrict_
     }
 }
 
+// ---- snr_mixer, register-resident: the pair (up to 1024 * 4 * NV samples each) is read ONCE into registers;
+//      both RMS rounds and the three outputs come from there (5 N bytes of memory traffic instead of 9 N).
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    const int tid = threadIdx.x;
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
+
+template <int NV>
+__global__ __launch_bounds__(1024) void snr_mixer_reg_kernel(const float* __restrict__ clean,
+                                                             const float* __restrict__ noise,
+                                                             const float* __restrict__ snr_db, int64_t N,
+                                                             float* __restrict__ clean_norm,
+                                                             float* __restrict__ noise_new, float* __restrict__ noisy) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* c = clean + (int64_t)b * N;
+    const float* z = noise + (int64_t)b * N;
+    float4 cv[NV], zv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int64_t o = ((int64_t)i * 1024 + tid) * 4;
+        const bool in = o < N;                                  // N % 4 == 0 on this path
+        cv[i] = in ? *reinterpret_cast<const float4*>(c + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        zv[i] = in ? *reinterpret_cast<const float4*>(z + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto sumsq = [&](const float4 (&v)[NV], float scale) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float x = scale * v[i].x, y = scale * v[i].y, u = scale * v[i].z, w = scale * v[i].w;
+            s = fmaf(x, x, s); s = fmaf(y, y, s); s = fmaf(u, u, s); s = fmaf(w, w, s);
+        }
+        return s;
+    };
+    const float lvl25 = __powf(10.0f, -25.0f / 20.0f);
+    const float fn = (float)N;
+    const float sc = lvl25 / sqrtf(block_sum_1024(sumsq(cv, 1.f), red) / fn);          // audio.py:134-135
+    const float sz = lvl25 / sqrtf(block_sum_1024(sumsq(zv, 1.f), red) / fn);          // :138-139
+    const float rmsclean = sqrtf(block_sum_1024(sumsq(cv, sc), red) / fn);
+    const float rmsnoise = sqrtf(block_sum_1024(sumsq(zv, sz), red) / fn);
+    const float level = __powf(10.0f, snr_db[b] / 20.0f);                              // :143
+    const float noisescalar = sqrtf(rmsclean / level / rmsnoise);                      // :144
+    float* oc = clean_norm + (int64_t)b * N;
+    float* on = noise_new + (int64_t)b * N;
+    float* om = noisy + (int64_t)b * N;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int64_t o = ((int64_t)i * 1024 + tid) * 4;
+        if (o >= N) continue;
+        float4 a = cv[i], w = zv[i];
+        a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+        w.x = noisescalar * (sz * w.x); w.y = noisescalar * (sz * w.y);
+        w.z = noisescalar * (sz * w.z); w.w = noisescalar * (sz * w.w);
+        *reinterpret_cast<float4*>(oc + o) = a;
+        *reinterpret_cast<float4*>(on + o) = w;
+        *reinterpret_cast<float4*>(om + o) = make_float4(a.x + w.x, a.y + w.y, a.z + w.z, a.w + w.w);
+    }
+}
+
+// ---- peak_normalize, register-resident (utterances of up to 1024 * 4 * NV samples, 16-byte aligned starts): one read
+template <int NV>
+__global__ __launch_bounds__(1024) void peak_normalize_reg_kernel(const float* __restrict__ signals,
+                                                                  const int64_t* __restrict__ starts,
+                                                                  const int64_t* __restrict__ lengths, float level,
+                                                                  float* __restrict__ out) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t s0 = starts[b], n = lengths[b];
+    const float* x = signals + s0;
+    float4 v[NV];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int64_t o = ((int64_t)i * 1024 + tid) * 4;
+        if (o + 3 < n) {
+            v[i] = *reinterpret_cast<const float4*>(x + o);
+        } else {
+            v[i].x = o + 0 < n ? x[o + 0] : 0.f;
+            v[i].y = o + 1 < n ? x[o + 1] : 0.f;
+            v[i].z = o + 2 < n ? x[o + 2] : 0.f;
+            v[i].w = 0.f;
+        }
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    float* o_ = out + s0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int64_t o = ((int64_t)i * 1024 + tid) * 4;
+        const float4 r = make_float4(level * (v[i].x / m), level * (v[i].y / m), level * (v[i].z / m), level * (v[i].w / m));
+        if (o + 3 < n) {
+            *reinterpret_cast<float4*>(o_ + o) = r;
+        } else {
+            if (o + 0 < n) o_[o + 0] = r.x;
+            if (o + 1 < n) o_[o + 1] = r.y;
+            if (o + 2 < n) o_[o + 2] = r.z;
+        }
+    }
+}
+
 // ---- mean of consecutive row groups: out[s, :] = mean(x[seg[s] .. seg[s+1], :])  (util.py:41-57) ----
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x,
                                                            const int64_t* __restrict__ seg, int D,
@@ -383,6 +496,27 @@ extern "C" int lidbox_signal_chunks(const float* signals, const int64_t* starts,
     return LIDBOX_OK;
 }
 
+extern "C" int lidbox_peak_normalize_max(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
+                                         float dBFS, long max_length, int aligned16, float* out,
+                                         lidbox_stream_t stream) {
+    LBX_ARG(signals && starts && lengths && out && B >= 0 && max_length >= 0, "pointers != NULL, B, max_length >= 0");
+    if (B == 0) return LIDBOX_OK;
+    // every utterance fits the registers of one 1024-thread workgroup and starts on a 16-byte boundary: one read
+    if (aligned16 && max_length <= 1024L * 4 * 16 && ((((uintptr_t)signals) | ((uintptr_t)out)) & 15) == 0) {
+        hipStream_t st = (hipStream_t)stream;
+        const float level = powf(10.0f, dBFS / 20.0f);
+        if (max_length <= 1024L * 4 * 4)
+            hipLaunchKernelGGL(peak_normalize_reg_kernel<4>, dim3(B), dim3(1024), 0, st, signals, starts, lengths, level, out);
+        else if (max_length <= 1024L * 4 * 8)
+            hipLaunchKernelGGL(peak_normalize_reg_kernel<8>, dim3(B), dim3(1024), 0, st, signals, starts, lengths, level, out);
+        else
+            hipLaunchKernelGGL(peak_normalize_reg_kernel<16>, dim3(B), dim3(1024), 0, st, signals, starts, lengths, level, out);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    }
+    return lidbox_peak_normalize(signals, starts, lengths, B, dBFS, out, stream);
+}
+
 extern "C" int lidbox_peak_normalize(const float* signals, const int64_t* starts, const int64_t* lengths, int B,
                                      float dBFS, float* out, lidbox_stream_t stream) {
     LBX_ARG(signals && starts && lengths && out && B >= 0, "pointers != NULL, B >= 0");
@@ -407,6 +541,22 @@ extern "C" int lidbox_snr_mixer(const float* clean, const float* noise, const fl
     LBX_ARG(clean && noise && snr_db && clean_norm && noise_new && noisy, "pointers != NULL");
     LBX_ARG(B >= 0 && N >= 1, "B >= 0, N >= 1");
     if (B == 0) return LIDBOX_OK;
+    const bool vec = N % 4 == 0 && ((((uintptr_t)clean) | ((uintptr_t)noise) | ((uintptr_t)clean_norm) |
+                                     ((uintptr_t)noise_new) | ((uintptr_t)noisy)) & 15) == 0;
+    static const bool no_reg = getenv("LIDBOX_SNR_NO_REG") != nullptr;            // A/B aid
+    if (vec && !no_reg && N <= 1024L * 4 * 8) {
+        // whole pair in registers: 4 or 8 float4 per thread and signal (16 would spill at the 128-VGPR limit of a
+        // 1024-thread workgroup); longer pairs take the three-pass kernel
+        hipStream_t st = (hipStream_t)stream;
+        if (N <= 1024L * 4 * 4)
+            hipLaunchKernelGGL(snr_mixer_reg_kernel<4>, dim3(B), dim3(1024), 0, st, clean, noise, snr_db, (int64_t)N,
+                               clean_norm, noise_new, noisy);
+        else
+            hipLaunchKernelGGL(snr_mixer_reg_kernel<8>, dim3(B), dim3(1024), 0, st, clean, noise, snr_db, (int64_t)N,
+                               clean_norm, noise_new, noisy);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    }
     hipLaunchKernelGGL(snr_mixer_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, clean, noise, snr_db, (int64_t)N,
                        clean_norm, noise_new, noisy);
     LBX_LAUNCH_OK();

@@ -170,11 +170,13 @@ def signal_chunks(r, sample_rate, length_ms, step_ms, max_pad_ms=0):
 
 
 def peak_normalize(r, dBFS=0.0):
-    """audio.py:57-59 per utterance -> RaggedSignals with the same layout"""
-    out = torch.zeros_like(r.flat)
+    """audio.py:57-59 per utterance -> RaggedSignals with the same layout (alignment gaps are left unspecified)"""
+    out = torch.empty_like(r.flat)
     with torch.cuda.device(r.flat.device):
-        nv.check(nv.lib.lidbox_peak_normalize(nv.ptr(r.flat), nv.ptr(r.starts), nv.ptr(r.lengths), r.B, float(dBFS),
-                                              nv.ptr(out), nv.current_stream()))
+        max_len = int(r.lengths_host.max()) if r.B else 0
+        aligned = int(r.B == 0 or bool((r.starts_host % ALIGN == 0).all()))
+        nv.check(nv.lib.lidbox_peak_normalize_max(nv.ptr(r.flat), nv.ptr(r.starts), nv.ptr(r.lengths), r.B, float(dBFS),
+                                                  max_len, aligned, nv.ptr(out), nv.current_stream()))
     return RaggedSignals(out, r.starts_host, r.lengths_host)
 
 

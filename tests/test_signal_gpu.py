@@ -132,7 +132,7 @@ def test_signal_chunks_match_oracle(length_ms, step_ms, pad_ms):
     assert c0 == chunks.shape[0]
 
 
-@pytest.mark.parametrize("N", [32000, 4001])
+@pytest.mark.parametrize("N", [32000, 4001, 16000, 40000, 4])      # register-resident (<= 32768, N % 4 == 0) and three-pass paths
 def test_snr_mixer_matches_oracle(N):
     from lidbox_amd.features import audio, signal_ops as sg
     rng = np.random.default_rng(N)
