@@ -70,31 +70,58 @@ __device__ __forceinline__ int reflect_idx(int i, int T) {
     return i;
 }
 
-// thread per (b, t, c), c fastest.  Window t covers padded rows t..t+w-1, padded row i <-> x row
-// reflect(i - w/2).
-__global__ void window_norm_kernel(const float* __restrict__ x, int B, int T, int C, int w,
-                                   int normalize_variance, float* __restrict__ out) {
+// Sliding window statistics.  Window t covers padded rows t..t+w-1, padded row i <-> x row reflect(i - w/2).
+// One thread per (utterance, channel) walks the time axis with running sums of (x - x0) and (x - x0)^2 in FLOAT64
+// (one value enters and one leaves per step), so the kernel is O(T) per channel instead of the reference's O(T*w)
+// materialised windows (features/__init__.py:61-66).  The variance comes from the one-pass identity, which in
+// float64 on float32 data shifted by the channel's first sample agrees with tf.math.reduce_std's two-pass result
+// to float32 rounding (the tests compare with the float64 two-pass oracle at 1e-3 like every other row).
+// Consecutive threads are consecutive channels: every access is a coalesced row segment.
+__global__ __launch_bounds__(256) void window_norm_kernel(const float* __restrict__ x, int B, int T, int C, int w,
+                                                          int normalize_variance, float* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)B * T * C;
-    if (i >= total) return;
+    if (i >= (long)B * C) return;
     const int c = (int)(i % C);
-    const long bt = i / C;
-    const int t = (int)(bt % T);
-    const long b = bt / T;
+    const long b = i / C;
     const float* xb = x + b * (long)T * C + c;
+    float* ob = out + b * (long)T * C + c;
     const int left = w / 2;
-    float s = 0.f;
-    for (int j = 0; j < w; ++j) s += xb[(long)reflect_idx(t + j - left, T) * C];
-    const float mean = s / (float)w;
-    const float d = xb[(long)t * C] - mean;
-    if (!normalize_variance) { out[i] = d; return; }
-    float v = 0.f;
+    const float x0 = xb[0];
+    double s = 0.0, q = 0.0;
     for (int j = 0; j < w; ++j) {
-        const float e = xb[(long)reflect_idx(t + j - left, T) * C] - mean;
-        v = fmaf(e, e, v);
+        const double v = (double)(xb[(long)reflect_idx(j - left, T) * C] - x0);
+        s += v;
+        q += v * v;
     }
-    const float sd = sqrtf(v / (float)w);
-    out[i] = sd != 0.f ? d / sd : 0.f;
+    const double inv_w = 1.0 / (double)w;
+    // 8 time steps per iteration: their 24 loads do not depend on the running sums and are issued first
+    for (int t0 = 0; t0 < T; t0 += 8) {
+        float xc[8], xa[8], xe[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = min(t0 + u, T - 1);
+            xc[u] = xb[(long)t * C];
+            xa[u] = xb[(long)reflect_idx(t - left, T) * C];
+            xe[u] = xb[(long)reflect_idx(min(t + w - left, 2 * (T - 1)), T) * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u;
+            if (t >= T) break;
+            const double mean = s * inv_w;
+            const float d = (float)((double)(xc[u] - x0) - mean);
+            if (!normalize_variance) {
+                ob[(long)t * C] = d;
+            } else {
+                const double var = q * inv_w - mean * mean;
+                const float sd = var > 0.0 ? (float)sqrt(var) : 0.f;
+                ob[(long)t * C] = sd != 0.f ? d / sd : 0.f;                   // divide_no_nan
+            }
+            const double a = (double)(xa[u] - x0), e = (double)(xe[u] - x0);
+            s += e - a;                                                        // window of step t + 1
+            q += e * e - a * a;
+        }
+    }
 }
 
 constexpr int MM_MAX_WG = 1024;
@@ -188,7 +215,7 @@ extern "C" int lidbox_window_norm_fwd(const float* x, int B, int T, int C, int w
     LBX_ARG(window_len >= 2 && window_len < T, "2 <= window_len < T (the sliding branch; use cmvn otherwise)");
     const long total = (long)B * T * C;
     if (total == 0) return LIDBOX_OK;
-    hipLaunchKernelGGL(window_norm_kernel, dim3((unsigned)lbx_cdiv(total, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(window_norm_kernel, dim3((unsigned)lbx_cdiv((long)B * C, 256)), dim3(256), 0,
                        (hipStream_t)stream, x, B, T, C, window_len, normalize_variance, out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
