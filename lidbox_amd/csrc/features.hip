@@ -326,6 +326,7 @@ struct FusedArgs {
     float power_half;           // power / 2 (only used when power != 2)
     int M, ncoef, nnz;
     int seg_len, seg_steps;     // segmented mel (SEGMEL kernels)
+    int dct_runs, dct_len;      // MFCC under SEGMEL: runs per coefficient (ncoef * dct_runs <= 64), bands per run
     const int* seg_meta;
     const float* seg_w;
     const float* win512;
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
     float* s_dct = reinterpret_cast<float*>(smem + 6144) + mel_floats;
     const int table_floats = 1536 + mel_floats + (KIND == LIDBOX_FEAT_MFCC ? a.M * a.ncoef : 0);
     const int table_bytes = (table_floats * 4 + 15) & ~15;
-    const int stage_floats = (KIND == LIDBOX_FEAT_SPECTROGRAM) ? 0 : 8 * a.M + (KIND == LIDBOX_FEAT_MFCC ? 8 * a.ncoef : 0);
+    // MFCC under SEGMEL keeps its 8 x ncoef result tile in the (by then dead) power buffer: 3 workgroups per CU still fit
+    const int stage_floats = (KIND == LIDBOX_FEAT_SPECTROGRAM) ? 0 : 8 * a.M + ((KIND == LIDBOX_FEAT_MFCC && !SEGMEL) ? 8 * a.ncoef : 0);
     const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
 
     const int tid = threadIdx.x;
@@ -693,9 +695,17 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                     }
                 }
                 if (sband >= 0 && sidx == 0) {
+                    if (KIND == LIDBOX_FEAT_MFCC) {
+                        // the DCT below wants [band][8 frames] (two 16-byte rows per band)
+                        *reinterpret_cast<float4*>(s_stage + sband * 8) = make_float4(
+                            __logf(acc[0] + LOG_EPS), __logf(acc[1] + LOG_EPS), __logf(acc[2] + LOG_EPS), __logf(acc[3] + LOG_EPS));
+                        *reinterpret_cast<float4*>(s_stage + sband * 8 + 4) = make_float4(
+                            __logf(acc[4] + LOG_EPS), __logf(acc[5] + LOG_EPS), __logf(acc[6] + LOG_EPS), __logf(acc[7] + LOG_EPS));
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        s_stage[i * a.M + sband] = (KIND != LIDBOX_FEAT_MEL) ? __logf(acc[i] + LOG_EPS) : acc[i];
+                        for (int i = 0; i < 8; ++i)
+                            s_stage[i * a.M + sband] = (KIND != LIDBOX_FEAT_MEL) ? __logf(acc[i] + LOG_EPS) : acc[i];
+                    }
                 }
             } else {
             // ---- 7. banded mel: lane (f, q) owns bands q, q+8, ...
@@ -711,11 +721,54 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
             wave_lds_sync();
             LBX_STAMP(7);
             if (KIND == LIDBOX_FEAT_MFCC) {
-                float* s_coef = s_stage + 8 * a.M;
-                for (int c = q; c < a.ncoef; c += 8) {
-                    float acc = 0.f;
-                    for (int n = 0; n < a.M; ++n) acc = fmaf(s_stage[f * a.M + n], s_dct[n * a.ncoef + c], acc);
-                    s_coef[f * a.ncoef + c] = acc;
+                float* s_coef = SEGMEL ? s_P : s_stage + 8 * a.M;
+                if (SEGMEL) {
+                    // DCT-II rows, same scheme as the mel runs: lane = (coefficient c, run of dct_len bands), all 8
+                    // frames at once from the transposed log-mel tile; a coefficient's dct_runs partial sums sit in
+                    // consecutive lanes and are combined in a fixed order.
+                    const int c = lane / a.dct_runs, run = lane - c * a.dct_runs;
+                    const bool on = c < a.ncoef;
+                    float acc[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+                    for (int j0 = 0; j0 < a.dct_len; j0 += 4) {
+                        float w[4];
+                        float4 p0[4], p1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int n = run * a.dct_len + j0 + u;
+                            const bool in = on && j0 + u < a.dct_len && n < a.M;
+                            const int nn = in ? n : 0;
+                            w[u] = in ? s_dct[nn * a.ncoef + c] : 0.f;
+                            p0[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8);
+                            p1[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8 + 4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[0] = fmaf(p0[u].x, w[u], acc[0]); acc[1] = fmaf(p0[u].y, w[u], acc[1]);
+                            acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
+                            acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
+                            acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
+                        }
+                    }
+                    for (int d = 1; d < a.dct_runs; d <<= 1) {
+                        const bool take = run + d < a.dct_runs;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float t = __shfl_down(acc[i], d, 64);
+                            acc[i] += take ? t : 0.f;
+                        }
+                    }
+                    if (on && run == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) s_coef[i * a.ncoef + c] = acc[i];
+                    }
+                } else {
+                    for (int c = q; c < a.ncoef; c += 8) {
+                        float acc = 0.f;
+                        for (int n = 0; n < a.M; ++n) acc = fmaf(s_stage[f * a.M + n], s_dct[n * a.ncoef + c], acc);
+                        s_coef[f * a.ncoef + c] = acc;
+                    }
                 }
                 wave_lds_sync();
                 float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.ncoef;
@@ -860,6 +913,10 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.L = p->L; a.S = p->S; a.power_half = 0.5f * p->power;
         a.M = p->M; a.ncoef = p->ncoef; a.nnz = p->nnz;
         a.seg_len = p->seg_len; a.seg_steps = p->seg_steps; a.seg_meta = p->d_seg_meta; a.seg_w = p->d_seg_w;
+        a.dct_runs = p->ncoef > 0 ? (64 / p->ncoef < 1 ? 1 : 64 / p->ncoef) : 1;
+        if (a.dct_runs > p->M) a.dct_runs = p->M;
+        a.dct_len = (p->M + a.dct_runs - 1) / a.dct_runs;
+        a.dct_runs = (p->M + a.dct_len - 1) / a.dct_len;          // drop runs that would be empty
         static const bool no_segmel = getenv("LIDBOX_FEAT_NO_SEGMEL") != nullptr;      // A/B aid
         const bool segmel = LBX_FEAT_SEGMEL && p->seg_ok && !no_segmel && kind != LIDBOX_FEAT_SPECTROGRAM;
         a.win512 = p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
@@ -875,7 +932,7 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                                  (kind == LIDBOX_FEAT_MFCC ? p->M * p->ncoef : 0);
         const int table_bytes = (table_floats * 4 + 15) & ~15;
         const int stage_floats = (kind == LIDBOX_FEAT_SPECTROGRAM) ? 0
-                                 : 8 * p->M + (kind == LIDBOX_FEAT_MFCC ? 8 * p->ncoef : 0);
+                                 : 8 * p->M + ((kind == LIDBOX_FEAT_MFCC && !segmel) ? 8 * p->ncoef : 0);
         const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
         const size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
         // grid: about four dispatch rounds of resident workgroups, equal tile counts per wave.  One tile per wave
