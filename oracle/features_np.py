@@ -102,9 +102,15 @@ def _hertz_to_mel(f, dtype):
 
 def linear_to_mel_weight_matrix(num_mel_bins=20, num_spectrogram_bins=129, sample_rate=8000,
                                 lower_edge_hertz=125.0, upper_edge_hertz=3800.0,
-                                dtype=np.float64):
-    """lidbox/features/mel_ops.py:28-75 -> [num_spectrogram_bins, num_mel_bins]."""
+                                dtype=np.float64, stock_linspace=False):
+    """lidbox/features/mel_ops.py:28-75 -> [num_spectrogram_bins, num_mel_bins].
+    stock_linspace=True swaps the vendored non-endpoint `_linspace` (:11-16) for the endpoint-inclusive
+    tf.linspace of the TensorFlow file the reference says it was copied from (:1-6); everything else is
+    the same code.  Only tests use it, to pin the body of this function against independent
+    implementations of the stock HTK filterbank (tests/test_oracle.py)."""
     M, F = int(num_mel_bins), int(num_spectrogram_bins)
+    _linspace = (lambda a, b, n, dt: np.linspace(dt(a), dt(b), int(n), dtype=dt)) if stock_linspace \
+        else globals()["_linspace"]
     nyquist = dtype(sample_rate) / dtype(2.0)                                   # :39
     linear_frequencies = _linspace(0.0, nyquist, F, dtype)[1:]                  # :40-41
     spec_mel = _hertz_to_mel(linear_frequencies, dtype)[:, None]                # :42-43

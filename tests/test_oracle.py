@@ -109,6 +109,37 @@ def test_mel_matrix_lidbox_quirk():
     assert np.abs(W32 - W).max() < 2e-4
 
 
+def test_mel_matrix_body_matches_independent_htk_filterbank():
+    """Third-party pin of the filterbank formulas (hertz->mel, edges, slopes, max/min, DC row): with the endpoint
+    linspace of the TensorFlow file that mel_ops.py:1-6 says it was copied from, the oracle's matrix must equal the
+    HTK filterbank of an unrelated implementation (transformers.audio_utils.mel_filter_bank, triangles in mel space,
+    no area normalisation).  The reference's own matrix then differs from that one ONLY through its vendored
+    non-endpoint _linspace (mel_ops.py:11-16), which the previous test pins."""
+    au = pytest.importorskip("transformers.audio_utils")
+    for M, F, sr, lo, hi in ((40, 257, 16000, 0.0, 8000.0), (20, 129, 8000, 125.0, 3800.0), (64, 513, 22050, 20.0, 11025.0),
+                             (13, 257, 16000, 300.0, 3400.0)):
+        W = fo.linear_to_mel_weight_matrix(M, F, sr, lo, hi, np.float64, stock_linspace=True)
+        ref = au.mel_filter_bank(F, M, lo, hi, sr, norm=None, mel_scale="htk", triangularize_in_mel_space=True)
+        assert W.shape == ref.shape == (F, M)
+        assert np.abs(W[1:] - ref[1:]).max() < 1e-9            # row 0 (DC) is zeroed by TF's HTK convention (mel_ops.py:37,74)
+        assert np.all(W[0] == 0)
+
+
+def test_power_spectrogram_matches_independent_stft(wav_paths):
+    """|STFT|^2 of the oracle (frame, periodic Hann, right zero-pad to 512, rfft: audio.py:219-230) against the
+    un-centred power spectrogram of transformers.audio_utils (an unrelated framing / window / FFT code path)."""
+    au = pytest.importorskip("transformers.audio_utils")
+    win = au.window_function(400, "hann", periodic=True)
+    assert np.abs(win - fo.hann_window(400, True, np.float64)).max() < 1e-12
+    for path in wav_paths[:3]:
+        s, r = fo.read_wav_pcm16(path)
+        s = s[:r].astype(np.float64)
+        P = fo.spectrograms(s[None], r)[0]
+        ref = au.spectrogram(s, win, 400, 160, fft_length=512, power=2.0, center=False, dtype=np.float64).T
+        assert P.shape == ref.shape
+        assert np.abs(P - ref).max() <= 1e-6 * np.abs(ref).max()        # that library transforms in complex64
+
+
 def test_linear_to_mel_shapes(wav_paths):
     for path in wav_paths:
         s, r = fo.read_wav_pcm16(path)
