@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "gemm_shared.h"
+#include "gemm_tuned.h"
 
 namespace {
 
@@ -490,6 +491,7 @@ __global__ void colsum_stage2(const float* __restrict__ partial, int slices, int
 // ------------------------------------------------------------------------------------------------
 struct RowsChoice {
     int bm, bn, splits, k_per_split;
+    bool no_tail_split = false;
 };
 
 // Cost model in "K-steps of a 128x128 tile at the full fp32 MFMA rate" (~1 us each per CU).
@@ -516,7 +518,15 @@ inline double launch_cost(int c, long wgs, double ksteps) {
     return per_cu * tile_t / conc_eff(conc < 1.0 ? 1.0 : conc);
 }
 
-RowsChoice choose_rows(long M, int N, int K, size_t ws_bytes) {
+// kind: 0 nn, 1 nt.  Measured decompositions (gemm_tuned.h) come first, the cost model covers every other shape.
+RowsChoice choose_rows(int kind, long M, int N, int K, size_t ws_bytes) {
+    if (const TunedGemm* t = tuned_gemm(kind, M, N, K)) {
+        const int kps = (int)(lbx_cdiv(lbx_cdiv(K, t->splits), BK) * BK);
+        const int splits = (int)lbx_cdiv(K, kps);
+        if (!(BK > 16 && t->bm == 128 && t->bn == 128) &&
+            (splits == 1 || (size_t)splits * M * N * sizeof(float) <= ws_bytes))
+            return RowsChoice{t->bm, t->bn, splits, kps, t->no_tail_split != 0};
+    }
     RowsChoice best{128, 128, 1, K};
     double best_cost = 1e30;
     for (int c = (BK > 16 ? 1 : 0); c < 4; ++c) {
@@ -584,11 +594,19 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     const long M = (long)A.batch * A.rows_per_batch;
     if (M == 0 || N == 0) return LIDBOX_OK;
     const size_t wsb = ws ? ws_bytes : 0;
-    RowsChoice ch = choose_rows(M, N, K, wsb);
-    if (const char* f = getenv("LIDBOX_GEMM_TILE")) {             // tuning aid: "128x128" etc.
+    RowsChoice ch = choose_rows(B_KINNER ? 1 : 0, M, N, K, wsb);
+    if (const char* f = getenv("LIDBOX_GEMM_PLAN")) {             // tuning aid (tools/gemm_sweep.py): "bm,bn,splits"
+        int bm = 0, bn = 0, sp = 0;
+        if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
+            !(BK > 16 && bm == 128 && bn == 128)) {
+            const int kps = (int)(lbx_cdiv(lbx_cdiv(K, sp), BK) * BK);
+            const int splits = (int)lbx_cdiv(K, kps);
+            if (splits == 1 || (size_t)splits * M * N * sizeof(float) <= wsb) ch = RowsChoice{bm, bn, splits, kps, false};
+        }
+    } else if (const char* f = getenv("LIDBOX_GEMM_TILE")) {      // tuning aid: "128x128" etc.
         int bm = 0, bn = 0;
         if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
-            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K;
+            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K; ch.no_tail_split = false;
             if (BK > 16 && bm == 128 && bn == 128) ch.bn = 64;
         }
     }
@@ -604,7 +622,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     // decomposition is unsplit and leaves such a tail, launch it over the largest row prefix whose
     // workgroup count is a whole number of rounds, and hand the few remaining rows to a second
     // launch planned on its own (small tiles, split along K) -- if the cost model agrees.
-    static const bool no_tail_split = getenv("LIDBOX_GEMM_NO_TAIL_SPLIT") != nullptr;
+    const bool no_tail_split = ch.no_tail_split || getenv("LIDBOX_GEMM_NO_TAIL_SPLIT") != nullptr;
     if (!no_tail_split && ch.splits == 1) {
         const int tiles_n = (int)lbx_cdiv(N, ch.bn);
         const long tiles_m = lbx_cdiv(M, ch.bm);
@@ -615,7 +633,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
             const long m_main = main_tiles_m * ch.bm;
             const long m_rem = M - m_main;
             if (main_tiles_m >= 1 && m_rem > 0) {
-                const RowsChoice rem = choose_rows(m_rem, N, K, wsb);
+                const RowsChoice rem = choose_rows(B_KINNER ? 1 : 0, m_rem, N, K, wsb);
                 const int c = cand_index(ch.bm, ch.bn), cr = cand_index(rem.bm, rem.bn);
                 const double ksteps = (double)lbx_cdiv(K, BK);
                 const double whole = launch_cost(c, wgs, ksteps);
@@ -640,6 +658,21 @@ struct TnPlan {
 };
 
 TnPlan tn_plan(long M, int K1, int N) {
+    if (const char* f = getenv("LIDBOX_GEMM_TN_PLAN")) {          // tuning aid (tools/gemm_sweep.py): "bm,bn,splits"
+        int bm = 0, bn = 0;
+        long sp = 0;
+        if (sscanf(f, "%d,%d,%ld", &bm, &bn, &sp) == 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
+            !(BK > 16 && bm == 128 && bn == 128)) {
+            const long rps = lbx_cdiv(lbx_cdiv(M, sp), BK) * BK;
+            return TnPlan{bm, bn, (int)lbx_cdiv(M, rps), rps};
+        }
+    }
+    if (const TunedGemm* t = tuned_gemm(2, M, N, K1)) {
+        if (!(BK > 16 && t->bm == 128 && t->bn == 128)) {
+            const long rps = lbx_cdiv(lbx_cdiv(M, (long)t->splits), BK) * BK;
+            return TnPlan{t->bm, t->bn, (int)lbx_cdiv(M, rps), rps};
+        }
+    }
     TnPlan best{128, 128, 1, M};
     double best_cost = 1e30;
     for (int c = (BK > 16 ? 1 : 0); c < 4; ++c) {
@@ -680,7 +713,7 @@ extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t wor
         const TnPlan pl = tn_plan(M, K, N);
         out4[0] = pl.bm; out4[1] = pl.bn; out4[2] = pl.splits; out4[3] = (int)pl.rows_per_split;
     } else {
-        const RowsChoice ch = choose_rows(M, N, K, workspace_bytes);
+        const RowsChoice ch = choose_rows(kind, M, N, K, workspace_bytes);
         out4[0] = ch.bm; out4[1] = ch.bn; out4[2] = ch.splits; out4[3] = ch.k_per_split;
     }
     return LIDBOX_OK;
@@ -689,8 +722,12 @@ extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t wor
 extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // room for the deepest split the cost model may pick for a small-M problem (capped at 64 MiB)
-    const RowsChoice ch = choose_rows(M, N, K, (size_t)64 << 20);
-    return ch.splits > 1 ? (size_t)ch.splits * M * N * sizeof(float) : 0;
+    size_t need = 0;
+    for (int kind = 0; kind < 2; ++kind) {
+        const RowsChoice ch = choose_rows(kind, M, N, K, (size_t)64 << 20);
+        if (ch.splits > 1 && (size_t)ch.splits * M * N * sizeof(float) > need) need = (size_t)ch.splits * M * N * sizeof(float);
+    }
+    return need;
 }
 
 extern "C" int lidbox_gemm_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N,

@@ -13,6 +13,7 @@ then Adam scales by 1/world.  The gradient buffer is reduced in contiguous bucke
 issued as an asynchronous collective as soon as its last wgrad has been enqueued and overlaps
 the remaining backward GEMMs.
 """
+import gc
 import os
 
 import torch
@@ -260,9 +261,18 @@ class Trainer:
 
     # ---------------------------------------------------------------- graph plumbing
     def _capture(self, fn):
+        # The cyclic collector must not run while the stream is capturing: freeing a dead Trainer's graphs / streams
+        # from inside a capture is an illegal HIP call in global capture mode and aborts the process (seen when a
+        # test's garbage was collected during the next test's capture).  torch.cuda.graph() collects once on entry.
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool()):
-            fn()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, pool=self._pool()):
+                fn()
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         return g
 
     def _pool(self):

@@ -246,3 +246,31 @@ def test_host_signal_chunk_plan_matches_oracle(nv):
                 assert c == ref[3]
     with pytest.raises(ValueError):
         nv.check(nv.lib.lidbox_signal_chunk_plan(100, 16000, 0, 10, 0, out))      # zero-length chunks
+
+
+def test_gemm_plans_tuned_table_and_model(nv):
+    """lidbox_gemm_plan_query is host logic: shapes listed in csrc/gemm_tuned.h (measured by tools/gemm_sweep.py) return
+    the measured decomposition, every other shape the cost model's; the workspace queries cover whatever is chosen."""
+    import ctypes
+    import re
+    src = open(os.path.join(os.path.dirname(nv.__file__), "csrc", "gemm_tuned.h")).read()
+    entries = [tuple(int(v) for v in m.groups()) for m in
+               re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", src, re.M)]
+    assert len(entries) >= 10
+    out = (ctypes.c_int * 4)()
+    for kind, M, N, K, bm, bn, splits, _ in entries:
+        nv.check(nv.lib.lidbox_gemm_plan_query(kind, M, N, K, 1 << 30, out))
+        assert (out[0], out[1]) == (bm, bn), (kind, M, N, K)
+        if kind == 2:
+            assert out[2] >= 1 and out[2] * out[3] >= M and (out[2] - 1) * out[3] < M       # slices cover the M rows
+            assert nv.lib.lidbox_gemm_tn_workspace(M, K, N) == (out[2] * K * N + out[2] * N) * 4
+        else:
+            assert out[2] == splits == 1 or out[2] * out[3] >= K
+            if out[2] > 1:
+                assert nv.lib.lidbox_gemm_rows_workspace(M, N, K) >= out[2] * M * N * 4
+    # an unlisted shape goes through the model: valid tile, whole K covered
+    for kind, M, N, K in ((0, 1000, 300, 77), (1, 5000, 64, 640), (2, 3000, 96, 200)):
+        assert tuple(e[:4] for e in entries).count((kind, M, N, K)) == 0
+        nv.check(nv.lib.lidbox_gemm_plan_query(kind, M, N, K, 1 << 26, out))
+        assert out[0] in (64, 128) and out[1] in (64, 128) and out[2] >= 1
+        assert out[2] * out[3] >= (M if kind == 2 else K)
