@@ -47,8 +47,9 @@ namespace {
 #endif
 constexpr int BK = LBX_GEMM_BK;           // K depth of one LDS tile (tuning aid: -DLBX_GEMM_BK=32)
 #ifndef LBX_GEMM_WAVES_HINT
-#define LBX_GEMM_WAVES_HINT 0              // 1: occupancy hint per tile shape (128x128 then fits 4 waves/SIMD in one unified
-                                           // register file).  Same-process A/B (tools/ab_gemm.py): 2355 vs 2360 us per step -- no gain
+#define LBX_GEMM_WAVES_HINT 1              // occupancy hint per tile shape: the register allocator then keeps the batched
+                                           // epilogue (gemm_shared.h) inside the K loop's budget -- 64x64: 56 registers
+                                           // (8 waves/SIMD), 128x64: 73 (6), 128x128: 116 (4); without it 72 / 104 / 180
 #endif
 #ifndef LBX_GEMM_MASK_PREFETCH
 #define LBX_GEMM_MASK_PREFETCH 0           // 1: fetch the ReLU mask as bits inside the K loop (A/B: 2375 vs 2355 us -- the mask

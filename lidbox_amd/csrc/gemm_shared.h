@@ -52,6 +52,11 @@ __device__ __forceinline__ float apply_epi(float v, int epi, float bias, const f
     }
 }
 
+template <bool V>
+struct FarTag {
+    static constexpr bool value = V;
+};
+
 // Epilogue of one workgroup tile held as MI x NJ accumulator blocks per wave (waves 2 x 2).
 // Rows of this launch are [m_beg, M).  gridDim.y > 1 = split along K: raw partial sums go to
 // P[split][row - m_beg][n] and rows_reduce_kernel applies the epilogue.
@@ -79,6 +84,42 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
     float* const out_base = partial ? P + ((long)split * (M - m_beg) - m_beg) * N : Cd.base;   // P[split][row - m_beg][n]
     const long out_rs = partial ? (long)N : Cd.rs;
     const bool batched = !partial && Cd.batch != 1;
+    // Loads and stores of a 32x32 block are issued in BATCHES of eight rows: the eight mask values and the eight old
+    // values of a column first, then the arithmetic, then the eight stores.  Written row by row (load mask -> select
+    // -> load old -> add -> store) the compiler cannot move row r+1's loads above row r's store (the pointers may
+    // alias), so every row paid two or three dependent round trips to memory while the workgroup held its slot
+    // without issuing MFMAs (96 round trips per wave of a 128x64 tile; now 8).  Rows / columns outside the matrix
+    // read a safe address (offset 0) and only their store is predicated: no control flow between the loads.  Eight
+    // rows at a time keeps the temporaries inside the registers the K loop no longer needs (occupancy unchanged).
+    if (!has_mask && !accum) {
+        // store-only epilogues (forward: bias / bias + ReLU, partial sums): nothing to batch, rows go out as they come
+#pragma unroll
+        for (int bi = 0; bi < MI; ++bi) {
+            const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
+            unsigned b0 = 0, t0 = (unsigned)rbase;
+            if (batched) { b0 = (unsigned)rbase / (unsigned)Cd.rpb; t0 = (unsigned)rbase - b0 * (unsigned)Cd.rpb; }
+            const long off0 = batched ? (long)b0 * Cd.bs + (long)t0 * Cd.rs : rbase * out_rs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                const long row = rbase + dr;
+                if (row >= M) continue;
+                long off = off0 + dr * out_rs;
+                if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
+#pragma unroll
+                for (int bj = 0; bj < NJ; ++bj) {
+                    if (!colok[bj]) continue;
+                    float x = acc[bi][bj][r] + bias[bj];
+                    if (do_relu) x = fmaxf(x, 0.f);
+                    out_base[off + col[bj]] = x;
+                }
+            }
+        }
+        return;
+    }
+    const bool far = batched && (unsigned)Cd.rpb < 28;          // wave-uniform
+    auto run = [&](auto far_tag) {
+    constexpr bool FAR = decltype(far_tag)::value;
 #pragma unroll
     for (int bi = 0; bi < MI; ++bi) {
         const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
@@ -86,30 +127,55 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         unsigned b0 = 0, t0 = (unsigned)rbase;
         if (batched) { b0 = (unsigned)rbase / (unsigned)Cd.rpb; t0 = (unsigned)rbase - b0 * (unsigned)Cd.rpb; }
         const long off0 = batched ? (long)b0 * Cd.bs + (long)t0 * Cd.rs : rbase * out_rs;
+        // An utterance boundary inside the block: rows behind it restart in the next batch element.  With >= 28 rows
+        // per utterance there is at most one boundary and the offset is a select (no control flow between the loads);
+        // shorter utterances (wave-uniform test) take the general formula.
+        const unsigned t_wrap = batched ? (unsigned)Cd.rpb : 0xffffffffu;
+        const long wrap = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
+        auto row_off = [&](int dr) -> long {
+            long o;
+            if (FAR) o = rbase + dr < M ? row_offset(Cd, (unsigned)(rbase + dr)) : 0;
+            else o = off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
+            return rbase + dr < M ? o : 0;
+        };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = (r & 3) + 8 * (r >> 2);
-            const long row = rbase + dr;
-            if (row >= M) continue;
-            long off = off0 + dr * out_rs;
-            if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
+        for (int bj = 0; bj < NJ; ++bj) {
+            const int c = colok[bj] ? col[bj] : 0;
 #pragma unroll
-            for (int bj = 0; bj < NJ; ++bj) {
-                if (!colok[bj]) continue;
-                float* dst = out_base + off + col[bj];
-                float v = acc[bi][bj][r] + bias[bj];
-                if (has_mask) {
-                    // have_mask_bits: the caller read the mask during its K loop; bit (bi*NJ + bj)*16 + r
-                    const bool keep = have_mask_bits ? ((mask_bits >> ((bi * NJ + bj) * 16 + r)) & 1ull) != 0
-                                                     : aux[off + col[bj]] > 0.f;
-                    v = keep ? v : 0.f;
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float v[8], mv[8], ov[8];
+                if (has_mask && !have_mask_bits) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) mv[i] = aux[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c];
                 }
-                if (accum) v += *dst;
-                if (do_relu) v = fmaxf(v, 0.f);
-                *dst = v;
+                if (accum) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ov[i] = out_base[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = r0 + i;
+                    float x = acc[bi][bj][r] + bias[bj];
+                    if (has_mask) {
+                        // have_mask_bits: the caller read the mask during its K loop; bit (bi*NJ + bj)*16 + r
+                        const bool keep = have_mask_bits ? ((mask_bits >> ((bi * NJ + bj) * 16 + r)) & 1ull) != 0 : mv[i] > 0.f;
+                        x = keep ? x : 0.f;
+                    }
+                    if (accum) x += ov[i];
+                    if (do_relu) x = fmaxf(x, 0.f);
+                    v[i] = x;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int dr = ((r0 + i) & 3) + 8 * ((r0 + i) >> 2);
+                    if (rbase + dr < M && colok[bj]) out_base[row_off(dr) + c] = v[i];
+                }
             }
         }
     }
+    };
+    if (far) run(FarTag<true>{});
+    else run(FarTag<false>{});
 }
 
 // C rows [m_beg, m_beg + Msub) = epi( sum_s P[s][Msub][N] ), fixed order

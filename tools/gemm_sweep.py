@@ -11,7 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lidbox_amd import _native as nv
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(_pos[0]) if _pos else 256
+CNN = "--cnn" in sys.argv          # lidbox.models.cnn (BASELINE configs[3]) instead of the x-vector
 REPS = 10
 
 
@@ -43,6 +45,11 @@ def main():
     keep = []
     layers = [("frame1", 198, 40, 5, 1, 512), ("frame2", 198, 512, 3, 2, 512), ("frame3", 99, 512, 3, 3, 512),
               ("frame4", 33, 512, 1, 1, 512), ("frame5", 33, 512, 1, 1, 1500)]
+    denses = [("segment1", 3000, 512), ("segment2", 512, 512), ("outputs", 512, 4)]
+    if CNN:
+        layers = [("conv_1", 198, 12, 5, 1, 500), ("conv_2", 198, 500, 7, 2, 500), ("conv_3", 99, 500, 1, 1, 500),
+                  ("conv_4", 99, 500, 1, 1, 3000)]
+        denses = [("fc_1", 3000, 1500), ("fc_2", 1500, 600), ("output", 600, 4)]
     for name, T, Cc, k, s, Co in layers:
         To, Tp = (T - 1) // s + 1, T + k - 1
         x = torch.randn(B, Tp, Cc, device="cuda"); W = torch.randn(k * Cc, Co, device="cuda") * 0.05
@@ -56,7 +63,7 @@ def main():
                       lambda wp, wn, A=A, W=W, Co=Co, Y=Y, K=K, bias=bias: nv.lib.lidbox_gemm_nn(A, nv.ptr(W), Co, Y, K, Co, nv.EPI_BIAS_RELU, nv.ptr(bias), wp, wn, st)))
         cases.append((name + " wgrad", 2, M, Co, K, 2.0 * M * K * Co,
                       lambda wp, wn, A=A, DY=DY, dW=dW, Co=Co, K=K, bias=bias: nv.lib.lidbox_gemm_tn(A, DY, nv.ptr(dW), Co, K, Co, 0, nv.ptr(bias), wp, wn, st)))
-        if name != "frame1":
+        if name not in ("frame1", "conv_1"):
             for g in range((k + s - 1) // s):
                 nt = min(s, k - g * s)
                 Cd = rows(dx, Tp * Cc, s * Cc, B, To, off=g * s * Cc)
@@ -65,7 +72,7 @@ def main():
                 epi = nv.EPI_RELU_MASK if g == 0 else nv.EPI_ACCUM_RELU_MASK
                 cases.append(("%s dgrad%d" % (name, g), 1, M, nt * Cc, Co, 2.0 * M * Co * nt * Cc,
                               lambda wp, wn, DY=DY, Wg=Wg, Co=Co, Cd=Cd, n=nt * Cc, epi=epi, mask=mask: nv.lib.lidbox_gemm_nt(DY, Wg, Co, Cd, Co, n, epi, mask, wp, wn, st)))
-    for name, K, N in [("segment1", 3000, 512), ("segment2", 512, 512), ("outputs", 512, 4)]:
+    for name, K, N in denses:
         x = torch.randn(B, K, device="cuda"); W = torch.randn(K, N, device="cuda") * 0.05
         bias = torch.randn(N, device="cuda"); y = torch.zeros(B, N, device="cuda")
         dy = torch.randn(B, N, device="cuda"); dx = torch.zeros(B, K, device="cuda"); dW = torch.zeros(K, N, device="cuda")
