@@ -102,12 +102,18 @@ class KernelTimer:
             self._orig[name] = orig
 
             def wrapper(*args, _n=name, _o=orig):
+                import ctypes
                 key, work = self._classify(_n, args)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = _o(*args)
                 e1.record()
-                self.records.setdefault(key, []).append((e0, e1, work))
+                nk = 1
+                if self.ENTRY[_n] in (0, 1, 2):           # kernels of the named instantiation this call launched
+                    out3 = (ctypes.c_int * 3)()
+                    self.nv.check(self.nv.lib.lidbox_gemm_last_launches(out3))
+                    nk = max(1, out3[0])
+                self.records.setdefault(key, []).append((e0, e1, work, nk))
                 return rc
             setattr(self.nv.lib, name, wrapper)
         return self
@@ -120,10 +126,11 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for key, recs in self.records.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-            work = sum(w for _, _, w in recs)
-            out[key] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs),
-                            work_per_launch=work / len(recs), rate=work / (ms * 1e-3))
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            work = sum(r[2] for r in recs)
+            nk = sum(r[3] for r in recs)                  # kernel launches (a tail split launches the instantiation twice)
+            out[key] = dict(launches=nk, calls=len(recs), total_ms=ms, avg_us=1e3 * ms / nk,
+                            work_per_launch=work / nk, rate=work / (ms * 1e-3))
         return out
 
 
@@ -292,8 +299,10 @@ def main():
                                   "frac": round(ach / peak_mfma, 4), "traffic": pmc_traffic(dom),
                                   "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
                                   "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
-                                  "note": "HIP-event bracket per launch (includes the split-K reduce kernel where one "
-                                          "follows); rocprofv3 --stats lists the same instantiation by this name"}
+                                  "note": "HIP-event brackets around the C-ABI calls that launch this instantiation, divided by "
+                                          "the kernel launches they made (lidbox_gemm_last_launches; a bracket also covers the "
+                                          "split-K reduce kernel where one follows); rocprofv3 --stats lists the same "
+                                          "instantiation by this name"}
             gemm_ms = sum(v["total_ms"] for v in gemms.values()) / nsteps
             gemm_flops = sum(v["rate"] * v["total_ms"] * 1e-3 for v in gemms.values()) / nsteps
             result["kernels"] = {k: {"launches_per_step": v["launches"] // nsteps, "ms_per_step": round(v["total_ms"] / nsteps, 4),

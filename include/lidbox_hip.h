@@ -159,6 +159,12 @@ enum {
  * launch will use).  kind 0 = nn, 1 = nt, 2 = tn (then K = K1).  out4 = {BM, BN, splits, k or rows per split}. */
 int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t workspace_bytes, int* out4);
 
+/* What the calling thread's most recent lidbox_gemm_nn / _nt / _tn call put on the stream (for profiling tools: it lets a
+ * HIP-event bracket around the call be compared with rocprofv3's per-kernel averages).  out3 = {kernels of the
+ * instantiation lidbox_gemm_plan_query names, GEMM kernels of another instantiation (the remainder of a tail split is
+ * planned on its own), reduce kernels}. */
+int lidbox_gemm_last_launches(int* out3);
+
 /* Split-K workspace (bytes) that lets lidbox_gemm_nn / _nt fill the chip when M*N is small
  * (Dense layers at M = batch): partial sums are reduced in a fixed order with the epilogue
  * fused into the reduce.  0 = not needed.  Passing NULL/0 is always legal (no split). */

@@ -495,6 +495,12 @@ struct RowsChoice {
     bool no_tail_split = false;
 };
 
+// what the calling thread's most recent lidbox_gemm_nn / _nt / _tn call launched (lidbox_gemm_last_launches):
+// {kernels of the instantiation plan_query names, GEMM kernels of another instantiation (a tail-split remainder planned
+// on its own), reduce kernels}
+thread_local int g_last_launches[3] = {0, 0, 0};
+thread_local int g_first_tile[2] = {0, 0};
+
 // Cost model in "K-steps of a 128x128 tile at the full fp32 MFMA rate" (~1 us each per CU).
 // A CU's resident workgroups share its four matrix pipes, so a CU's time is the SUM of its
 // tiles' MFMA time; co-resident workgroups hide each other's barrier / staging stalls, a lone
@@ -567,6 +573,9 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
     const int tiles_n = (int)lbx_cdiv(N, ch.bn);
     const long ntiles = lbx_cdiv(Msub, ch.bm) * tiles_n;
     dim3 grid((unsigned)ntiles, (unsigned)ch.splits);
+    if (g_last_launches[0] == 0) { g_first_tile[0] = ch.bm; g_first_tile[1] = ch.bn; }
+    ++g_last_launches[(ch.bm == g_first_tile[0] && ch.bn == g_first_tile[1]) ? 0 : 1];
+    if (ch.splits > 1) ++g_last_launches[2];
 #define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
 #if LBX_GEMM_BK == 16
     if (ch.bm == 128 && ch.bn == 128) LBX_ROWS(128, 128);
@@ -593,6 +602,7 @@ template <bool B_KINNER>
 int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd, int K, int N, int epi,
                 const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
     const long M = (long)A.batch * A.rows_per_batch;
+    g_last_launches[0] = g_last_launches[1] = g_last_launches[2] = 0;
     if (M == 0 || N == 0) return LIDBOX_OK;
     const size_t wsb = ws ? ws_bytes : 0;
     RowsChoice ch = choose_rows(B_KINNER ? 1 : 0, M, N, K, wsb);
@@ -720,6 +730,12 @@ extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t wor
     return LIDBOX_OK;
 }
 
+extern "C" int lidbox_gemm_last_launches(int* out3) {
+    LBX_ARG(out3, "out3 != NULL");
+    out3[0] = g_last_launches[0]; out3[1] = g_last_launches[1]; out3[2] = g_last_launches[2];
+    return LIDBOX_OK;
+}
+
 extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // room for the deepest split the cost model may pick for a small-M problem (capped at 64 MiB)
@@ -763,6 +779,7 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     const TnPlan pl = tn_plan(M, K1, N);
     const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
     LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_tn_workspace)");
+    g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1;
     hipStream_t st = (hipStream_t)stream;
     const int tiles_n = (int)lbx_cdiv(N, pl.bn);
     const int ntiles = (int)(lbx_cdiv(K1, pl.bm) * tiles_n);
