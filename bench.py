@@ -275,6 +275,10 @@ def main():
     }
 
     sys.stdout.flush()
+    # RCCL writes its banner through C stdio, which is fully buffered when stdout is not a terminal: flush the C
+    # streams while descriptor 1 still points at stderr, or the banner would come out at exit, behind the JSON line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     os.dup2(saved_stdout_fd, 1)
     os.close(saved_stdout_fd)
     if rank == 0:
