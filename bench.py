@@ -93,7 +93,8 @@ class KernelTimer:
         if kind == 2:
             key = "gemm_tn_kernel<%d, %d>" % (out[0], out[1])
         else:
-            key = "gemm_rows_kernel<%d, %d, %s>" % (out[0], out[1], "NT" if kind else "NN")
+            waves = self.nv.lib.lidbox_gemm_plan_waves(kind, M, N, K, int(ws_bytes or 0))
+            key = "gemm_rows%s_kernel<%d, %d, %s>" % ("8" if waves == 8 else "", out[0], out[1], "NT" if kind else "NN")
         return key, 2.0 * M * K * N
 
     def __enter__(self):
@@ -147,9 +148,9 @@ def pmc_traffic(kernel_key):
         kern = json.load(open(files[-1]))["kernels"]
     except Exception:
         return None
-    m = re.match(r"gemm_rows_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
+    m = re.match(r"gemm_rows(8?)_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
     if m:
-        name = "gemm_rows_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), "true" if m.group(3) == "NT" else "false")
+        name = "gemm_rows%s_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), m.group(3), "true" if m.group(4) == "NT" else "false")
     elif kernel_key.startswith("gemm_tn_kernel<"):
         name = kernel_key[:-1] + ", true>"
     elif kernel_key == "fused_feat512_kernel":

@@ -159,6 +159,10 @@ enum {
  * launch will use).  kind 0 = nn, 1 = nt, 2 = tn (then K = K1).  out4 = {BM, BN, splits, k or rows per split}. */
 int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t workspace_bytes, int* out4);
 
+/* Waves per workgroup of the kernel lidbox_gemm_plan_query names: 4 = gemm_rows_kernel / gemm_tn_kernel, 8 =
+ * gemm_rows8_kernel (the same tile worked by twice the waves; nn / nt only). */
+int lidbox_gemm_plan_waves(int kind, long M, int N, int K, size_t workspace_bytes);
+
 /* What the calling thread's most recent lidbox_gemm_nn / _nt / _tn call put on the stream (for profiling tools: it lets a
  * HIP-event bracket around the call be compared with rocprofv3's per-kernel averages).  out3 = {kernels of the
  * instantiation lidbox_gemm_plan_query names, GEMM kernels of another instantiation (the remainder of a tail split is

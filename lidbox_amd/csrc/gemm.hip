@@ -66,11 +66,12 @@ constexpr int BK = LBX_GEMM_BK;           // K depth of one LDS tile (tuning aid
 //      Rows outside the matrix are CLAMPED to row 0 (finite data whose products only reach
 //      output rows/columns that are never stored), so interior K-steps carry no predicates at
 //      all; only the tail step (CHECK) tests k and zero-fills.
-template <int ROWS, bool ALIGNED>
+template <int ROWS, bool ALIGNED, int NT = 256>
 struct KInnerLoader {
     static constexpr int F4R = BK / 4;                // float4 per tile row: 4 (BK 16) or 8 (BK 32)
-    static constexpr int RPP = 256 / F4R;             // tile rows per pass: 64 or 32
-    static constexpr int PASSES = ROWS / RPP;
+    static constexpr int RPP = NT / F4R;              // tile rows per pass: 64 or 32 (256 threads), 128 (512)
+    static constexpr int PASSES = ROWS >= RPP ? ROWS / RPP : 1;
+    static constexpr bool PARTIAL = ROWS < RPP;       // more threads than float4s in the tile: the upper ones idle
     static constexpr int LD = ROWS + 8 / F4R;         // = 2 or 1 (mod 32): conflict-free transposed stores
     float4 v[PASSES];
     const float* ptr[PASSES];
@@ -83,7 +84,7 @@ struct KInnerLoader {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const long r = row_base + r0 + p * RPP;
-            ptr[p] = rows.base + (r < nrows ? row_offset(rows, (unsigned)r) : 0) + k;
+            ptr[p] = rows.base + ((r < nrows && !(PARTIAL && r0 >= ROWS)) ? row_offset(rows, (unsigned)r) : 0) + k;
         }
     }
     // loads the tile starting at the current k, then advances by BK
@@ -112,6 +113,7 @@ struct KInnerLoader {
         k += BK;
     }
     __device__ __forceinline__ void store(float* tile) const {
+        if (PARTIAL && r0 >= ROWS) return;               // idle threads loaded row 0 (in bounds) and store nothing
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             float* d = tile + (c4 * 4) * LD + r0 + p * RPP;
@@ -126,11 +128,12 @@ struct KInnerLoader {
 // ---- K-outer operand: BK x COLS tile copied into LDS [BK][COLS]; rows are the contraction index.
 //      Columns outside the matrix are clamped to column 0 on the aligned path (never stored);
 //      the unaligned path keeps per-element column tests (it must not read past a row's end).
-template <int COLS, bool ALIGNED>
+template <int COLS, bool ALIGNED, int NT = 256>
 struct KOuterLoader {
     static constexpr int F4 = COLS / 4;                // float4 per tile row: 32 or 16
-    static constexpr int RPP = 256 / F4;               // tile rows per pass: 8 or 16
-    static constexpr int PASSES = BK / RPP;            // 2 or 1
+    static constexpr int RPP = NT / F4;                // tile rows per pass: 8 or 16 (256 threads)
+    static constexpr int PASSES = BK >= RPP ? BK / RPP : 1;   // 2 or 1
+    static constexpr bool PARTIAL = BK < RPP;          // more threads than float4s in the tile: the upper ones idle
     static constexpr int LD = COLS;
     float4 v[PASSES];
     const float* ptr[PASSES];                          // plain-matrix mode: bumped by BK*ld per step
@@ -140,6 +143,7 @@ struct KOuterLoader {
     __device__ __forceinline__ void init(int tid, int col0, int ncols) {
         c4 = tid % F4;
         kk0 = tid / F4;
+        if (PARTIAL && kk0 >= BK) kk0 -= BK;           // surplus threads mirror an active one: same loads, same LDS stores
         c = col0 + c4 * 4;
         ncols_ = ncols;
         cload = (ALIGNED && c >= ncols) ? 0 : c;       // clamped column used for addressing
@@ -230,22 +234,25 @@ __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int w
 // grid.x = tiles (XCD-chunk remapped), grid.y = K splits.  splits > 1: raw partial sums go to
 // P[split][M][N] and rows_reduce_kernel finishes.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool B_KINNER, bool ALIGNED>
-__global__ LBX_ROWS_BOUNDS(BM, BN) void gemm_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
-                                                        RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K,
-                                                        int N, int epi, const float* __restrict__ aux,
-                                                        int tiles_n, unsigned ntiles, int k_per_split) {
-    constexpr int MI = BM / 64, NJ = BN / 64;
-    using LA = KInnerLoader<BM, ALIGNED>;
-    using LBI = KInnerLoader<BN, ALIGNED>;
-    using LBO = KOuterLoader<BN, ALIGNED>;
+// WAVES = 4: waves 2 x 2.  WAVES = 8 (gemm_rows8_kernel): waves 4 x 2 over the same tile -- half the accumulators per
+// wave, so twice the waves fit a SIMD at the L2 -> LDS traffic of the larger tile.
+template <int BM, int BN, bool B_KINNER, bool ALIGNED, int WAVES>
+__device__ __forceinline__ void gemm_rows_body(const RowsD& A, const float* __restrict__ Bm, long ldb,
+                                               const RowsOutD& Cd, float* __restrict__ P, long m_beg, long M, int K,
+                                               int N, int epi, const float* __restrict__ aux,
+                                               int tiles_n, unsigned ntiles, int k_per_split) {
+    constexpr int WN = 2, WM = WAVES / WN, NT = 64 * WAVES;
+    constexpr int MI = BM / (32 * WM), NJ = BN / (32 * WN);
+    using LA = KInnerLoader<BM, ALIGNED, NT>;
+    using LBI = KInnerLoader<BN, ALIGNED, NT>;
+    using LBO = KOuterLoader<BN, ALIGNED, NT>;
     constexpr int LDA = LA::LD;
     constexpr int LDB = B_KINNER ? LBI::LD : LBO::LD;
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
     const int tn = chunk % tiles_n;
     const long tm = chunk / tiles_n;
@@ -332,6 +339,22 @@ __global__ LBX_ROWS_BOUNDS(BM, BN) void gemm_rows_kernel(RowsD A, const float* _
         for (int idx = 2 * nk; idx < NPRE; ++idx) mbits |= (unsigned long long)(*mask_ptr(idx) > 0.f) << idx;
 
     store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, mbits, pre_mask);
+}
+
+template <int BM, int BN, bool B_KINNER, bool ALIGNED>
+__global__ LBX_ROWS_BOUNDS(BM, BN) void gemm_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
+                                                        RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K,
+                                                        int N, int epi, const float* __restrict__ aux,
+                                                        int tiles_n, unsigned ntiles, int k_per_split) {
+    gemm_rows_body<BM, BN, B_KINNER, ALIGNED, 4>(A, Bm, ldb, Cd, P, m_beg, M, K, N, epi, aux, tiles_n, ntiles, k_per_split);
+}
+
+template <int BM, int BN, bool B_KINNER, bool ALIGNED>
+__global__ __launch_bounds__(512, (BM * BN >= 16384 ? 6 : 8)) void gemm_rows8_kernel(RowsD A, const float* __restrict__ Bm, long ldb,
+                                                            RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K,
+                                                            int N, int epi, const float* __restrict__ aux,
+                                                            int tiles_n, unsigned ntiles, int k_per_split) {
+    gemm_rows_body<BM, BN, B_KINNER, ALIGNED, 8>(A, Bm, ldb, Cd, P, m_beg, M, K, N, epi, aux, tiles_n, ntiles, k_per_split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,6 +516,7 @@ __global__ void colsum_stage2(const float* __restrict__ partial, int slices, int
 struct RowsChoice {
     int bm, bn, splits, k_per_split;
     bool no_tail_split = false;
+    int waves = 4;                 // 8: gemm_rows8_kernel (128-row tiles only)
 };
 
 // what the calling thread's most recent lidbox_gemm_nn / _nt / _tn call launched (lidbox_gemm_last_launches):
@@ -532,7 +556,7 @@ RowsChoice choose_rows(int kind, long M, int N, int K, size_t ws_bytes) {
         const int splits = (int)lbx_cdiv(K, kps);
         if (!(BK > 16 && t->bm == 128 && t->bn == 128) &&
             (splits == 1 || (size_t)splits * M * N * sizeof(float) <= ws_bytes))
-            return RowsChoice{t->bm, t->bn, splits, kps, t->no_tail_split != 0};
+            return RowsChoice{t->bm, t->bn, splits, kps, t->no_tail_split != 0, (t->waves == 8 && t->bm == 128 && BK == 16) ? 8 : 4};
     }
     RowsChoice best{128, 128, 1, K};
     double best_cost = 1e30;
@@ -551,6 +575,17 @@ RowsChoice choose_rows(int kind, long M, int N, int K, size_t ws_bytes) {
         }
     }
     return best;
+}
+
+template <int BM, int BN, bool B_KINNER>
+void launch_rows8_t(bool al, dim3 grid, hipStream_t st, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, float* P,
+                    long m_beg, long m_end, int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps) {
+    if (al)
+        hipLaunchKernelGGL((gemm_rows8_kernel<BM, BN, B_KINNER, true>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg,
+                           m_end, K, N, epi, aux, tiles_n, ntiles, kps);
+    else
+        hipLaunchKernelGGL((gemm_rows8_kernel<BM, BN, B_KINNER, false>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg,
+                           m_end, K, N, epi, aux, tiles_n, ntiles, kps);
 }
 
 template <int BM, int BN, bool B_KINNER>
@@ -577,14 +612,18 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
     ++g_last_launches[(ch.bm == g_first_tile[0] && ch.bn == g_first_tile[1]) ? 0 : 1];
     if (ch.splits > 1) ++g_last_launches[2];
 #define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+#define LBX_ROWS8(BM_, BN_) launch_rows8_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
 #if LBX_GEMM_BK == 16
-    if (ch.bm == 128 && ch.bn == 128) LBX_ROWS(128, 128);
+    if (ch.waves == 8 && ch.bm == 128 && ch.bn == 128) LBX_ROWS8(128, 128);
+    else if (ch.waves == 8 && ch.bm == 128 && ch.bn == 64) LBX_ROWS8(128, 64);
+    else if (ch.bm == 128 && ch.bn == 128) LBX_ROWS(128, 128);
     else
 #endif
     if (ch.bm == 128) LBX_ROWS(128, 64);
     else if (ch.bn == 128) LBX_ROWS(64, 128);
     else LBX_ROWS(64, 64);
 #undef LBX_ROWS
+#undef LBX_ROWS8
     LBX_LAUNCH_OK();
     if (ch.splits > 1) {
         long g = lbx_cdiv(Msub * N, 256);
@@ -607,12 +646,13 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     const size_t wsb = ws ? ws_bytes : 0;
     RowsChoice ch = choose_rows(B_KINNER ? 1 : 0, M, N, K, wsb);
     if (const char* f = getenv("LIDBOX_GEMM_PLAN")) {             // tuning aid (tools/gemm_sweep.py): "bm,bn,splits"
-        int bm = 0, bn = 0, sp = 0;
-        if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
+        int bm = 0, bn = 0, sp = 0, wv = 4;
+        if (sscanf(f, "%d,%d,%d,%d", &bm, &bn, &sp, &wv) >= 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
             !(BK > 16 && bm == 128 && bn == 128)) {
             const int kps = (int)(lbx_cdiv(lbx_cdiv(K, sp), BK) * BK);
             const int splits = (int)lbx_cdiv(K, kps);
-            if (splits == 1 || (size_t)splits * M * N * sizeof(float) <= wsb) ch = RowsChoice{bm, bn, splits, kps, false};
+            if (splits == 1 || (size_t)splits * M * N * sizeof(float) <= wsb)
+                ch = RowsChoice{bm, bn, splits, kps, false, (wv == 8 && bm == 128 && BK == 16) ? 8 : 4};
         }
     } else if (const char* f = getenv("LIDBOX_GEMM_TILE")) {      // tuning aid: "128x128" etc.
         int bm = 0, bn = 0;
@@ -728,6 +768,11 @@ extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t wor
         out4[0] = ch.bm; out4[1] = ch.bn; out4[2] = ch.splits; out4[3] = ch.k_per_split;
     }
     return LIDBOX_OK;
+}
+
+extern "C" int lidbox_gemm_plan_waves(int kind, long M, int N, int K, size_t workspace_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 1) return 4;
+    return choose_rows(kind, M, N, K, workspace_bytes).waves;
 }
 
 extern "C" int lidbox_gemm_last_launches(int* out3) {

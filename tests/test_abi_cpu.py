@@ -255,12 +255,13 @@ def test_gemm_plans_tuned_table_and_model(nv):
     import re
     src = open(os.path.join(os.path.dirname(nv.__file__), "csrc", "gemm_tuned.h")).read()
     entries = [tuple(int(v) for v in m.groups()) for m in
-               re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", src, re.M)]
+               re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", src, re.M)]
     assert len(entries) >= 10
     out = (ctypes.c_int * 4)()
-    for kind, M, N, K, bm, bn, splits, _ in entries:
+    for kind, M, N, K, bm, bn, splits, _, waves in entries:
         nv.check(nv.lib.lidbox_gemm_plan_query(kind, M, N, K, 1 << 30, out))
         assert (out[0], out[1]) == (bm, bn), (kind, M, N, K)
+        assert waves in (4, 8) and (kind == 2 or nv.lib.lidbox_gemm_plan_waves(kind, M, N, K, 1 << 30) == waves)
         if kind == 2:
             assert out[2] >= 1 and out[2] * out[3] >= M and (out[2] - 1) * out[3] < M       # slices cover the M rows
             assert nv.lib.lidbox_gemm_tn_workspace(M, K, N) == (out[2] * K * N + out[2] * N) * 4

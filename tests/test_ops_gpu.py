@@ -86,6 +86,42 @@ def test_gemm_nt_and_epilogues(M, K, N):
     _close(c.cpu().numpy(), ref * (mask > 0) - 2.0)
 
 
+@pytest.mark.parametrize("plan", ["128,128,1", "128,64,1", "64,128,1", "64,64,1", "128,128,1,8", "128,64,1,8", "64,64,3", "128,64,2,8"])
+@pytest.mark.parametrize("M,K,N", [(1500, 200, 512), (777, 520, 200), (130, 36, 68)])
+def test_every_rows_decomposition_gives_the_same_product(plan, M, K, N, monkeypatch):
+    """every tile shape / split count / 4- and 8-wave kernel the planner (cost model or csrc/gemm_tuned.h) can pick,
+    forced through the tuning override, on shapes with ragged edges: nn with bias + ReLU, nt with accumulate + mask"""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM_PLAN", plan)
+    rng = np.random.default_rng(M + N)
+    A, Bm, Bt = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((N, K))
+    bias, mask = rng.standard_normal(N), rng.standard_normal((M, N))
+    a, b, bt, bi, mk = _dev(A), _dev(Bm), _dev(Bt), _dev(bias), _dev(mask)
+    st = nv.current_stream()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    c = torch.zeros((M, N), device="cuda")
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), ws.numel(), st))
+    _close(c.cpu().numpy(), np.maximum(A @ Bm + bias, 0))
+    c.fill_(-2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_ACCUM_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), ws.numel(), st))
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0) - 2.0)
+    # batched rows with a gap between utterances (the conv layout): 5 utterances of 30 rows in a [5, 33, N] buffer
+    if M >= 150:
+        Bn, R, Rp = 5, 30, 33
+        cb = torch.full((Bn, Rp, N), 7.0, device="cuda")
+        mkb = torch.zeros((Bn, Rp, N), device="cuda")
+        mkb[:, 3:, :] = mk[:Bn * R].reshape(Bn, R, N)
+        cv, mv = cb[:, 3:, :], mkb[:, 3:, :]
+        Cd = nv.Rows(cv.data_ptr(), Rp * N, N, Bn, R)
+        nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, Bn * R), nv.ptr(bt), K, Cd, K, N, nv.EPI_ACCUM_RELU_MASK,
+                                       nv.C.c_void_p(mv.data_ptr()), nv.ptr(ws), ws.numel(), st))
+        got = cb.cpu().numpy()
+        _close(got[:, 3:, :].reshape(Bn * R, N), (A[:Bn * R] @ Bt.T) * (mask[:Bn * R] > 0) + 7.0)
+        assert np.all(got[:, :3, :] == 7.0)                     # the rows between utterances are not touched
+
+
 @pytest.mark.parametrize("M,K1,N", [(4096, 200, 512), (1000, 1536, 512), (256, 3000, 512), (50, 7, 3), (8448, 512, 1500)])
 def test_gemm_tn_and_colsum(M, K1, N):
     from lidbox_amd import _native as nv

@@ -109,6 +109,9 @@ def main():
                         variants.append((p, {"LIDBOX_GEMM_PLAN": p}))
                         if sp == 1:
                             variants.append((p + ",notail", {"LIDBOX_GEMM_PLAN": p, "LIDBOX_GEMM_NO_TAIL_SPLIT": "1"}))
+                        if sp == 1 and bm == 128 and "--waves8" in sys.argv:      # 8-wave variant of the 128-row tiles
+                            variants.append((p + ",8", {"LIDBOX_GEMM_PLAN": p + ",8"}))
+                            variants.append((p + ",8,notail", {"LIDBOX_GEMM_PLAN": p + ",8", "LIDBOX_GEMM_NO_TAIL_SPLIT": "1"}))
         res = []
         for vname, env in variants:
             setenv(**env)
@@ -142,10 +145,12 @@ def main():
                " ".join("%s:%.1f" % (k, v) for k, v in sorted(med.items(), key=lambda kv: kv[1]))), flush=True)
         if best != "model" and med[best] < 0.98 * med["model"] and M > 256:     # small-M dense layers: noise-level differences
             f = best.split(",")
-            table.append("    {%d, %d, %d, %d, %s, %s, %s, %d},   // %s B=%d: %.1f -> %.1f us" %
-                         (kind, M, N, K, f[0], f[1], f[2], int(len(f) > 3), cname, B, med["model"], med[best]))
+            nums = [t for t in f if t.isdigit()]
+            table.append("    {%d, %d, %d, %d, %s, %s, %s, %d, %s},   // %s B=%d: %.1f -> %.1f us" %
+                         (kind, M, N, K, nums[0], nums[1], nums[2], int("notail" in f), nums[3] if len(nums) > 3 else "4",
+                          cname, B, med["model"], med[best]))
     print("TOTAL model %.1f us   best-of-sweep %.1f us" % (tot_def, tot_best))
-    print("// tuned entries {kind, M, N, K, bm, bn, splits, no_tail_split}:")
+    print("// tuned entries {kind, M, N, K, bm, bn, splits, no_tail_split, waves}:")
     print("\n".join(table))
 
 
