@@ -96,9 +96,63 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     }
 }
 
+// Short utterances (T <= TMAX <= 40: the x-vector pools 33 frames): one wave per (utterance, 256 channels), a lane owns 4
+// consecutive channels and keeps all T rows of them in registers -- every load is issued before the first use, the second
+// pass of the two-pass variance reads registers instead of memory, and there is no LDS or barrier.  Rows t >= T re-read row
+// T-1 (no control flow between the loads) and are left out of the sums.  Sums run over t in order (deterministic).
+template <bool STATS, int TMAX>
+__global__ __launch_bounds__(64) void pool_fwd_reg_kernel(const float* __restrict__ x, int T, int C, long bs, long rs,
+                                                          float* __restrict__ out) {
+    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const long b = blockIdx.y;
+    const float* xp = x + b * bs + c;
+    float4 v[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) v[t] = *reinterpret_cast<const float4*>(xp + (long)(t < T ? t : T - 1) * rs);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const float w = t < T ? 1.f : 0.f;
+        s.x = fmaf(w, v[t].x, s.x); s.y = fmaf(w, v[t].y, s.y); s.z = fmaf(w, v[t].z, s.z); s.w = fmaf(w, v[t].w, s.w);
+    }
+    const float invT = 1.f / (float)T;
+    const float4 mean = make_float4(s.x / (float)T, s.y / (float)T, s.z / (float)T, s.w / (float)T);
+    if (!STATS) {
+        *reinterpret_cast<float4*>(out + b * C + c) = mean;
+        return;
+    }
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const float w = t < T ? 1.f : 0.f;
+        const float dx = v[t].x - mean.x, dy = v[t].y - mean.y, dz = v[t].z - mean.z, dw = v[t].w - mean.w;
+        q.x = fmaf(w * dx, dx, q.x); q.y = fmaf(w * dy, dy, q.y); q.z = fmaf(w * dz, dz, q.z); q.w = fmaf(w * dw, dw, q.w);
+    }
+    (void)invT;
+    auto sd = [&](float var) { return sqrtf(fminf(fmaxf(var / (float)T, STDDEV_SQRT_MIN_CLIP), FLT_MAX)); };
+    *reinterpret_cast<float4*>(out + b * 2 * C + c) = mean;
+    *reinterpret_cast<float4*>(out + b * 2 * C + C + c) = make_float4(sd(q.x), sd(q.y), sd(q.z), sd(q.w));
+}
+
+template <bool STATS, int TMAX>
+void launch_pool_fwd_reg(const float* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
+    hipLaunchKernelGGL((pool_fwd_reg_kernel<STATS, TMAX>), dim3((unsigned)lbx_cdiv(C, 256), (unsigned)B), dim3(64), 0, st, x, T, C,
+                       bs, rs, out);
+}
+
 template <bool STATS>
 void launch_pool_fwd(const float* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
     const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && (((uintptr_t)x) & 15) == 0;
+    if (vec && T >= 1 && T <= 40 && (((uintptr_t)out) & 15) == 0) {
+        if (T <= 8) launch_pool_fwd_reg<STATS, 8>(x, B, T, C, bs, rs, out, st);
+        else if (T <= 16) launch_pool_fwd_reg<STATS, 16>(x, B, T, C, bs, rs, out, st);
+        else if (T <= 24) launch_pool_fwd_reg<STATS, 24>(x, B, T, C, bs, rs, out, st);
+        else if (T <= 32) launch_pool_fwd_reg<STATS, 32>(x, B, T, C, bs, rs, out, st);
+        else if (T <= 36) launch_pool_fwd_reg<STATS, 36>(x, B, T, C, bs, rs, out, st);
+        else launch_pool_fwd_reg<STATS, 40>(x, B, T, C, bs, rs, out, st);
+        return;
+    }
     if (vec)
         hipLaunchKernelGGL((pool_fwd_kernel<STATS, 4>), dim3((unsigned)lbx_cdiv(C, 64), (unsigned)B), dim3(256), 0, st, x, T,
                            C, bs, rs, out);
@@ -159,10 +213,69 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// 16-byte variant with the loads batched: a wave handles R consecutive rows of (utterance, 256 channels); the statistics come
+// in as four float4 and all R row loads are issued before the first store (rows >= T re-read row T-1, only their store is
+// predicated), so the wave pays one memory round trip instead of one per row.
+template <bool STATS, int R>
+__global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
+                                                           const float* __restrict__ dout, int T, int C, long bs, long rs,
+                                                           int relu_mask, float* __restrict__ dx) {
+    const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const long b = blockIdx.y;
+    const int t0 = blockIdx.z * R;
+    const float* xp = x + b * bs + c;
+    float4 v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = *reinterpret_cast<const float4*>(xp + (long)(t0 + i < T ? t0 + i : T - 1) * rs);
+    const float invT = 1.f / (float)T;
+    float a[4], k[4], mean[4];
+    if (STATS) {
+        const float4 mn = *reinterpret_cast<const float4*>(pooled + b * 2 * C + c);
+        const float4 sd = *reinterpret_cast<const float4*>(pooled + b * 2 * C + C + c);
+        const float4 dm = *reinterpret_cast<const float4*>(dout + b * 2 * C + c);
+        const float4 ds = *reinterpret_cast<const float4*>(dout + b * 2 * C + C + c);
+        const float sdv[4] = {sd.x, sd.y, sd.z, sd.w}, dsv[4] = {ds.x, ds.y, ds.z, ds.w};
+        const float mnv[4] = {mn.x, mn.y, mn.z, mn.w}, dmv[4] = {dm.x, dm.y, dm.z, dm.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // clip_by_value passes gradient only inside [1e-10, max]; sd == sqrt(1e-10) <=> clipped
+            const float dvar = sdv[j] > 1.0000001e-5f ? dsv[j] / (2.f * sdv[j]) : 0.f;
+            mean[j] = mnv[j];
+            a[j] = dmv[j] * invT;
+            k[j] = dvar * 2.f * invT;
+        }
+    } else {
+        const float4 dm = *reinterpret_cast<const float4*>(dout + b * C + c);
+        const float dmv[4] = {dm.x, dm.y, dm.z, dm.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mean[j] = 0.f; a[j] = dmv[j] * invT; k[j] = 0.f; }
+    }
+    float* dp = dx + b * bs + c;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const float xv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g[j] = STATS ? fmaf(k[j], xv[j] - mean[j], a[j]) : a[j];
+            if (relu_mask && !(xv[j] > 0.f)) g[j] = 0.f;
+        }
+        if (t0 + i < T) *reinterpret_cast<float4*>(dp + (long)(t0 + i) * rs) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
 template <bool STATS>
 void launch_pool_bwd(const float* x, const float* pooled, const float* dout, int B, int T, int C, long bs, long rs,
                      int relu_mask, float* dx, hipStream_t st) {
     const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0;
+    // short utterances only (the x-vector pools 33 frames): at T = 99 (the CNN) the row loop below measured faster
+    if (vec && T >= 1 && T <= 48 && ((((uintptr_t)pooled) | ((uintptr_t)dout)) & 15) == 0) {
+        constexpr int R = 12;
+        dim3 grid((unsigned)lbx_cdiv(C, 256), (unsigned)B, (unsigned)lbx_cdiv(T, R));
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<STATS, R>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx);
+        return;
+    }
     const int V = vec ? 4 : 1;
     unsigned zs = (unsigned)(T < 8 ? T : 8);                 // time splits: more waves for the small-batch case
     dim3 grid((unsigned)lbx_cdiv(C, 64 * V), (unsigned)B, zs);
