@@ -55,10 +55,24 @@ constexpr int BK = LBX_GEMM_BK;           // K depth of one LDS tile (tuning aid
 #define LBX_GEMM_MASK_PREFETCH 0           // 1: fetch the ReLU mask as bits inside the K loop (A/B: 2375 vs 2355 us -- the mask
                                            // costs bandwidth / issue slots, not epilogue latency)
 #endif
+#ifndef LBX_GEMM_WAVES_128
+#define LBX_GEMM_WAVES_128 3               // waves/SIMD asked for 128x128 tiles (4 would need <= 128 registers)
+#endif
+#ifndef LBX_GEMM_TN_HINT
+#define LBX_GEMM_TN_HINT 1                 // 1: hint on the 128x128 wgrad kernel only (-2.5 % on the three launches that use it;
+                                           // 2: on every wgrad tile -- 64x64 and 128x64 measured 8-27 % SLOWER with it)
+#endif
 #if LBX_GEMM_WAVES_HINT
-#define LBX_ROWS_BOUNDS(BM, BN) __launch_bounds__(256, ((BM) * (BN) >= 16384 ? 3 : ((BM) * (BN) >= 8192 ? 6 : 8)))
+#define LBX_ROWS_BOUNDS(BM, BN) __launch_bounds__(256, ((BM) * (BN) >= 16384 ? LBX_GEMM_WAVES_128 : ((BM) * (BN) >= 8192 ? 6 : 8)))
 #else
 #define LBX_ROWS_BOUNDS(BM, BN) __launch_bounds__(256)
+#endif
+#if LBX_GEMM_TN_HINT == 2
+#define LBX_TN_BOUNDS(BM, BN) LBX_ROWS_BOUNDS(BM, BN)
+#elif LBX_GEMM_TN_HINT == 1
+#define LBX_TN_BOUNDS(BM, BN) __launch_bounds__(256, ((BM) * (BN) >= 16384 ? LBX_GEMM_WAVES_128 : 1))
+#else
+#define LBX_TN_BOUNDS(BM, BN) __launch_bounds__(256)
 #endif
 
 // ---- K-inner operand (contraction index contiguous in HBM): ROWS x BK tile, transposed into
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(512, (BM * BN >= 16384 ? 6 : 8)) void gemm_rows8_ke
 // wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = column sums of B[Mslice]
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool ALIGNED>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P,
+__global__ LBX_TN_BOUNDS(BM, BN) void gemm_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P,
                                                       float* __restrict__ Pc, long M, int K1, int N,
                                                       int tiles_n, int ntiles, long rows_per_split) {
     constexpr int MI = BM / 64, NJ = BN / 64;
