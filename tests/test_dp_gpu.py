@@ -131,7 +131,31 @@ def test_rccl_backend_between_graph_segments_world1():
            "--batch", "32", "--no-cpu-baseline", "--no-kernel-timing"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one JSON line (RCCL's banner belongs on stderr): %r" % lines
+    r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["steps"] == 5 and r["value"] > 0
     assert np.isfinite(r["config"]["final_loss"])
+
+
+def test_bench_line_contract_single_process():
+    """`python bench.py` (no launcher): one JSON line with the contract's keys, the roofline of the dominant GEMM
+    instantiation from live HIP events and the feature kernel's HBM roofline"""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_feature", "kernels"):
+        assert key in r, key
+    assert r["unit"] == "utterances/s" and r["dtype"] == "f32" and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["config"]["global_batch"] == 256 and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1 and rf["kernel"] in r["kernels"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches_per_step"] >= 1
+    ff = r["roofline_feature"]
+    assert ff["bound"] == "hbm" and ff["bytes_per_launch"] == 256 * 159680 and 0 < ff["frac"] < 1
+    assert abs(r["value"] - 256 * 1e3 / r["ms_per_step"]) <= 1e-3 * r["value"]
