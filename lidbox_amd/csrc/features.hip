@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
     float* s_segw = reinterpret_cast<float*>(s_segmeta + 192);
     const int mel_floats = mel_table_floats(SEGMEL, a.M, a.nnz, a.seg_len);
     float* s_dct = reinterpret_cast<float*>(smem + 6144) + mel_floats;
-    const int table_floats = 1536 + mel_floats + (KIND == LIDBOX_FEAT_MFCC ? a.M * a.ncoef : 0);
+    // MFCC under SEGMEL with <= 8 bands per run: a lane's DCT weights live in registers, no table in LDS (the table would
+    // push a workgroup past a third of the CU's LDS: 2 instead of 3 workgroups per CU)
+    const bool dct_regs = KIND == LIDBOX_FEAT_MFCC && SEGMEL && a.dct_len <= 8;
+    const int table_floats = 1536 + mel_floats + ((KIND == LIDBOX_FEAT_MFCC && !dct_regs) ? a.M * a.ncoef : 0);
     const int table_bytes = (table_floats * 4 + 15) & ~15;
     // MFCC under SEGMEL keeps its 8 x ncoef result tile in the (by then dead) power buffer: 3 workgroups per CU still fit
     const int stage_floats = (KIND == LIDBOX_FEAT_SPECTROGRAM) ? 0 : 8 * a.M + ((KIND == LIDBOX_FEAT_MFCC && !SEGMEL) ? 8 * a.ncoef : 0);
@@ -451,13 +454,25 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
             for (int i = tid; i < a.nnz; i += 256) s_mw[i] = a.mel_w[i];
         }
         if (KIND == LIDBOX_FEAT_MFCC)
-            for (int i = tid; i < a.M * a.ncoef; i += 256) s_dct[i] = a.dct[i];
+            if (!dct_regs)
+                for (int i = tid; i < a.M * a.ncoef; i += 256) s_dct[i] = a.dct[i];
     }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane & 7;          // lane within the frame
     const int f = lane >> 3;         // frame slot within the wave
+    float wd[8];                     // DCT weights of this lane's (coefficient, run) -- see step 8
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wd[u] = 0.f;
+    if (dct_regs) {
+        const int c = lane / a.dct_runs, run = lane - c * a.dct_runs;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = run * a.dct_len + u;
+            if (c < a.ncoef && u < a.dct_len && n < a.M) wd[u] = a.dct[n * a.ncoef + c];
+        }
+    }
     char* wbuf = smem + table_bytes + wave * wave_bytes;
     float* s_P = reinterpret_cast<float*>(wbuf);                         // [8][P_STRIDE] or (SEGMEL) [PT_ROWS][8]; aliases exchange
     float* s_stage = reinterpret_cast<float*>(wbuf + WAVE_SCRATCH);      // [8][M] (+ [8][ncoef])
@@ -731,7 +746,10 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                     float acc[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-                    for (int j0 = 0; j0 < a.dct_len; j0 += 4) {
+                    const int jend = dct_regs ? 8 : a.dct_len;
+#pragma unroll 2
+                    for (int j0 = 0; j0 < jend; j0 += 4) {
+                        if (dct_regs && j0 >= a.dct_len) break;
                         float w[4];
                         float4 p0[4], p1[4];
 #pragma unroll
@@ -739,7 +757,8 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                             const int n = run * a.dct_len + j0 + u;
                             const bool in = on && j0 + u < a.dct_len && n < a.M;
                             const int nn = in ? n : 0;
-                            w[u] = in ? s_dct[nn * a.ncoef + c] : 0.f;
+                            if (dct_regs) w[u] = j0 == 0 ? wd[u] : wd[4 + u];      // zero where the run has no band
+                            else w[u] = in ? s_dct[nn * a.ncoef + c] : 0.f;
                             p0[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8);
                             p1[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8 + 4);
                         }
@@ -928,8 +947,9 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.tiles_per_utt = (T + 7) / 8;
         a.ntiles = (long)B * a.tiles_per_utt;
         // LDS: tables + 4 wave scratch blocks (must mirror the carve in the kernel)
+        const bool dct_regs = kind == LIDBOX_FEAT_MFCC && segmel && a.dct_len <= 8;      // mirrors the kernel
         const int table_floats = 1536 + mel_table_floats(segmel, p->M, p->nnz, p->seg_len) +
-                                 (kind == LIDBOX_FEAT_MFCC ? p->M * p->ncoef : 0);
+                                 ((kind == LIDBOX_FEAT_MFCC && !dct_regs) ? p->M * p->ncoef : 0);
         const int table_bytes = (table_floats * 4 + 15) & ~15;
         const int stage_floats = (kind == LIDBOX_FEAT_SPECTROGRAM) ? 0
                                  : 8 * p->M + ((kind == LIDBOX_FEAT_MFCC && !segmel) ? 8 * p->ncoef : 0);
