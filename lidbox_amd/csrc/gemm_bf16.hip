@@ -46,6 +46,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef LBX16_TAIL_MIN_ROUNDS
+#define LBX16_TAIL_MIN_ROUNDS 1
+#endif
+#ifndef LBX16_TAIL_MIN_K
+#define LBX16_TAIL_MIN_K 1024              // tail split of the rows launches: measured a loss at K = 512 (bs 256), a gain at K >= 1500
+#endif
 constexpr int BK = 32;        // contraction depth of one LDS tile
 constexpr int BT = 128;       // tile rows (M side) = tile columns (N side)
 constexpr int LDT = 40;       // LDS row stride in bf16: 32 + 8 pad = 80 bytes
@@ -225,9 +231,10 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // ------------------------------------------------------------------------------------------------
 template <bool B_KINNER>
 __global__ __launch_bounds__(256, 2) void gemm16_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
-                                                          float* __restrict__ P, long M, int K, int N, int epi,
+                                                          float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
                                                           const float* __restrict__ aux, int tiles_n, unsigned ntiles,
                                                           int k_per_split) {
+    // this launch covers rows [m_beg, M)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][TILE_ELEMS];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TILE_ELEMS];
 
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_rows_kernel(RowsD A, const floa
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
     const int tn = chunk % tiles_n;
-    const long m0 = (long)(chunk / tiles_n) * BT;
+    const long m0 = m_beg + (long)(chunk / tiles_n) * BT;
     const int n0 = tn * BT;
     const int split = blockIdx.y;
     const int kbeg = split * k_per_split;
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_rows_kernel(RowsD A, const floa
         if (kt < nk) LBX16_STEP(1)
     }
 #undef LBX16_STEP
-    store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, 0, M, N, epi, aux, Cd, P, split);
+    store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -442,20 +449,44 @@ int launch_rows16(const char* fn, lidbox_rows_t A, const float* Bm, long ldb, li
     }
     const Rows16Plan pl = plan_rows16(M, N, K, ws ? ws_bytes : 0);
     const int tiles_n = (int)lbx_cdiv(N, BT);
-    const long ntiles = lbx_cdiv(M, BT) * tiles_n;
     const RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
     float* P = (float*)ws;
-    hipLaunchKernelGGL((gemm16_rows_kernel<B_KINNER>), dim3((unsigned)ntiles, (unsigned)pl.splits), dim3(256), 0, st,
-                       to_dev(A), Bm, ldb, Co, P, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, pl.k_per_split);
-    LBX_LAUNCH_OK();
-    if (pl.splits > 1) {
-        long g = lbx_cdiv(M * N, 256);
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, pl.splits, 0L, M, N,
-                           Co, epi, aux);
+    // rows [m_beg, m_end) with a given split plan (+ its fixed-order reduce)
+    auto launch_range = [&](long m_beg, long m_end, const Rows16Plan& q) -> int {
+        const long msub = m_end - m_beg;
+        const long ntiles = lbx_cdiv(msub, BT) * tiles_n;
+        hipLaunchKernelGGL((gemm16_rows_kernel<B_KINNER>), dim3((unsigned)ntiles, (unsigned)q.splits), dim3(256), 0, st,
+                           to_dev(A), Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, q.k_per_split);
         LBX_LAUNCH_OK();
+        if (q.splits > 1) {
+            long g = lbx_cdiv(msub * N, 256);
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, q.splits, m_beg, msub,
+                               N, Co, epi, aux);
+            LBX_LAUNCH_OK();
+        }
+        return LIDBOX_OK;
+    };
+    // Tail quantisation (as in gemm.hip): two workgroups per CU = 512 slots, and the last partial round of a launch
+    // runs at the pace of a full one.  When the tiles beyond the last whole round are few (<= a quarter round), the
+    // launch covers the row prefix that is a whole number of rounds and the few remaining rows go to a second launch
+    // split along K (each of its workgroups does 1/splits of a tile, so it costs a fraction of a round).
+    static const bool no_tail_split = getenv("LIDBOX_GEMM16_NO_TAIL_SPLIT") != nullptr;      // A/B aid
+    const long slots = 2 * NUM_CU;
+    const long tiles = lbx_cdiv(M, BT) * tiles_n;
+    if (!no_tail_split && pl.splits == 1 && tiles > slots && K >= LBX16_TAIL_MIN_K) {   // short K: the extra launch costs more than the round
+        const long rounds = tiles / slots, rem_tiles = tiles - rounds * slots;
+        const long main_tiles_m = rounds * slots / tiles_n;
+        const long m_main = main_tiles_m * BT, m_rem = M - m_main;
+        if (rounds >= LBX16_TAIL_MIN_ROUNDS && rem_tiles > 0 && rem_tiles <= slots / 4 && main_tiles_m >= 1 && m_rem > 0) {
+            const Rows16Plan rp = plan_rows16(m_rem, N, K, ws ? ws_bytes : 0);
+            if (rp.splits > 1) {
+                if (int rc = launch_range(0, m_main, pl)) return rc;
+                return launch_range(m_main, M, rp);
+            }
+        }
     }
-    return LIDBOX_OK;
+    return launch_range(0, M, pl);
 }
 
 }  // namespace

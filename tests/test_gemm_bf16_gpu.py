@@ -172,3 +172,32 @@ def test_bf16_gemm_rejects_unaligned_shapes():
     rc = nv.lib.lidbox_gemm_bf16_nn(_rows(a, 0, 7, 1, 8), nv.ptr(b), 8, _rows(c, 0, 8, 1, 8), 7, 8, nv.EPI_NONE, None, None, 0,
                                     nv.current_stream())
     assert rc != 0 and "multiples of 4" in nv.last_error()
+
+
+@pytest.mark.parametrize("M,K,N", [(17024, 1536, 512), (17000, 1024, 512), (8500, 1280, 1024), (17024, 512, 512)])
+def test_bf16_gemm_tail_split_matches_single_launch(M, K, N):
+    """More tiles than one round of workgroup slots with a few left over: the launch is cut into a whole-round prefix and a
+    K-split remainder (gemm_bf16.hip: launch_rows16).  Same results as the product of the rounded operands, for the
+    forward epilogue and for the backward one (mask + accumulate) over rows with a gap between utterances."""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + N)
+    A, B, Bt = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((N, K))
+    bias, mask = rng.standard_normal(N), rng.standard_normal((M, N))
+    a, b, bt, bi, mk = _dev(A), _dev(B), _dev(Bt), _dev(bias), _dev(mask)
+    st = nv.current_stream()
+    ws = _ws(256 << 20)
+    c = torch.zeros((M, N), device="cuda")
+    nv.check(nv.lib.lidbox_gemm_bf16_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU,
+                                        nv.ptr(bi), nv.ptr(ws), ws.numel(), st))
+    _close(c.cpu().numpy(), np.maximum(_bf16(A) @ _bf16(B) + np.float32(bias), 0))
+    # utterances of 100 rows in a [B, 103, N] buffer (3 untouched rows in front of each)
+    Bn, R, Rp = M // 100, 100, 103
+    cb = torch.full((Bn, Rp, N), 7.0, device="cuda")
+    mkb = torch.zeros((Bn, Rp, N), device="cuda")
+    mkb[:, 3:, :] = mk[:Bn * R].reshape(Bn, R, N)
+    Cd = nv.Rows(cb[:, 3:, :].data_ptr(), Rp * N, N, Bn, R)
+    nv.check(nv.lib.lidbox_gemm_bf16_nt(_rows(a, 0, K, 1, Bn * R), nv.ptr(bt), K, Cd, K, N, nv.EPI_ACCUM_RELU_MASK,
+                                        nv.C.c_void_p(mkb[:, 3:, :].data_ptr()), nv.ptr(ws), ws.numel(), st))
+    got = cb.cpu().numpy()
+    _close(got[:, 3:, :].reshape(Bn * R, N), (_bf16(A[:Bn * R]) @ _bf16(Bt).T) * (mask[:Bn * R] > 0) + 7.0)
+    assert np.all(got[:, :3, :] == 7.0)
