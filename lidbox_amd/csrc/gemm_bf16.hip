@@ -425,7 +425,9 @@ struct Tn16Plan {
 
 Tn16Plan plan_tn16(long M, int K1, int N) {
     const long tiles = lbx_cdiv(K1, BT) * lbx_cdiv(N, BT);
-    long s = (2 * NUM_CU) / tiles;                   // whole rounds only: one workgroup too many costs a full round
+    long target = 2 * NUM_CU;
+    if (const char* e = getenv("LIDBOX_GEMM16_TN_SLOTS")) { const long v = atol(e); if (v >= 1) target = v; }   // tuning aid
+    long s = target / tiles;                         // whole rounds only: one workgroup too many costs a full round
     const long max_s = lbx_cdiv(M, 4 * BK);          // at least four K-steps per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
