@@ -13,8 +13,11 @@ N > 1 is weak scaling (256 utterances per GPU, configs[2] at N = 8): one all-red
 backward GEMMs on a side stream, only frame1's 0.4 MB is exposed.
 
 A "step" is one full pass of the hot path over one batch resident in HBM (inputs are uploaded
-before the timed region).  Timed region: barrier + synchronize, K graph-replayed steps,
-synchronize + barrier; max over ranks.  One JSON line is printed by rank 0.
+before the timed region; the timed loop rotates over 4 different resident batches per rank, each with
+its own captured hipGraph, so consecutive steps see different utterances).  Timed region: barrier +
+synchronize, K graph-replayed steps, synchronize + barrier; max over ranks.  One JSON line is printed
+by rank 0.  `python bench.py --gpus N` without a launcher re-executes itself under
+torch.distributed.run (N ranks on 127.0.0.1) and still prints exactly one line.
 
 Extra measurements in the same process (rank 0):
   roofline          fp32-MFMA roofline of the dominant GEMM kernel family: algorithmic flops of
@@ -58,6 +61,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--resident-batches", type=int, default=4,
+                    help="different batches kept in HBM per rank; the timed loop rotates over them")
     ap.add_argument("--compute-dtype", choices=["float32", "bfloat16"], default="float32",
                     help="GEMM arithmetic; float32 is the BASELINE metric's configuration, bfloat16 = config 5's "
                          "bf16-compute / fp32-master variant of the same workload")
@@ -135,18 +140,37 @@ class KernelTimer:
         return out
 
 
+def source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, *.h, include/*.h): what tools/traffic_from_pmc.py stamps into a PMC
+    summary, so that a summary taken from other kernels is never quoted next to this build's timings (the GPU box has
+    no .git, a source hash works everywhere)."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in (os.path.join(ROOT, "lidbox_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of `kernel_key` from the newest committed PMC summary (profiles/*traffic*.json,
     produced by tools/traffic_from_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-    same command).  bench.py cannot run rocprofv3 on itself, so this is read back, not measured live."""
+    same command) -- bench.py cannot run rocprofv3 on itself.  Returns None unless the summary carries the hash of
+    the kernel sources this process runs (a summary of older kernels is stale, not a measurement)."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")))
     if not files:
         return None
     try:
-        kern = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        kern = doc["kernels"]
     except Exception:
+        return None
+    if doc.get("source_hash") != source_hash():
         return None
     m = re.match(r"gemm_rows(8?)_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
     if m:
@@ -154,14 +178,15 @@ def pmc_traffic(kernel_key):
     elif kernel_key.startswith("gemm_tn_kernel<"):
         name = kernel_key[:-1] + ", true>"
     elif kernel_key == "fused_feat512_kernel":
-        name = "fused_feat512_kernel<2, true, true, true>"
+        cands = [k for k in kern if k.startswith("fused_feat512_kernel<2,")]
+        name = cands[0] if cands else None
     else:
-        return None                                            # no PMC pass committed for this kernel
-    v = kern.get(name)
+        name = kernel_key if kernel_key in kern else None      # other families: exact name or nothing
+    v = kern.get(name) if name else None
     return int(v["hbm_bytes_per_launch"]) if v else None
 
 
-def cpu_baseline(seconds, batch=64):
+def cpu_baseline(seconds, batch=PER_GPU_BATCH):
     """oracle/torch_ref.py train step on the host cores, bounded sample.  torch-CPU does not scale past a
     few dozen threads on this workload (256 threads is 10x SLOWER than 16 on the 2 x 64-core host), so the
     thread count is chosen by a short sweep and reported as `cores`."""
@@ -176,7 +201,7 @@ def cpu_baseline(seconds, batch=64):
         torch.set_num_threads(th)
         step.step(sig_t, y_t)                                        # warm-up at this thread count
         n, t0 = 0, time.perf_counter()
-        while n < 3 or (time.perf_counter() - t0 < 1.5 and n < 20):
+        while n < 2 or (time.perf_counter() - t0 < 1.5 and n < 20):
             step.step(sig_t, y_t)
             n += 1
         rate = n * batch / (time.perf_counter() - t0)
@@ -197,8 +222,25 @@ def cpu_baseline(seconds, batch=64):
                        "cores (best of a 8/16/32/64-thread sweep)" % (n, batch, dt, best_threads, ncpu))
 
 
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` without WORLD_SIZE: run the same command as N ranks of one node through
+    torch.distributed.run on 127.0.0.1 (a free port), pass its stdout (rank 0's one JSON line) through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_launcher(args))
     from lidbox_amd import _native as nv
     from lidbox_amd.features import audio
     from lidbox_amd.models import xvector
@@ -213,22 +255,23 @@ def main():
     os.dup2(2, 1)
     rank, world, local_rank = init_distributed()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    # ---- synthetic global batch (SURVEY 8d recipe), this rank's contiguous shard resident in HBM
+    # ---- synthetic global batches (SURVEY 8d recipe, seeds 1234, 1235, ...), this rank's contiguous shard of each
+    #      resident in HBM
     B = args.batch
     global_B = B * world
-    sig, labels = synthetic_batch(global_B, NUM_LANGS, SAMPLE_RATE, DURATION_S, seed=1234)
     lo, hi = shard_bounds(global_B, rank, world)
-    sig_d = torch.from_numpy(sig[lo:hi]).to(dev)
-    lab_d = torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)
-    del sig
+    batches = []
+    for i in range(max(1, args.resident_batches)):
+        sig, labels = synthetic_batch(global_B, NUM_LANGS, SAMPLE_RATE, DURATION_S, seed=1234 + i)
+        batches.append((torch.from_numpy(sig[lo:hi]).to(dev), torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)))
+        del sig
+    sig_d, lab_d = batches[0]
 
     model = xvector.create((198, 40), NUM_LANGS, seed=0, device=dev, compute_dtype=args.compute_dtype)
     bf16 = args.compute_dtype == "bfloat16"
@@ -243,12 +286,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        trainer.train_step(sig_d, lab_d)
+    # one untimed pass over every resident batch captures its graph (so that no capture lands in the timed region
+    # whatever --warmup is), then the W warm-up steps, then exactly K timed steps
+    first_loss = None
+    for xb, yb in batches:
+        l0 = trainer.train_step(xb, yb)
+        if first_loss is None:
+            first_loss = float(l0)
+    for i in range(args.warmup):
+        trainer.train_step(*batches[i % len(batches)])
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.train_step(sig_d, lab_d)
+    for i in range(args.steps):
+        loss = trainer.train_step(*batches[i % len(batches)])
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -272,7 +322,8 @@ def main():
                                   1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""),
                    "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
                    "languages": NUM_LANGS, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world, "grad_buckets": trainer.sync.num_buckets if world > 1 else 1,
-                   "hip_graph": not args.no_graph, "final_loss": round(final_loss, 6)},
+                   "hip_graph": not args.no_graph, "resident_batches": len(batches),
+                   "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6)},
     }
 
     sys.stdout.flush()
