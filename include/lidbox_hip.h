@@ -100,6 +100,10 @@ int lidbox_extract_features_fwd(const lidbox_feat_plan* plan, int kind, const fl
  * divide_no_nan.  normalize_variance=0 -> cmn. */
 int lidbox_cmvn_fwd(const float* x, long outer, long R, long inner, int normalize_variance,
                     float* out, lidbox_stream_t stream);
+/* the same with `outer` slices x_outer_stride / out_outer_stride floats apart (>= R * inner); x == out (in place) is
+ * allowed: the MFCC + CMVN front-end of cnn.py normalises the features where the first Conv1D reads them. */
+int lidbox_cmvn_strided_fwd(const float* x, long outer, long R, long inner, long x_outer_stride,
+                            int normalize_variance, float* out, long out_outer_stride, lidbox_stream_t stream);
 
 /* lidbox/features/__init__.py:35-67  sliding branch of window_normalization on x [B,T,C]
  * (axis=1, T > window_len >= 2): REFLECT pad [w/2, w/2-1+(w&1)], per-window mean/std. */
@@ -343,6 +347,28 @@ int lidbox_cavg_result(const float* tp, const float* fn, const float* fp_pairs, 
 int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, void* state,
                      lidbox_stream_t stream);
+
+/* out[0] = mean of n floats (one workgroup, fixed order).  Keras reduces the per-example losses of a batch this way
+ * (losses.py:38 returns per-example values; keras_utils.py:141-149 compiles the mean). */
+int lidbox_mean(const float* x, long n, float* out, lidbox_stream_t stream);
+
+/* out[b, n] = -acos(z[b, n]) for the first N of D columns: SparseAngularProximity.predict (losses.py:44-47), the
+ * scores the C_avg metric sees. */
+int lidbox_neg_acos(const float* z, long B, int D, int N, float* out, lidbox_stream_t stream);
+
+/* Keras SpatialDropout1D (xvector.py:50-51, cnn.py:29-30) in place on x [B, T, C] (batch stride in floats): whole
+ * channels of an utterance are zeroed with probability `rate`, kept ones scaled by 1/(1-rate).  The mask is a
+ * counter-based hash of (seed, *step_counter, b, c); step_counter is a DEVICE int64 (NULL = 0), e.g. the Adam step,
+ * so a replayed hipGraph draws a fresh mask per step.  mask_out: optional [B, C] copy of the applied factors. */
+int lidbox_spatial_dropout(float* x, int B, int T, int C, long batch_stride, float rate,
+                           unsigned long long seed, const void* step_counter, float* mask_out,
+                           lidbox_stream_t stream);
+
+/* stream-ordered pitched device-to-device copy / zero fill (hipMemcpy2DAsync / hipMemset2DAsync: memcpy / memset
+ * nodes under graph capture): what moves a dense [B, T, C] batch behind the causal pad rows of a layer input. */
+int lidbox_copy_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes,
+                   size_t height, lidbox_stream_t stream);
+int lidbox_zero_2d(void* dst, size_t pitch, size_t width_bytes, size_t height, lidbox_stream_t stream);
 
 /* fill n floats with value (stream-ordered) */
 int lidbox_fill(float* x, long n, float value, lidbox_stream_t stream);

@@ -61,6 +61,7 @@ _SIGS = {
     "lidbox_extract_features_workspace": (_sz, [_vp, _i, _i, _i, _vp, _l]),
     "lidbox_extract_features_fwd": (_i, [_vp, _i, _vp, _i, _i, _l, _vp, _l, _vp, _sz, _vp]),
     "lidbox_cmvn_fwd": (_i, [_vp, _l, _l, _l, _i, _vp, _vp]),
+    "lidbox_cmvn_strided_fwd": (_i, [_vp, _l, _l, _l, _l, _i, _vp, _l, _vp]),
     "lidbox_window_norm_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lidbox_minmax": (_i, [_vp, _l, _vp, _vp, _vp]),
     "lidbox_feature_scaling_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
@@ -106,6 +107,11 @@ _SIGS = {
     "lidbox_cavg_result": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
+    "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),
+    "lidbox_neg_acos": (_i, [_vp, _l, _i, _i, _vp, _vp]),
+    "lidbox_spatial_dropout": (_i, [_vp, _i, _i, _i, _l, _f, C.c_ulonglong, _vp, _vp, _vp]),
+    "lidbox_copy_2d": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),
+    "lidbox_zero_2d": (_i, [_vp, _sz, _sz, _sz, _vp]),
 }
 
 for _name, (_res, _args) in _SIGS.items():

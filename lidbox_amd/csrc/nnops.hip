@@ -317,10 +317,12 @@ __global__ __launch_bounds__(256) void nll_kernel(const float* __restrict__ logp
         float s = 0.f;
         for (int n = 0; n < N; ++n) s += expf(logp[(long)b * N + n] - m);
         const float lse = m + logf(s);
-        part += lse - logp[(long)b * N + y];
+        // a label outside [0, N) (TF: an error on CPU, NaN on GPU): NaN loss, zero gradient row, never indexed with
+        const bool ok = y >= 0 && y < N;
+        part += ok ? lse - logp[(long)b * N + y] : NAN;
         if (dz)
             for (int n = 0; n < N; ++n)
-                dz[(long)b * N + n] = (expf(logp[(long)b * N + n] - lse) - (n == y ? 1.f : 0.f)) * scale;
+                dz[(long)b * N + n] = ok ? (expf(logp[(long)b * N + n] - lse) - (n == y ? 1.f : 0.f)) * scale : 0.f;
     }
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -373,6 +375,12 @@ __global__ __launch_bounds__(256) void ap_loss_kernel(const float* __restrict__ 
     if (row >= B) return;
     const float* zr = z + (long)row * D;
     const int y = labels[row];
+    if (y < 0 || y >= N) {                                 // label outside the N language vectors: NaN loss, zero gradient row
+        if (lane == 0) loss[row] = NAN;
+        if (dz)
+            for (int d = lane; d < D; d += 64) dz[(long)row * D + d] = 0.f;
+        return;
+    }
     const float th_y = acosf(zr[y]);                       // losses.py:31-33 (theta_l)
     float L = 0.f, dsum = 0.f;
     for (int n = lane; n < N; n += 64) {
@@ -527,6 +535,56 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// mean of n floats, one workgroup (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+// out[b, n] = -acos(z[b, n]), n < N of the D columns (the scores SparseAngularProximity.predict hands to the metrics,
+// losses.py:44-47)
+__global__ void neg_acos_kernel(const float* __restrict__ z, long B, int D, int N, float* __restrict__ out) {
+    const long total = B * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / N;
+        const int n = (int)(i - b * N);
+        out[i] = -acosf(z[b * D + n]);
+    }
+}
+
+// counter-based uniform in [0, 1): splitmix64 finaliser over (seed, step, utterance, channel)
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long step, unsigned b, unsigned c) {
+    unsigned long long v = seed + 0x9E3779B97F4A7C15ull * (step + 1) + (((unsigned long long)b << 32) | c);
+    v ^= v >> 30; v *= 0xBF58476D1CE4E5B9ull;
+    v ^= v >> 27; v *= 0x94D049BB133111EBull;
+    v ^= v >> 31;
+    return (float)(v >> 40) * (1.0f / 16777216.0f);
+}
+
+// Keras SpatialDropout1D on x [B, T, C] (row stride C, batch stride bs) in place: a channel of an utterance is zeroed
+// with probability `rate` for all T frames, the kept ones are scaled by 1 / (1 - rate).  The draw is a function of
+// (seed, *step, b, c); `step` is a device counter (the Adam step), so a replayed hipGraph draws a fresh mask every step.
+__global__ __launch_bounds__(256) void spatial_dropout_kernel(float* __restrict__ x, int T, int C, long bs, float rate,
+                                                              unsigned long long seed, const long long* __restrict__ step,
+                                                              float* __restrict__ mask_out) {
+    const int b = blockIdx.y;
+    const unsigned long long stp = step ? (unsigned long long)*step : 0ull;
+    const float keep_scale = 1.f / (1.f - rate);
+    float* xb = x + (long)b * bs;
+    const long total = (long)T * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float m = hash_uniform(seed, stp, (unsigned)b, (unsigned)c) >= rate ? keep_scale : 0.f;
+        xb[i] *= m;
+        if (mask_out && i < C) mask_out[(long)b * C + c] = m;
+    }
+}
+
 __global__ void fill_kernel(float* __restrict__ x, long n, float value) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         x[i] = value;
@@ -671,6 +729,53 @@ extern "C" int lidbox_adam_step(float* param, const float* grad, float* m, float
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        m, v, n, (const AdamState*)state, beta1, beta2, eps, grad_scale);
     LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_mean(const float* x, long n, float* out, lidbox_stream_t stream) {
+    LBX_ARG(x && out && n >= 1, "x, out != NULL; n >= 1");
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_neg_acos(const float* z, long B, int D, int N, float* out, lidbox_stream_t stream) {
+    LBX_ARG(z && out && B >= 0 && N >= 1 && D >= N, "z, out != NULL; 1 <= N <= D");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(neg_acos_kernel, dim3(ew_grid(B * N)), dim3(256), 0, (hipStream_t)stream, z, B, D, N, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_spatial_dropout(float* x, int B, int T, int C, long batch_stride, float rate,
+                                      unsigned long long seed, const void* step_counter, float* mask_out,
+                                      lidbox_stream_t stream) {
+    LBX_ARG(x && B >= 0 && T >= 0 && C >= 1, "x != NULL; C >= 1");
+    LBX_ARG(rate >= 0.f && rate < 1.f, "0 <= rate < 1");
+    LBX_ARG(batch_stride >= (long)T * C, "batch_stride >= T * C");
+    LBX_ARG(B <= 65535, "B <= 65535");
+    if (B == 0 || T == 0 || rate == 0.f) return LIDBOX_OK;
+    long gx = lbx_cdiv((long)T * C, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(spatial_dropout_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       x, T, C, batch_stride, rate, seed, (const long long*)step_counter, mask_out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_copy_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes,
+                              size_t height, lidbox_stream_t stream) {
+    LBX_ARG(dst && src && dst_pitch >= width_bytes && src_pitch >= width_bytes, "dst, src != NULL; pitches >= width");
+    if (width_bytes == 0 || height == 0) return LIDBOX_OK;
+    LBX_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, hipMemcpyDeviceToDevice,
+                             (hipStream_t)stream));
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_zero_2d(void* dst, size_t pitch, size_t width_bytes, size_t height, lidbox_stream_t stream) {
+    LBX_ARG(dst && pitch >= width_bytes, "dst != NULL; pitch >= width");
+    if (width_bytes == 0 || height == 0) return LIDBOX_OK;
+    LBX_HIP(hipMemset2DAsync(dst, pitch, 0, width_bytes, height, (hipStream_t)stream));
     return LIDBOX_OK;
 }
 

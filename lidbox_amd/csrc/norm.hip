@@ -16,17 +16,19 @@ namespace {
 
 // x viewed as [outer, R, inner]; one workgroup per (outer, column tile of cw columns);
 // 256 threads = cw columns x (256/cw) row groups.
-__global__ __launch_bounds__(256) void cmvn_kernel(const float* __restrict__ x, long R, long inner,
+// x and out may be the same buffer (every element is read and written by the same thread, the write comes last);
+// xs / os: floats between consecutive `outer` slices (>= R * inner).
+__global__ __launch_bounds__(256) void cmvn_kernel(const float* x, long R, long inner, long xs, long os,
                                                    int cw, int normalize_variance,
-                                                   float* __restrict__ out) {
+                                                   float* out) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int col = tid % cw, g = tid / cw, ng = 256 / cw;
     const long c = (long)blockIdx.x * cw + col;
     const long o = blockIdx.y;
     const bool active = c < inner;
-    const float* xp = x + o * R * inner + c;
-    float* op = out + o * R * inner + c;
+    const float* xp = x + o * xs + c;
+    float* op = out + o * os + c;
 
     float s = 0.f;
     if (active)
@@ -195,15 +197,22 @@ inline unsigned ew_grid(long n) {
 
 extern "C" int lidbox_cmvn_fwd(const float* x, long outer, long R, long inner, int normalize_variance,
                                float* out, lidbox_stream_t stream) {
+    return lidbox_cmvn_strided_fwd(x, outer, R, inner, R * inner, normalize_variance, out, R * inner, stream);
+}
+
+extern "C" int lidbox_cmvn_strided_fwd(const float* x, long outer, long R, long inner, long x_outer_stride,
+                                       int normalize_variance, float* out, long out_outer_stride,
+                                       lidbox_stream_t stream) {
     LBX_ARG(x && out, "x, out != NULL");
     LBX_ARG(outer >= 0 && R >= 0 && inner >= 0, "non-negative shape");
+    LBX_ARG(x_outer_stride >= R * inner && out_outer_stride >= R * inner, "outer strides >= R * inner");
     if (outer == 0 || R == 0 || inner == 0) return LIDBOX_OK;
     LBX_ARG(outer <= 65535, "outer <= 65535");
     int cw = 64;
     while (cw > 1 && cw / 2 >= inner) cw /= 2;
     dim3 grid((unsigned)lbx_cdiv(inner, cw), (unsigned)outer);
-    hipLaunchKernelGGL(cmvn_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, R, inner, cw,
-                       normalize_variance, out);
+    hipLaunchKernelGGL(cmvn_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, R, inner, x_outer_stride,
+                       out_outer_stride, cw, normalize_variance, out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -181,6 +181,10 @@ class SequentialTDNN:
             raise ValueError("output_activation must be 'log_softmax' or None")
         self.output_activation = output_activation
         self.channel_dropout_rate = float(channel_dropout_rate)
+        if not 0.0 <= self.channel_dropout_rate < 1.0:
+            raise ValueError("channel_dropout_rate must be in [0, 1)")
+        self.dropout_seed = int(np.random.default_rng(seed).integers(1, 2 ** 62))
+        self._dropout_calls = 0
         self.embedding_layer = self.denses[0].name
         # GEMM arithmetic: "float32" (exact fp32 MFMA) or "bfloat16" (operands rounded to bf16 on chip, fp32
         # accumulate; all buffers, the master weights and every non-GEMM kernel stay fp32)
@@ -455,9 +459,11 @@ class SequentialTDNN:
         Tp = dprev.shape[1]
         relu_prev = self.convs[i - 1].relu
         if c.k < c.s:
-            dprev.zero_()                                   # holes inside every stride period
+            nv.check(lib.lidbox_zero_2d(nv.ptr(dprev), 4 * dprev.numel(), 4 * dprev.numel(), 1, st))   # holes inside every stride period
         elif To * c.s < Tp:
-            dprev[:, To * c.s:, :].zero_()                  # tail rows beyond group 0's coverage
+            # tail rows beyond group 0's coverage
+            nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), 4 * Tp * cin,
+                                        4 * (Tp - To * c.s) * cin, B, st))
         ngroups = (c.k + c.s - 1) // c.s
         for g in range(ngroups):
             ntaps = min(c.s, c.k - g * c.s)
@@ -489,7 +495,9 @@ class SequentialTDNN:
         relu_prev = self.convs[i - 1].relu
         To = ws.Ts[i + 1]
         if To < dprev.shape[1]:
-            dprev[:, To:, :].zero_()                        # rows tap 0 does not overwrite
+            Tp = dprev.shape[1]                             # rows tap 0 does not overwrite
+            nv.check(nv.lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * cin), 4 * Tp * cin,
+                                           4 * (Tp - To) * cin, ws.B, st))
         for j in range(c.k):
             mask = ctypes.c_void_p(aprev.data_ptr() + 4 * j * c.d * cin) if relu_prev else None
             if j == 0:
@@ -504,12 +512,21 @@ class SequentialTDNN:
         x = nv.require_gpu_tensor(x, "x", torch.float32)
         if x.dim() != 3 or x.shape[2] != self.input_dim:
             raise ValueError("expected input [B, T, %d], got %s" % (self.input_dim, tuple(x.shape)))
+        if x.stride(2) != 1 or x.stride(1) != x.shape[2]:
+            x = x.contiguous()
+        a0 = ws.act[0]
+        Tp, C = a0.shape[1], a0.shape[2]
+        st = nv.current_stream()
+        in_ptr = ctypes.c_void_p(a0.data_ptr() + 4 * ws.pads[0] * C)
+        nv.check(nv.lib.lidbox_copy_2d(in_ptr, 4 * Tp * C, nv.ptr(x), 4 * (x.stride(0) if ws.B > 1 else ws.T * C),
+                                       4 * ws.T * C, ws.B, st))
         if training and self.channel_dropout_rate > 0:
-            # Keras SpatialDropout1D (xvector.py:50-51): whole channels dropped per utterance
-            keep = 1.0 - self.channel_dropout_rate
-            mask = (torch.rand((x.shape[0], 1, x.shape[2]), device=x.device) < keep).to(x.dtype) / keep
-            x = x * mask
-        ws.input_view().copy_(x)
+            # Keras SpatialDropout1D (xvector.py:50-51): whole channels dropped per utterance; eager calls draw from a
+            # host-side call counter (the captured train step keys its masks on the device-side Adam step instead)
+            self._dropout_calls += 1
+            nv.check(nv.lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, Tp * C, self.channel_dropout_rate,
+                                                   (self.dropout_seed + 0x51ED27 * self._dropout_calls) & (2 ** 64 - 1),
+                                                   None, None, st))
 
     def __call__(self, x, training=False):
         """x [B,T,C] on the HIP device -> log-probs [B, num_outputs] (a fresh tensor)."""

@@ -95,7 +95,9 @@ class GradSync:
 
     @property
     def grad_scale(self):
-        """what the optimizer multiplies the summed gradient by (mean over the global batch)"""
+        """1 / world: what turns the all-reduced SUM of per-rank mean gradients into their mean (equal shards only).
+        `Trainer` does not use it: it scales every rank's loss gradient by 1 / global_batch instead (`_loss_scale`),
+        which is also right for uneven shards, and hands Adam a grad_scale of 1."""
         return 1.0 / self.world
 
 
@@ -175,56 +177,73 @@ class Trainer:
         self._warming = False            # True during the pre-capture warm-up pass: streaming metrics must not count it
         self._graphs = {}
         self._static = {}
+        self._global_batch = None        # sum of the ranks' shard sizes (set at the first step under data parallelism)
 
     # ---------------------------------------------------------------- pieces of a step
     def _forward_loss(self, ws, inputs, labels):
         lib, st = nv.lib, nv.current_stream()
         model = self.model
+        a0 = ws.act[0]
+        Tp, C = a0.shape[1], a0.shape[2]
+        in_ptr = nv.C.c_void_p(a0.data_ptr() + 4 * ws.pads[0] * C)       # behind the causal zero rows of the first Conv1D
         if self.feature is not None:
             plan, kind = self.feature["plan"], self.feature["kind"]
-            a0 = ws.act[0]
-            Tp, C = a0.shape[1], a0.shape[2]
             Bn, N = inputs.shape
             stride = inputs.stride(0) if Bn > 1 else N
+            # features land directly in the first Conv1D's input buffer
+            nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride, in_ptr,
+                                                     Tp * C, None, 0, st))
             if self.feature.get("cmvn"):
-                # MFCC/log-mel -> per-utterance CMVN over time (features/__init__.py:22-32) -> input buffer
-                if not hasattr(ws, "feat_tmp"):
-                    ws.feat_tmp = torch.empty((Bn, ws.T, C), dtype=torch.float32, device=self.device)
-                    ws.feat_norm = torch.empty_like(ws.feat_tmp)
-                nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride,
-                                                         nv.ptr(ws.feat_tmp), 0, None, 0, st))
-                nv.check(lib.lidbox_cmvn_fwd(nv.ptr(ws.feat_tmp), Bn, ws.T, C, 1, nv.ptr(ws.feat_norm), st))
-                ws.input_view().copy_(ws.feat_norm)
-            else:
-                # features land directly behind the causal zero rows of the first Conv1D's input
-                out_ptr = nv.C.c_void_p(a0.data_ptr() + 4 * ws.pads[0] * C)
-                nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride, out_ptr,
-                                                         Tp * C, None, 0, st))
+                # per-utterance CMVN over time (features/__init__.py:22-32), in place where the conv reads it
+                nv.check(lib.lidbox_cmvn_strided_fwd(in_ptr, Bn, ws.T, C, Tp * C, 1, in_ptr, Tp * C, st))
         else:
-            ws.input_view().copy_(inputs)
+            if inputs.stride(2) != 1 or inputs.stride(1) != C:
+                inputs = inputs.contiguous()
+            nv.check(lib.lidbox_copy_2d(in_ptr, 4 * Tp * C, nv.ptr(inputs), 4 * (inputs.stride(0) if ws.B > 1 else ws.T * C),
+                                        4 * ws.T * C, ws.B, st))
+        if model.channel_dropout_rate > 0:
+            # SpatialDropout1D of the training pass (xvector.py:50-51, cnn.py:29-30); the Adam step counter on the device
+            # keys the mask, so every replay of the captured step draws a new one
+            nv.check(lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, Tp * C, model.channel_dropout_rate,
+                                                model.dropout_seed, nv.ptr(self.adam_state), None, st))
         out = model.forward_ws(ws)
         B = ws.B
+        scale = self._loss_scale(B)
         if self.loss_kind == "nll":
-            nv.check(lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, out.shape[1], 1.0 / B,
+            nv.check(lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, out.shape[1], scale,
                                             nv.ptr(ws.loss), nv.ptr(ws.dh[-1]), st))
         else:
             D = out.shape[1]
             zn, dzn, per = self._ap_buffers(ws, D)
             nv.check(lib.lidbox_l2_normalize_fwd(nv.ptr(out), B, D, nv.ptr(zn), st))
             nv.check(lib.lidbox_ap_loss_fwd_bwd(nv.ptr(zn), nv.ptr(labels), B, D, self.ap.N, self.ap.delta_weight,
-                                                1.0 / B, nv.ptr(per), nv.ptr(dzn), st))
+                                                scale, nv.ptr(per), nv.ptr(dzn), st))
             nv.check(lib.lidbox_l2_normalize_bwd(nv.ptr(out), nv.ptr(dzn), B, D, nv.ptr(ws.dh[-1]), st))
-            ws.loss[0:1].copy_(per.mean(dim=0, keepdim=True))
+            nv.check(lib.lidbox_mean(nv.ptr(per), B, nv.ptr(ws.loss), st))
             if self.metric is not None and not self._warming:
-                self.metric._update_sparse(labels, -torch.acos(zn[:, :self.ap.N]))
+                nv.check(lib.lidbox_neg_acos(nv.ptr(zn), B, D, self.ap.N, nv.ptr(ws.ap_scores), st))
+                self.metric._update_sparse(labels, ws.ap_scores)
         if self.loss_kind == "nll" and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)
+
+    def _loss_scale(self, B):
+        """d(mean loss)/d(per-example loss).  Under data parallelism the mean is over the GLOBAL batch (the ranks' shard
+        sizes summed once, at the first step), so that uneven shards (`shard_bounds` gives the remainder to the first
+        ranks) still yield the gradient of the global-batch mean after the all-reduce(sum)."""
+        if not self.sync.active:
+            return 1.0 / B
+        if self._global_batch is None:
+            t = torch.tensor([B], dtype=torch.int64, device=self.device)
+            self.sync.dist.all_reduce(t, group=self.sync.group)
+            self._global_batch = int(t.item())
+        return 1.0 / self._global_batch
 
     def _ap_buffers(self, ws, D):
         if not hasattr(ws, "ap_zn"):
             ws.ap_zn = torch.zeros((ws.B, D), dtype=torch.float32, device=self.device)
             ws.ap_dzn = torch.zeros_like(ws.ap_zn)
             ws.ap_per = torch.zeros(ws.B, dtype=torch.float32, device=self.device)
+            ws.ap_scores = torch.zeros((ws.B, self.ap.N), dtype=torch.float32, device=self.device)
         return ws.ap_zn, ws.ap_dzn, ws.ap_per
 
     def _backward_stage(self, ws, k):
@@ -257,7 +276,7 @@ class Trainer:
         m = self.model
         nv.check(nv.lib.lidbox_adam_step(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v),
                                          m.num_flat, o["lr"], o["beta_1"], o["beta_2"], o["epsilon"],
-                                         self.sync.grad_scale, nv.ptr(self.adam_state), nv.current_stream()))
+                                         1.0, nv.ptr(self.adam_state), nv.current_stream()))
 
     # ---------------------------------------------------------------- graph plumbing
     def _capture(self, fn):

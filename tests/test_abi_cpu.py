@@ -158,6 +158,18 @@ _DP_WORKER = textwrap.dedent("""
     flat.copy_(per_utt[lo:hi].sum(0) / (hi - lo))
     sync.launch(1); sync.launch(0); sync.wait()
     assert float((flat * sync.grad_scale - expect).abs().max()) < 1e-12
+    # uneven shards (11 utterances -> 6 + 5): every rank scales by 1 / GLOBAL batch (what Trainer._loss_scale does),
+    # the all-reduced sum then is the global mean's gradient with no further scaling
+    B2 = 11
+    per2 = torch.randn(B2, n, dtype=torch.float64)
+    lo2, hi2 = shard_bounds(B2, rank, world)
+    assert (hi2 - lo2) == (6 if rank == 0 else 5)
+    cnt = torch.tensor([hi2 - lo2]); dist.all_reduce(cnt)
+    assert int(cnt) == B2
+    flat2 = per2[lo2:hi2].sum(0) / int(cnt)
+    s2 = GradSync(flat2, [0, 250, n])
+    s2.launch(1); s2.launch(0); s2.wait()
+    assert float((flat2 - per2.mean(0)).abs().max()) < 1e-12
     # C_avg-style counters: all-reduce(sum) of integer-valued float counters is exact
     c = torch.full((7,), float(rank + 1))
     dist.all_reduce(c)

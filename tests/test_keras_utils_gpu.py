@@ -70,6 +70,7 @@ def test_from_config_fit_checkpoints_and_extractor(tmp_path):
     ex_cfg = {"cache_directory": str(tmp_path), "model": cfg["experiment"]["model"], "experiment_name": "exp1",
               "input_shape": [50, 24], "output_shape": [4], "best_checkpoint": {"monitor": "val_loss", "mode": "min"}}
     extractor = ku.KerasWrapper.from_config_as_embedding_extractor_fn(ex_cfg)
+    best = ku.KerasWrapper.get_best_checkpoint_path(ckdir, key="val_loss", mode="min")     # the resumed run added a checkpoint
     x = val[0][0].cuda()
     emb = extractor(x)
     ref_model = xvector.create((50, 24), 4, seed=99)

@@ -331,3 +331,62 @@ def test_xvector_extended_matches_oracle_forward_and_backward():
     for name, ref in g.items():
         gotg = m.param(name, grad=True).cpu().numpy()
         assert np.abs(gotg - ref).max() <= 1e-3 * max(1e-12, np.abs(ref).max()), name
+
+
+def test_trainer_applies_spatial_dropout_with_a_fresh_mask_per_graph_replay():
+    """`Trainer` is the only training path, so the model's channel_dropout_rate must act there
+    (xvector.py:50-51), also behind the fused feature kernel and under hipGraph replay."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    sig, y = synthetic_batch(8, num_labels=4, duration_s=0.5)
+    sd, yd = _dev(sig), _dev(y, np.int32)
+    plan = audio.get_plan(16000, 400, 160)
+    for use_graph in (False, True):
+        m = xvector.create((48, 40), 4, channel_dropout_rate=0.5, seed=3)
+        t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=use_graph)
+        ref = Trainer(xvector.create((48, 40), 4, seed=3), feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=False)
+        ref.loss_and_grads(sd, yd)
+        clean = ref.model.workspace(8, 48).input_view().clone()          # log-mel features without dropout
+        seen = []
+        for _ in range(3):
+            t.train_step(sd, yd)
+            x = m.workspace(8, 48).input_view()
+            dropped = (x == 0).all(dim=1)                                # [B, C]: channel zero for every frame
+            kept = ~dropped
+            assert 0.25 < float(dropped.float().mean()) < 0.75
+            # kept channels hold 2 x the clean features (1 / (1 - 0.5)), dropped ones exact zeros
+            scale = torch.where(kept, 2.0, 0.0)[:, None, :]
+            assert float((x - clean * scale).abs().max()) <= 1e-5 * float(clean.abs().max())
+            seen.append(dropped.cpu().numpy())
+        assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[1], seen[2])
+    # feature-tensor inputs take the same path
+    m = xvector.create((48, 40), 4, channel_dropout_rate=0.5, seed=3)
+    t = Trainer(m, use_graph=True)
+    t.train_step(clean.contiguous(), yd)
+    x = m.workspace(8, 48).input_view()
+    assert 0.25 < float((x == 0).all(dim=1).float().mean()) < 0.75
+    # inference never drops
+    assert float((m(clean.contiguous()) - m(clean.contiguous())).abs().max()) == 0.0
+
+
+def test_config0_32_utterances_logmel_xvector_forward():
+    """BASELINE configs[0]: 32 x (16 kHz, 2 s) synthetic wavs -> log-mel -> x-vector forward, against the oracle"""
+    from lidbox_amd.data import tf_utils
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    sig, _ = synthetic_batch(32, num_labels=4, duration_s=2.0)
+    m = xvector.create((198, 40), 4, seed=0)
+    feats = tf_utils.extract_features(_dev(sig), [16000] * 32, "logmelspectrogram")
+    ref_feats = fo.extract_features(sig, [16000] * 32, "logmelspectrogram")
+    got_feats = feats.cpu().numpy()
+    assert got_feats.shape == (32, 198, 40)
+    assert np.abs(got_feats - ref_feats).max() < 2e-4
+    got = m(feats).cpu().numpy()
+    ref = mo.xvector_fwd(_oracle_params(m), ref_feats)
+    assert got.shape == (32, 4)
+    assert np.abs(got - ref).max() < 1e-3
+    emb = xvector.as_embedding_extractor(m)(feats).cpu().numpy()
+    assert _cos(emb, mo.xvector_fwd(_oracle_params(m), ref_feats, embedding=True)).min() >= 0.9999

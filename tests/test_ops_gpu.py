@@ -354,3 +354,99 @@ def test_abi_rejects_bad_arguments():
     assert "lidbox_gemm_nn" in nv.last_error()
     assert nv.lib.lidbox_stats_pool_fwd(None, 1, 1, 1, 1, 1, None, None) == -1
     assert nv.lib.lidbox_ap_loss_fwd_bwd(nv.ptr(x), nv.ptr(x), 1, 2, 3, 1.0, 1.0, nv.ptr(x), None, None) == -1
+
+
+def test_out_of_range_labels_give_nan_loss_and_zero_gradient_rows():
+    """a label outside [0, N) is never used as an index (TF: InvalidArgument on CPU, NaN on GPU)"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(60)
+    B, N, D = 9, 5, 16
+    st = nv.current_stream()
+    y = rng.integers(0, N, size=B).astype(np.int32)
+    y[2], y[7] = N, -1
+    logp = _dev(mo.log_softmax(rng.standard_normal((B, N))))
+    loss = torch.zeros(4, device="cuda")
+    dz = torch.full((B, N), 5.0, device="cuda")
+    nv.check(nv.lib.lidbox_nll_fwd_bwd(nv.ptr(logp), nv.ptr(_dev(y, np.int32)), B, N, 1.0 / B, nv.ptr(loss), nv.ptr(dz), st))
+    assert np.isnan(float(loss[0]))
+    g = dz.cpu().numpy()
+    assert not g[2].any() and not g[7].any() and np.isfinite(g).all() and g[0].any()
+    z = rng.standard_normal((B, D))
+    zn = _dev(z / np.linalg.norm(z, axis=1, keepdims=True))
+    per = torch.zeros(B, device="cuda")
+    dzn = torch.full((B, D), 5.0, device="cuda")
+    nv.check(nv.lib.lidbox_ap_loss_fwd_bwd(nv.ptr(zn), nv.ptr(_dev(y, np.int32)), B, D, N, 16.0, 1.0 / B, nv.ptr(per), nv.ptr(dzn), st))
+    p, g = per.cpu().numpy(), dzn.cpu().numpy()
+    assert np.isnan(p[2]) and np.isnan(p[7]) and np.isfinite(np.delete(p, [2, 7])).all()
+    assert not g[2].any() and not g[7].any() and np.isfinite(g).all()
+
+
+def test_mean_neg_acos_copy_zero_2d():
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(61)
+    st = nv.current_stream()
+    for n in (1, 255, 4096, 10001):
+        x = rng.standard_normal(n)
+        out = torch.zeros(1, device="cuda")
+        nv.check(nv.lib.lidbox_mean(nv.ptr(_dev(x)), n, nv.ptr(out), st))
+        assert abs(float(out) - x.astype(np.float32).astype(np.float64).mean()) < 1e-5
+    z = rng.uniform(-1, 1, size=(37, 20))
+    out = torch.zeros((37, 7), device="cuda")
+    nv.check(nv.lib.lidbox_neg_acos(nv.ptr(_dev(z)), 37, 20, 7, nv.ptr(out), st))
+    assert np.abs(out.cpu().numpy() + np.arccos(z[:, :7].astype(np.float32))).max() < 1e-5
+    # pitched copy into / zero fill of a padded layer input [B, pad + T, C]
+    B, T, C, pad = 5, 11, 6, 3
+    src = _dev(rng.standard_normal((B, T, C)))
+    dst = torch.full((B, pad + T, C), 9.0, device="cuda")
+    nv.check(nv.lib.lidbox_copy_2d(ctypes.c_void_p(dst.data_ptr() + 4 * pad * C), 4 * (pad + T) * C, nv.ptr(src), 4 * T * C,
+                                   4 * T * C, B, st))
+    assert torch.equal(dst[:, pad:], src) and bool((dst[:, :pad] == 9.0).all())
+    nv.check(nv.lib.lidbox_zero_2d(ctypes.c_void_p(dst.data_ptr() + 4 * (pad + T - 2) * C), 4 * (pad + T) * C, 4 * 2 * C, B, st))
+    assert bool((dst[:, -2:] == 0).all()) and torch.equal(dst[:, pad:-2], src[:, :-2])
+
+
+def test_cmvn_strided_in_place_equals_dense():
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(62)
+    st = nv.current_stream()
+    B, T, C, pad = 7, 98, 12, 5
+    x = rng.standard_normal((B, T, C)) * 3 + 1
+    dense_in, dense_out = _dev(x), torch.zeros((B, T, C), device="cuda")
+    for nv_flag in (0, 1):
+        nv.check(nv.lib.lidbox_cmvn_fwd(nv.ptr(dense_in), B, T, C, nv_flag, nv.ptr(dense_out), st))
+        padded = torch.zeros((B, pad + T, C), device="cuda")
+        padded[:, pad:] = dense_in
+        p = ctypes.c_void_p(padded.data_ptr() + 4 * pad * C)
+        nv.check(nv.lib.lidbox_cmvn_strided_fwd(p, B, T, C, (pad + T) * C, nv_flag, p, (pad + T) * C, st))
+        assert torch.equal(padded[:, pad:], dense_out) and not bool(padded[:, :pad].any())
+
+
+def test_spatial_dropout_kernel():
+    """whole channels of an utterance dropped for all frames, kept ones scaled by 1/(1-rate); the mask follows the device
+    step counter; rate 0 is the identity"""
+    from lidbox_amd import _native as nv
+    st = nv.current_stream()
+    B, T, C, pad, rate = 64, 20, 40, 4, 0.25
+    step = torch.zeros(2, dtype=torch.int64, device="cuda")
+    masks = []
+    for s_ in range(3):
+        step[0] = s_
+        x = torch.ones((B, pad + T, C), device="cuda")
+        m = torch.zeros((B, C), device="cuda")
+        p = ctypes.c_void_p(x.data_ptr() + 4 * pad * C)
+        nv.check(nv.lib.lidbox_spatial_dropout(p, B, T, C, (pad + T) * C, rate, 1234, nv.ptr(step), nv.ptr(m), st))
+        xv = x[:, pad:]
+        assert bool((x[:, :pad] == 1).all())                               # rows before the view untouched
+        assert bool((xv == xv[:, :1]).all())                               # the same factor for every frame
+        assert torch.equal(xv[:, 0], m)
+        vals = set(np.unique(m.cpu().numpy()).tolist())
+        assert vals == {0.0, np.float32(1.0 / (1.0 - rate)).item()}
+        masks.append(m.cpu().numpy())
+    keep = np.mean([float((m > 0).mean()) for m in masks])
+    assert abs(keep - (1 - rate)) < 0.03                                    # 7680 draws
+    assert not np.array_equal(masks[0], masks[1]) and not np.array_equal(masks[1], masks[2])
+    x = torch.ones((B, T, C), device="cuda")
+    nv.check(nv.lib.lidbox_spatial_dropout(nv.ptr(x), B, T, C, T * C, 0.0, 1, None, None, st))
+    assert bool((x == 1).all())
+    with pytest.raises(ValueError):
+        nv.check(nv.lib.lidbox_spatial_dropout(nv.ptr(x), B, T, C, T * C, 1.0, 1, None, None, st))
