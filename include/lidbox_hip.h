@@ -348,6 +348,29 @@ int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n
                      float beta1, float beta2, float eps, float grad_scale, void* state,
                      lidbox_stream_t stream);
 
+/* ------------------------------------------------------------------ BatchNormalization (f1: xvector_2d.py:36,43)
+ * tf.keras.layers.BatchNormalization(axis=-1) over x viewed as [R rows, C channels] (dense).  Training: batch mean and
+ * population variance -> mean_out / invstd_out (kept for backward), scale = gamma * invstd, shift = beta - mean * scale,
+ * and (moving_* != NULL) moving = moving * momentum + batch * (1 - momentum).  Inference: the same constants from the
+ * moving statistics.  lidbox_bn_apply writes y = x * scale + shift through a rows descriptor (the last front-end layer
+ * lands behind the causal pad rows of the first Conv1D's input).  Deterministic (fixed-order partial sums in float64).
+ * workspace: lidbox_bn_workspace(R, C) bytes, 8-byte aligned. */
+size_t lidbox_bn_workspace(long R, int C);
+int lidbox_bn_train_stats(const float* x, long R, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* moving_mean, float* moving_var, float* mean_out, float* invstd_out,
+                          float* scale_out, float* shift_out, void* workspace, size_t workspace_bytes,
+                          lidbox_stream_t stream);
+int lidbox_bn_infer_consts(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                           float eps, int C, float* scale_out, float* shift_out, lidbox_stream_t stream);
+int lidbox_bn_apply(const float* x, long R, int C, const float* scale, const float* shift, lidbox_rows_out_t y,
+                    lidbox_stream_t stream);
+/* backward of the training-mode normalisation: dgamma = sum dy * xhat, dbeta = sum dy,
+ * dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)); relu_mask != 0 multiplies dx by (x > 0): x is then the
+ * output of the Conv2D's ReLU and dx the gradient in front of it.  dy through a rows descriptor, x / dx dense. */
+int lidbox_bn_bwd(const float* x, lidbox_rows_t dy, long R, int C, const float* mean, const float* invstd,
+                  const float* gamma, int relu_mask, float* dgamma, float* dbeta, float* dx, void* workspace,
+                  size_t workspace_bytes, lidbox_stream_t stream);
+
 /* out[0] = mean of n floats (one workgroup, fixed order).  Keras reduces the per-example losses of a batch this way
  * (losses.py:38 returns per-example values; keras_utils.py:141-149 compiles the mean). */
 int lidbox_mean(const float* x, long n, float* out, lidbox_stream_t stream);
@@ -369,6 +392,10 @@ int lidbox_spatial_dropout(float* x, int B, int T, int C, long batch_stride, flo
 int lidbox_copy_2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes,
                    size_t height, lidbox_stream_t stream);
 int lidbox_zero_2d(void* dst, size_t pitch, size_t width_bytes, size_t height, lidbox_stream_t stream);
+
+/* x *= alpha over n floats (stream-ordered): turns an all-reduce(sum) of the replicas' BatchNormalization running
+ * statistics into their mean */
+int lidbox_scale(float* x, long n, float alpha, lidbox_stream_t stream);
 
 /* fill n floats with value (stream-ordered) */
 int lidbox_fill(float* x, long n, float value, lidbox_stream_t stream);

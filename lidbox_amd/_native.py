@@ -108,6 +108,12 @@ _SIGS = {
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),
+    "lidbox_scale": (_i, [_vp, _l, _f, _vp]),
+    "lidbox_bn_workspace": (_sz, [_l, _i]),
+    "lidbox_bn_train_stats": (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "lidbox_bn_infer_consts": (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "lidbox_bn_apply": (_i, [_vp, _l, _i, _vp, _vp, Rows, _vp]),
+    "lidbox_bn_bwd": (_i, [_vp, Rows, _l, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lidbox_neg_acos": (_i, [_vp, _l, _i, _i, _vp, _vp]),
     "lidbox_spatial_dropout": (_i, [_vp, _i, _i, _i, _l, _f, C.c_ulonglong, _vp, _vp, _vp]),
     "lidbox_copy_2d": (_i, [_vp, _sz, _vp, _sz, _sz, _sz, _vp]),

@@ -585,6 +585,10 @@ __global__ __launch_bounds__(256) void spatial_dropout_kernel(float* __restrict_
     }
 }
 
+__global__ void scale_kernel(float* __restrict__ x, long n, float alpha) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= alpha;
+}
+
 __global__ void fill_kernel(float* __restrict__ x, long n, float value) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         x[i] = value;
@@ -776,6 +780,14 @@ extern "C" int lidbox_zero_2d(void* dst, size_t pitch, size_t width_bytes, size_
     LBX_ARG(dst && pitch >= width_bytes, "dst != NULL; pitch >= width");
     if (width_bytes == 0 || height == 0) return LIDBOX_OK;
     LBX_HIP(hipMemset2DAsync(dst, pitch, 0, width_bytes, height, (hipStream_t)stream));
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_scale(float* x, long n, float alpha, lidbox_stream_t stream) {
+    LBX_ARG(x && n >= 0, "x != NULL");
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, alpha);
+    LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
 

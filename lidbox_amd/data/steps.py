@@ -214,16 +214,21 @@ def create_signal_chunks(ds, length_ms, step_ms, max_pad_ms=0, deterministic_out
 # ------------------------------------------------------------------ embeddings
 def extract_embeddings(ds, config):
     """reference steps.py:674-705.  config = {"extractors": [...], "batch_size": 1, "no_unbatch": False}.
-    The reference builds each extractor from a model config + checkpoint (KerasWrapper); here an extractor is an
-    already built callable -- the result of `module.as_embedding_extractor(model)`, or a model that has
-    `.embed` -- mapping inputs [B, T, C] to embeddings [B, D].  The embeddings of several extractors are
-    concatenated on axis 1 (steps.py:693).  Elements of one batch must share the input shape (tf.data's
-    `batch` has the same requirement)."""
+    An extractor is, as in the reference, a model config + checkpoint description handed to
+    `KerasWrapper.from_config_as_embedding_extractor_fn` (keys cache_directory, model, experiment_name, input_shape,
+    output_shape, best_checkpoint; steps.py:680-681) -- or, additionally, an already built callable: the result of
+    `module.as_embedding_extractor(model)`, or a model that has `.embed`, mapping inputs [B, T, C] to embeddings
+    [B, D].  The embeddings of several extractors are concatenated on axis 1 (steps.py:693).  Elements of one batch
+    must share the input shape (tf.data's `batch` has the same requirement)."""
     extractors = []
     for e in config["extractors"]:
-        fn = e.embed if hasattr(e, "embed") else e
+        if isinstance(e, dict):
+            from ..models.keras_utils import KerasWrapper
+            fn = KerasWrapper.from_config_as_embedding_extractor_fn(e)
+        else:
+            fn = e.embed if hasattr(e, "embed") else e
         if not callable(fn):
-            raise ValueError("extractors must be callables mapping inputs [B,T,C] to embeddings [B,D]")
+            raise ValueError("extractors must be checkpoint configs or callables mapping inputs [B,T,C] to embeddings [B,D]")
         extractors.append(fn)
     logger.info("Using %d extractors", len(extractors))
     batch_size = int(config.get("batch_size", 1))

@@ -105,7 +105,11 @@ class ModelCheckpoint:
 class EarlyStopping:
     """tf.keras.callbacks.EarlyStopping subset: monitor, patience, mode, min_delta"""
 
-    def __init__(self, monitor="val_loss", patience=0, mode="min", min_delta=0.0, **unused):
+    def __init__(self, monitor="val_loss", patience=0, mode="min", min_delta=0.0, verbose=0, **unsupported):
+        # arguments that would change behaviour but are not implemented must not be swallowed
+        bad = {k: v for k, v in unsupported.items() if not (k == "restore_best_weights" and not v) and not (k == "baseline" and v is None)}
+        if bad:
+            raise ValueError("EarlyStopping: unsupported arguments %s" % sorted(bad))
         self.monitor, self.patience, self.mode, self.min_delta = monitor, int(patience), mode, float(min_delta)
         self.best, self.wait = None, 0
 
@@ -119,7 +123,7 @@ class EarlyStopping:
             self.best, self.wait = value, 0
         else:
             self.wait += 1
-            if self.wait > self.patience:
+            if self.wait >= self.patience:                   # tf.keras: stops once `patience` epochs brought no improvement
                 wrapper.stop_training = True
 
 
@@ -274,11 +278,15 @@ class KerasWrapper:
         x = torch.as_tensor(x, dtype=torch.float32)
         y = torch.as_tensor(y).to(torch.int32).reshape(-1)
         key = tuple(x.shape)
-        buf = self._staging.get(key)
+        buf = self._staging.pop(key, None)
         if buf is None:
+            # at most 4 shapes stay staged (what Trainer / the model keep graphs and workspaces for): `fit` expects a
+            # small set of fixed batch shapes -- bucket or pad variable-length batches (group_by_input_length) up front
+            while len(self._staging) >= 4:
+                self._staging.pop(next(iter(self._staging)))
             dev = self.keras_model.device
             buf = (torch.empty(key, dtype=torch.float32, device=dev), torch.empty(key[0], dtype=torch.int32, device=dev))
-            self._staging[key] = buf
+        self._staging[key] = buf                             # most recently used last
         buf[0].copy_(x)
         buf[1].copy_(y)
         return buf

@@ -57,6 +57,26 @@ class FreqAttentionSpec:
             raise ValueError("frequency attention supports 1 <= d_f <= 64 bins")
 
 
+class FreqConvSpec:
+    """FrameLayer2D of reference xvector_2d.py:26-46: Conv2D(filters, (1, k), strides=(1, s), padding="valid",
+    activation="relu") along the FREQUENCY axis of [B, T, F, C] followed by BatchNormalization (Keras defaults: momentum
+    0.99, epsilon 1e-3).  Every frame is an independent row batch, so the convolution is the same implicit-row GEMM as a
+    Conv1D with "batch" = B*T and no padding."""
+
+    def __init__(self, name, filters, kernel_width, stride, momentum=0.99, epsilon=1e-3, dropout_rate=None):
+        self.name, self.filters, self.k, self.s = name, int(filters), int(kernel_width), int(stride)
+        self.momentum, self.epsilon = float(momentum), float(epsilon)
+        if dropout_rate:
+            raise ValueError("FrameLayer2D dropout is not supported (the reference never enables it: xvector_2d.py:70-73)")
+        if self.k < 1 or self.s < 1 or self.filters < 1:
+            raise ValueError("filters, kernel width and stride must be >= 1")
+
+
+def freq_out_len(F, k, s):
+    """Keras Conv2D(padding="valid") along frequency"""
+    return (F - k) // s + 1 if F >= k else 0
+
+
 class DenseSpec:
     def __init__(self, name, units, relu=True):
         self.name, self.units, self.relu = name, int(units), relu
@@ -113,6 +133,20 @@ class _Workspace:
         # activations (zero-initialised once: the pad rows stay zero forever)
         self.act = [torch.zeros((B, self.pads[i] + self.Ts[i], chans[i]), **f32) for i in range(len(chans))]
         self.dact = [None] + [torch.zeros_like(a) for a in self.act[1:]]
+        fe = model.frontend
+        if fe:
+            # 2-D front-end (xvector_2d.py:69-73): model input [B, T, F]; layer i: a = relu(conv) [B*T*F_i+1, C_i+1] dense,
+            # y = BatchNorm(a) dense -- except the last layer's, which IS the first Conv1D's input (act[0])
+            self.dact[0] = torch.zeros_like(self.act[0])
+            self.fe_in = torch.zeros((B, T, model.model_input_dim), **f32)
+            self.fe_R = [B * T * model.fe_dims[i + 1] for i in range(len(fe))]
+            self.fe_a = [torch.zeros((self.fe_R[i], l.filters), **f32) for i, l in enumerate(fe)]
+            self.fe_dz = [torch.zeros_like(a) for a in self.fe_a]
+            self.fe_y = [torch.zeros_like(a) for a in self.fe_a[:-1]]
+            self.fe_dy = [torch.zeros_like(a) for a in self.fe_a[:-1]]
+            self.fe_consts = [torch.zeros((4, l.filters), **f32) for l in fe]        # mean, invstd, scale, shift
+            bn_bytes = max(int(nv.lib.lidbox_bn_workspace(self.fe_R[i], l.filters)) for i, l in enumerate(fe))
+            self.bn_ws = torch.empty(max(16, bn_bytes), dtype=torch.uint8, device=dev)
         C_last = chans[-1]
         att = model.attention
         if att is not None:
@@ -134,6 +168,15 @@ class _Workspace:
         # one GEMM workspace sized for the largest split (wgrad partials, small-M split-K partials)
         ws_bytes = 16
         g = model.gemm
+        if fe:
+            cin_f = 1
+            for i, l in enumerate(fe):
+                gf = model.fe_gemm(i)
+                M, kk = self.fe_R[i], l.k * cin_f
+                if M > 0:
+                    ws_bytes = max(ws_bytes, gf.tn_workspace(M, kk, l.filters), gf.rows_workspace(M, l.filters, kk),
+                                   gf.rows_workspace(M, kk, l.filters))
+                cin_f = l.filters
         cin = model.input_dim
         for i, c in enumerate(convs):
             M = B * self.Ts[i + 1]
@@ -155,21 +198,39 @@ class _Workspace:
         self.gemm_ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)     # wgrad side stream's own workspace
 
     def input_view(self):
-        """[B, T, C0] view of act[0] behind its causal zero rows."""
+        """[B, T, C0] view of where the model input lives: act[0] behind its causal zero rows, or the 2-D front-end's
+        input buffer."""
+        if hasattr(self, "fe_in"):
+            return self.fe_in
         return self.act[0][:, self.pads[0]:, :]
+
+    def input_target(self):
+        """(pointer, floats between utterances, T, C) of the model input buffer (what Trainer / _load_input fill)"""
+        v = self.input_view()
+        return ctypes.c_void_p(v.data_ptr()), v.stride(0), v.shape[1], v.shape[2]
 
 
 class SequentialTDNN:
     """convs -> pool -> denses -> log_softmax, parameters in one flat buffer."""
 
     def __init__(self, input_shape, convs, pool, denses, name="tdnn", output_activation="log_softmax",
-                 channel_dropout_rate=0.0, seed=None, device=None, compute_dtype="float32", attention=None):
+                 channel_dropout_rate=0.0, seed=None, device=None, compute_dtype="float32", attention=None, frontend=None):
         if not torch.cuda.is_available():
             raise nv.LidboxHipError("lidbox_amd models need a HIP device (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.name = name
         self.input_shape = tuple(input_shape)
-        self.input_dim = int(input_shape[-1])
+        self.model_input_dim = int(input_shape[-1])            # channels of what the caller passes
+        self.frontend = list(frontend) if frontend else None
+        self.input_dim = self.model_input_dim                  # channels of the first Conv1D's input
+        if self.frontend:
+            # [B, T, F] -> reshape_to_image -> FrameLayer2D x n -> flatten_channels (xvector_2d.py:68-76)
+            self.fe_dims = [self.model_input_dim]
+            for l in self.frontend:
+                self.fe_dims.append(freq_out_len(self.fe_dims[-1], l.k, l.s))
+            if self.fe_dims[-1] < 1:
+                raise ValueError("input has too few frequency channels (%d) for the 2-D front-end" % self.model_input_dim)
+            self.input_dim = self.fe_dims[-1] * self.frontend[-1].filters
         self.convs, self.pool, self.denses = list(convs), pool, list(denses)
         self.attention = attention
         assert pool in ("stats", "avg")
@@ -199,6 +260,13 @@ class SequentialTDNN:
         # ---- flat parameter layout
         self.layout = {}           # name -> (offset, shape)
         off = 0
+        if self.frontend:          # first in the flat buffer: their gradients complete last, in the lowest all-reduce bucket
+            cin = 1
+            for l in self.frontend:
+                self.layout[l.name + "_conv.W"] = (off, (1, l.k, cin, l.filters)); off = _align4(off + l.k * cin * l.filters)
+                for suffix in ("_conv.b", "_bn.gamma", "_bn.beta"):
+                    self.layout[l.name + suffix] = (off, (l.filters,)); off = _align4(off + l.filters)
+                cin = l.filters
         cin = self.input_dim
         for c in self.convs:
             self.layout[c.name + ".W"] = (off, (cin, c.filters) if c.dense_kernel else (c.k, cin, c.filters))
@@ -216,6 +284,12 @@ class SequentialTDNN:
         self.num_flat = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.flat_grad = torch.zeros_like(self.flat)
+        # non-trainable state (BatchNormalization moving statistics): its own flat buffer, not touched by Adam
+        self.state_layout, soff = {}, 0
+        for l in self.frontend or []:
+            for suffix in ("_bn.moving_mean", "_bn.moving_variance"):
+                self.state_layout[l.name + suffix] = (soff, (l.filters,)); soff = _align4(soff + l.filters)
+        self.state = torch.zeros(max(soff, 4), dtype=torch.float32, device=self.device)
         self._init_weights(seed)
         self._ws = {}
         # optional second HIP stream: wgrad GEMMs run on it concurrently with the dgrad chain (they only
@@ -229,7 +303,10 @@ class SequentialTDNN:
         host = np.zeros(self.num_flat, np.float32)
         for name, (off, shape) in self.layout.items():
             if name.endswith(".W"):
-                if len(shape) == 3:
+                if len(shape) == 4:                          # Conv2D kernel [1, k, C_in, C_out]
+                    _, k, ci, co = shape
+                    fan_in, fan_out = k * ci, k * co
+                elif len(shape) == 3:
                     k, ci, co = shape
                     fan_in, fan_out = k * ci, k * co
                 else:
@@ -237,9 +314,16 @@ class SequentialTDNN:
                 limit = math.sqrt(6.0 / (fan_in + fan_out))
                 n = int(np.prod(shape))
                 host[off:off + n] = rng.uniform(-limit, limit, size=n).astype(np.float32)
+            elif name.endswith("_bn.gamma"):
+                host[off:off + shape[0]] = 1.0
         self.flat.copy_(torch.from_numpy(host))
+        for name, (off, shape) in self.state_layout.items():
+            self.state[off:off + shape[0]] = 1.0 if name.endswith("moving_variance") else 0.0
 
     def param(self, name, grad=False):
+        if name in self.state_layout:
+            off, shape = self.state_layout[name]
+            return self.state[off:off + int(np.prod(shape))].view(shape)
         off, shape = self.layout[name]
         buf = self.flat_grad if grad else self.flat
         return buf[off:off + int(np.prod(shape))].view(shape)
@@ -248,15 +332,25 @@ class SequentialTDNN:
         return [(n, self.param(n)) for n in self.layout]
 
     def count_params(self):
-        return sum(int(np.prod(s)) for _, s in self.layout.values())
+        """Keras `Model.count_params()`: trainable + non-trainable (BatchNormalization moving statistics)"""
+        return sum(int(np.prod(s)) for _, s in list(self.layout.values()) + list(self.state_layout.values()))
 
     def get_weights(self):
-        """dict name -> numpy array in Keras layouts."""
-        return {n: self.param(n).detach().cpu().numpy().copy() for n in self.layout}
+        """dict name -> numpy array in Keras layouts (trainable parameters and the BatchNormalization moving statistics)."""
+        return {n: self.param(n).detach().cpu().numpy().copy() for n in list(self.layout) + list(self.state_layout)}
 
     def set_weights(self, weights):
         for n, w in weights.items():
-            self.param(n).copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device))
+            self.param(n).copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device).reshape(self.param(n).shape))
+
+    def _sp(self, name):
+        off, _ = self.state_layout[name]
+        return ctypes.c_void_p(self.state.data_ptr() + 4 * off)
+
+    def fe_gemm(self, i):
+        """GEMM family of front-end layer i: the first one contracts over k = 5 single-channel taps (row stride 1 float),
+        which the bf16 family's 16-byte operand rule excludes -- it always runs in the fp32 family"""
+        return self.gemm if i > 0 else _GemmFamily("float32")
 
     def _p(self, name, grad=False):
         off, _ = self.layout[name]
@@ -296,10 +390,91 @@ class SequentialTDNN:
         Tp, C = buf.shape[1], buf.shape[2]
         return _rows(buf.data_ptr() + 4 * ws.pads[i] * C, Tp * C, C, ws.B, ws.Ts[i])
 
-    def forward_ws(self, ws, upto_embedding=False):
-        """act[0] must already hold the input.  Returns logp (or the embedding)."""
+    def _fe_rows_in(self, ws, i):
+        """implicit rows of front-end layer i's input: one row per (frame, output column), k * C_in contiguous floats"""
+        l = self.frontend[i]
+        cin = 1 if i == 0 else self.frontend[i - 1].filters
+        src = ws.fe_in if i == 0 else ws.fe_y[i - 1]
+        return _rows(src.data_ptr(), self.fe_dims[i] * cin, l.s * cin, ws.B * ws.T, self.fe_dims[i + 1])
+
+    def _fe_last_rows(self, buf, ws):
+        """the last front-end layer's output rows (b, t, col) inside act[0] / dact[0] (flatten_channels, xvector_2d.py:76)"""
+        Tp, C = buf.shape[1], buf.shape[2]
+        return _rows(buf.data_ptr() + 4 * ws.pads[0] * C, Tp * C, self.frontend[-1].filters, ws.B, ws.T * self.fe_dims[-1])
+
+    def _forward_frontend(self, ws, training, update_moving):
+        st, lib = nv.current_stream(), nv.lib
+        cin = 1
+        for i, l in enumerate(self.frontend):
+            R, Co, K = ws.fe_R[i], l.filters, l.k * cin
+            if R == 0:
+                break
+            g = self.fe_gemm(i)
+            nv.check(g.nn(self._fe_rows_in(ws, i), self._p(l.name + "_conv.W"), Co, _rows(ws.fe_a[i].data_ptr(), 0, Co, 1, R),
+                          K, Co, nv.EPI_BIAS_RELU, self._p(l.name + "_conv.b"), nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
+            c = ws.fe_consts[i]
+            cp = [ctypes.c_void_p(c.data_ptr() + 4 * j * Co) for j in range(4)]
+            if training:
+                mm = self._sp(l.name + "_bn.moving_mean") if update_moving else None
+                mv = self._sp(l.name + "_bn.moving_variance") if update_moving else None
+                nv.check(lib.lidbox_bn_train_stats(nv.ptr(ws.fe_a[i]), R, Co, self._p(l.name + "_bn.gamma"), self._p(l.name + "_bn.beta"),
+                                                   l.epsilon, l.momentum, mm, mv, cp[0], cp[1], cp[2], cp[3],
+                                                   nv.ptr(ws.bn_ws), ws.bn_ws.numel(), st))
+            else:
+                nv.check(lib.lidbox_bn_infer_consts(self._p(l.name + "_bn.gamma"), self._p(l.name + "_bn.beta"),
+                                                    self._sp(l.name + "_bn.moving_mean"), self._sp(l.name + "_bn.moving_variance"),
+                                                    l.epsilon, Co, cp[2], cp[3], st))
+            last = i == len(self.frontend) - 1
+            y = self._fe_last_rows(ws.act[0], ws) if last else _rows(ws.fe_y[i].data_ptr(), 0, Co, 1, R)
+            nv.check(lib.lidbox_bn_apply(nv.ptr(ws.fe_a[i]), R, Co, cp[2], cp[3], y, st))
+            cin = Co
+
+    def _backward_frontend(self, ws):
+        """dact[0] holds d loss / d (front-end output).  BatchNorm + ReLU backward, wgrad / bias gradient, dgrad per layer."""
+        st, lib = nv.current_stream(), nv.lib
+        gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
+        n = len(self.frontend)
+        for i in range(n - 1, -1, -1):
+            l = self.frontend[i]
+            cin = 1 if i == 0 else self.frontend[i - 1].filters
+            R, Co, K = ws.fe_R[i], l.filters, l.k * cin
+            if R == 0:
+                continue
+            g = self.fe_gemm(i)
+            c = ws.fe_consts[i]
+            dy = self._fe_last_rows(ws.dact[0], ws) if i == n - 1 else _rows(ws.fe_dy[i].data_ptr(), 0, Co, 1, R)
+            nv.check(lib.lidbox_bn_bwd(nv.ptr(ws.fe_a[i]), dy, R, Co, ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(c.data_ptr() + 4 * Co),
+                                       self._p(l.name + "_bn.gamma"), 1, self._p(l.name + "_bn.gamma", True),
+                                       self._p(l.name + "_bn.beta", True), nv.ptr(ws.fe_dz[i]), nv.ptr(ws.bn_ws), ws.bn_ws.numel(), st))
+            dz = _rows(ws.fe_dz[i].data_ptr(), 0, Co, 1, R)
+            A_rows = self._fe_rows_in(ws, i)
+            self._launch_wgrad(ws, lambda w, nb, s_, A_rows=A_rows, dz=dz, l=l, K=K, Co=Co, g=g: nv.check(g.tn(
+                A_rows, dz, self._p(l.name + "_conv.W", True), Co, K, Co, 0, self._p(l.name + "_conv.b", True), w, nb, s_)))
+            if i == 0:
+                continue
+            # dgrad into fe_dy[i-1] [B*T, F_i, C_in]: tap groups as in backward_conv_ws, the frame as the "batch"
+            dprev = ws.fe_dy[i - 1]
+            Fi, Fo, BT = self.fe_dims[i], self.fe_dims[i + 1], ws.B * ws.T
+            if l.k < l.s:
+                nv.check(lib.lidbox_zero_2d(nv.ptr(dprev), 4 * dprev.numel(), 4 * dprev.numel(), 1, st))
+            elif Fo * l.s < Fi:
+                nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * Fo * l.s * cin), 4 * Fi * cin,
+                                            4 * (Fi - Fo * l.s) * cin, BT, st))
+            for grp in range((l.k + l.s - 1) // l.s):
+                ntaps = min(l.s, l.k - grp * l.s)
+                Cd = _rows(dprev.data_ptr() + 4 * grp * l.s * cin, Fi * cin, l.s * cin, BT, Fo)
+                Wg = ctypes.c_void_p(self._p(l.name + "_conv.W").value + 4 * grp * l.s * cin * Co)
+                nv.check(g.nt(dz, Wg, Co, Cd, Co, ntaps * cin, nv.EPI_NONE if grp == 0 else nv.EPI_ACCUM, None, gws, gws_n, st))
+        self.join_wgrad()
+
+    def forward_ws(self, ws, upto_embedding=False, training=False, update_moving=True):
+        """The model input buffer (ws.input_view()) must already hold the input.  Returns logp (or the embedding).
+        training selects batch statistics in BatchNormalization layers (update_moving=False leaves the running
+        statistics alone: warm-up passes before a graph capture)."""
         st = nv.current_stream()
         lib = nv.lib
+        if self.frontend:
+            self._forward_frontend(ws, training, update_moving)
         cin = self.input_dim
         for i, c in enumerate(self.convs):
             if ws.B * ws.Ts[i + 1] > 0 and c.d == 1:
@@ -450,14 +625,14 @@ class SequentialTDNN:
         A_rows = self._conv_rows_in(ws, i)
         self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
             A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
-        if i == 0:
+        if i == 0 and not self.frontend:
             return
         # dgrad into dact[i].  Window t touches padded rows [t*s, t*s+k).  Group g = taps
         # [g*s, g*s+ntaps) writes rows (t+g)*s + [0, ntaps): disjoint across t, so each group is one
         # GEMM; group 0 overwrites, later groups accumulate.  Rows no tap produces must read as zero.
         dprev, aprev = ws.dact[i], ws.act[i]
         Tp = dprev.shape[1]
-        relu_prev = self.convs[i - 1].relu
+        relu_prev = self.convs[i - 1].relu if i > 0 else False      # conv 0 behind a front-end reads a BatchNorm output
         if c.k < c.s:
             nv.check(lib.lidbox_zero_2d(nv.ptr(dprev), 4 * dprev.numel(), 4 * dprev.numel(), 1, st))   # holes inside every stride period
         elif To * c.s < Tp:
@@ -476,6 +651,8 @@ class SequentialTDNN:
             else:
                 epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
             nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+        if i == 0:
+            self._backward_frontend(ws)
 
     def _backward_dilated(self, ws, i, dy):
         """dilated conv i (strides 1): per tap j, dW[j] = act[i][rows + j*d]^T dY and
@@ -510,21 +687,19 @@ class SequentialTDNN:
     # ------------------------------------------------------------------ public call
     def _load_input(self, ws, x, training):
         x = nv.require_gpu_tensor(x, "x", torch.float32)
-        if x.dim() != 3 or x.shape[2] != self.input_dim:
-            raise ValueError("expected input [B, T, %d], got %s" % (self.input_dim, tuple(x.shape)))
+        if x.dim() != 3 or x.shape[2] != self.model_input_dim:
+            raise ValueError("expected input [B, T, %d], got %s" % (self.model_input_dim, tuple(x.shape)))
         if x.stride(2) != 1 or x.stride(1) != x.shape[2]:
             x = x.contiguous()
-        a0 = ws.act[0]
-        Tp, C = a0.shape[1], a0.shape[2]
         st = nv.current_stream()
-        in_ptr = ctypes.c_void_p(a0.data_ptr() + 4 * ws.pads[0] * C)
-        nv.check(nv.lib.lidbox_copy_2d(in_ptr, 4 * Tp * C, nv.ptr(x), 4 * (x.stride(0) if ws.B > 1 else ws.T * C),
+        in_ptr, in_bs, _, C = ws.input_target()
+        nv.check(nv.lib.lidbox_copy_2d(in_ptr, 4 * in_bs, nv.ptr(x), 4 * (x.stride(0) if ws.B > 1 else ws.T * C),
                                        4 * ws.T * C, ws.B, st))
         if training and self.channel_dropout_rate > 0:
             # Keras SpatialDropout1D (xvector.py:50-51): whole channels dropped per utterance; eager calls draw from a
             # host-side call counter (the captured train step keys its masks on the device-side Adam step instead)
             self._dropout_calls += 1
-            nv.check(nv.lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, Tp * C, self.channel_dropout_rate,
+            nv.check(nv.lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, in_bs, self.channel_dropout_rate,
                                                    (self.dropout_seed + 0x51ED27 * self._dropout_calls) & (2 ** 64 - 1),
                                                    None, None, st))
 
@@ -533,7 +708,7 @@ class SequentialTDNN:
         with torch.cuda.device(self.device):
             ws = self.workspace(x.shape[0], x.shape[1])
             self._load_input(ws, x, training)
-            return self.forward_ws(ws).clone()
+            return self.forward_ws(ws, training=training).clone()
 
     def embed(self, x):
         """as_embedding_extractor output: first dense layer's affine output (activation removed)."""

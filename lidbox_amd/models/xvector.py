@@ -11,6 +11,32 @@ TIME_AXIS = 1
 STDDEV_SQRT_MIN_CLIP = 1e-10     # reference xvector.py:22 (applied inside lidbox_stats_pool_fwd)
 
 
+class GlobalMeanStddevPooling1D:
+    """reference xvector.py:25-35: mean and standard deviation of the inputs [B, T, C] over the time axis, concatenated
+    to [B, 2C]; the variance is clipped to [1e-10, max] before the square root.  A callable over device tensors on
+    `lidbox_stats_pool_fwd` (the kernel the models' pooling stage runs); time-major rows may be strided."""
+    name = "stats_pooling"
+
+    def __call__(self, inputs):
+        import torch
+        from .. import _native as nv
+        x = nv.require_gpu_tensor(inputs, "inputs", torch.float32)
+        if x.dim() != 3:
+            raise ValueError("expected inputs [B, T, C], got %s" % (tuple(x.shape),))
+        if x.stride(2) != 1:
+            x = x.contiguous()
+        B, T, C = x.shape
+        if T == 0:
+            raise ValueError("cannot pool over an empty time axis")
+        out = torch.empty((B, 2 * C), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            nv.check(nv.lib.lidbox_stats_pool_fwd(nv.ptr(x), B, T, C, x.stride(0) if B > 1 else T * x.stride(1), x.stride(1),
+                                                  nv.ptr(out), nv.current_stream()))
+        return out
+
+    call = __call__
+
+
 def frame_layer(filters, kernel_size, strides, padding="causal", activation="relu", name="frame", dilation_rate=1):
     """reference xvector.py:38-39.  dilation_rate is not in the reference (its third argument is Keras `strides`);
     it is this build's opt-in for Kaldi-style dilated TDNN contexts and follows Keras Conv1D(dilation_rate=...)."""

@@ -183,30 +183,29 @@ class Trainer:
     def _forward_loss(self, ws, inputs, labels):
         lib, st = nv.lib, nv.current_stream()
         model = self.model
-        a0 = ws.act[0]
-        Tp, C = a0.shape[1], a0.shape[2]
-        in_ptr = nv.C.c_void_p(a0.data_ptr() + 4 * ws.pads[0] * C)       # behind the causal zero rows of the first Conv1D
+        in_ptr, in_bs, _, C = ws.input_target()              # act[0] behind the first Conv1D's causal zero rows, or the 2-D front-end's input
         if self.feature is not None:
             plan, kind = self.feature["plan"], self.feature["kind"]
             Bn, N = inputs.shape
             stride = inputs.stride(0) if Bn > 1 else N
-            # features land directly in the first Conv1D's input buffer
+            # features land directly in the model's input buffer
             nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride, in_ptr,
-                                                     Tp * C, None, 0, st))
+                                                     in_bs, None, 0, st))
             if self.feature.get("cmvn"):
                 # per-utterance CMVN over time (features/__init__.py:22-32), in place where the conv reads it
-                nv.check(lib.lidbox_cmvn_strided_fwd(in_ptr, Bn, ws.T, C, Tp * C, 1, in_ptr, Tp * C, st))
+                nv.check(lib.lidbox_cmvn_strided_fwd(in_ptr, Bn, ws.T, C, in_bs, 1, in_ptr, in_bs, st))
         else:
             if inputs.stride(2) != 1 or inputs.stride(1) != C:
                 inputs = inputs.contiguous()
-            nv.check(lib.lidbox_copy_2d(in_ptr, 4 * Tp * C, nv.ptr(inputs), 4 * (inputs.stride(0) if ws.B > 1 else ws.T * C),
+            nv.check(lib.lidbox_copy_2d(in_ptr, 4 * in_bs, nv.ptr(inputs), 4 * (inputs.stride(0) if ws.B > 1 else ws.T * C),
                                         4 * ws.T * C, ws.B, st))
         if model.channel_dropout_rate > 0:
             # SpatialDropout1D of the training pass (xvector.py:50-51, cnn.py:29-30); the Adam step counter on the device
             # keys the mask, so every replay of the captured step draws a new one
-            nv.check(lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, Tp * C, model.channel_dropout_rate,
+            nv.check(lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, in_bs, model.channel_dropout_rate,
                                                 model.dropout_seed, nv.ptr(self.adam_state), None, st))
-        out = model.forward_ws(ws)
+        # BatchNormalization layers: batch statistics; the running statistics move once per real step (not in warm-up passes)
+        out = model.forward_ws(ws, training=True, update_moving=not self._warming)
         B = ws.B
         scale = self._loss_scale(B)
         if self.loss_kind == "nll":
@@ -363,7 +362,20 @@ class Trainer:
                         self.sync.launch(nb - 1 - k)              # bucket (nb-1-k) is complete after stage k
                 self.sync.wait()
                 run[-1]()                                         # Adam
+            self._sync_state()
             return ws.loss[0]
+
+    def _sync_state(self):
+        """BatchNormalization running statistics under data parallelism: every replica normalises with ITS shard's batch
+        statistics (tf.keras BatchNormalization under MirroredStrategy; the reference never asks for
+        SyncBatchNormalization) and moves its running statistics with them; the replicas' running statistics are then
+        averaged (the MEAN aggregation Keras declares for these variables), one small all-reduce per step, so every rank
+        checkpoints the same values."""
+        state = getattr(self.model, "state", None)
+        if not self.sync.active or not getattr(self.model, "state_layout", None):
+            return
+        self.sync.dist.all_reduce(state, op=self.sync.dist.ReduceOp.SUM, group=self.sync.group)
+        nv.check(nv.lib.lidbox_scale(nv.ptr(state), state.numel(), 1.0 / self.sync.world, nv.current_stream()))
 
     def loss_and_grads(self, inputs, labels):
         """forward + backward only (no all-reduce, no optimizer): returns (loss, flat_grad view)."""

@@ -371,3 +371,98 @@ class SparseAverageDetectionCost(AverageDetectionCost):
 
     def update_state(self, labels, scores):
         super().update_state(np.eye(self.N, dtype=np.float32)[np.asarray(labels, np.int64)], scores)
+
+
+# ------------------------------------------------------------------ 8f.1 xvector_2d: Conv2D over frequency + BatchNorm
+FRAMES_2D = [("frame2d_1", 256, 5, 1), ("frame2d_2", 128, 3, 2), ("frame2d_3", 64, 3, 3),
+             ("frame2d_4", 32, 3, 3)]           # (name, filters, kernel width, stride) -- xvector_2d.py:70-73, kernel (1, w), strides (1, s)
+BN_MOMENTUM, BN_EPSILON = 0.99, 1e-3            # tf.keras.layers.BatchNormalization defaults (xvector_2d.py:36)
+
+
+def conv_freq_out_len(F, k, s):
+    """Keras Conv2D(padding="valid") along the frequency axis"""
+    return (F - k) // s + 1 if F >= k else 0
+
+
+def conv_freq_fwd(x, W, b, s, relu=True):
+    """Conv2D(filters, (1, k), strides=(1, s), padding="valid", activation="relu") on x [B, T, F, C_in]
+    (xvector_2d.py:29-35): every frame is convolved along frequency only.  W [1, k, C_in, C_out] (Keras kernel layout)."""
+    _, k, Ci, Co = W.shape
+    B, T, F, _ = x.shape
+    Fo = conv_freq_out_len(F, k, s)
+    idx = np.arange(Fo)[:, None] * s + np.arange(k)[None, :]
+    col = x[:, :, idx, :].reshape(B, T, Fo, k * Ci)
+    y = col @ W.reshape(k * Ci, Co) + b
+    return np.maximum(y, 0) if relu else y
+
+
+def batchnorm_fwd(x, gamma, beta, moving_mean, moving_var, training, momentum=BN_MOMENTUM, eps=BN_EPSILON):
+    """BatchNormalization(axis=-1).  training: batch mean / population variance over every axis but the last, moving
+    statistics moved by (1 - momentum) towards them; inference: the moving statistics.  Returns (y, moving_mean, moving_var)."""
+    axes = tuple(range(x.ndim - 1))
+    if training:
+        mean = x.mean(axis=axes)
+        var = ((x - mean) ** 2).mean(axis=axes)
+        moving_mean = moving_mean * momentum + mean * (1 - momentum)
+        moving_var = moving_var * momentum + var * (1 - momentum)
+    else:
+        mean, var = moving_mean, moving_var
+    return gamma * (x - mean) / np.sqrt(var + eps) + beta, moving_mean, moving_var
+
+
+def xvector_2d_freq_dims(F):
+    dims = [F]
+    for _, _, k, s in FRAMES_2D:
+        dims.append(conv_freq_out_len(dims[-1], k, s))
+    return dims
+
+
+def xvector_2d_init(input_dim, num_outputs, seed=0, dtype=np.float32):
+    """xvector_2d.py:66-93 in Keras layouts: Conv2D kernels [1, k, C_in, C_out] (glorot_uniform), biases 0, BatchNorm
+    gamma 1 / beta 0 / moving_mean 0 / moving_variance 1, then the x-vector TDNN on cols * 32 input channels."""
+    rng = np.random.default_rng(seed)
+    p, c = {}, 1
+    for name, f, k, s in FRAMES_2D:
+        p[name + "_conv.W"] = glorot_uniform(rng, (1, k, c, f), k * c, k * f, dtype)
+        p[name + "_conv.b"] = np.zeros(f, dtype)
+        p[name + "_bn.gamma"] = np.ones(f, dtype)
+        p[name + "_bn.beta"] = np.zeros(f, dtype)
+        p[name + "_bn.moving_mean"] = np.zeros(f, dtype)
+        p[name + "_bn.moving_variance"] = np.ones(f, dtype)
+        c = f
+    cols = xvector_2d_freq_dims(input_dim)[-1]
+    if cols < 1:
+        raise ValueError("input has too few frequency channels for the 2-D front-end")
+    c = cols * c
+    for name, f, k, s in XVECTOR_FRAMES:
+        p[name + ".W"] = glorot_uniform(rng, (k, c, f), k * c, k * f, dtype)
+        p[name + ".b"] = np.zeros(f, dtype)
+        c = f
+    c = 2 * c
+    for name, u in XVECTOR_SEGMENTS + [("output", num_outputs)]:
+        p[name + ".W"] = glorot_uniform(rng, (c, u), c, u, dtype)
+        p[name + ".b"] = np.zeros(u, dtype)
+        c = u
+    return p
+
+
+def xvector_2d_fwd(p, x, training=False, embedding=False):
+    """xvector_2d.py:66-93 with output_activation="log_softmax".  x [B, T, F] -> (log-probs [B, N], updated moving
+    statistics {name: value}); training selects batch statistics in the BatchNormalization layers."""
+    B, T, F = x.shape
+    h = x.reshape(B, T, F, 1)                                                     # reshape_to_image
+    new_stats = {}
+    for name, f, k, s in FRAMES_2D:
+        h = conv_freq_fwd(h, p[name + "_conv.W"], p[name + "_conv.b"], s, relu=True)
+        h, mm, mv = batchnorm_fwd(h, p[name + "_bn.gamma"], p[name + "_bn.beta"], p[name + "_bn.moving_mean"],
+                                  p[name + "_bn.moving_variance"], training)
+        new_stats[name + "_bn.moving_mean"], new_stats[name + "_bn.moving_variance"] = mm, mv
+    h = h.reshape(B, T, h.shape[2] * h.shape[3])                                  # flatten_channels
+    for name, f, k, s in XVECTOR_FRAMES:
+        h = conv1d_causal_fwd(h, p[name + ".W"], p[name + ".b"], s, relu=True)
+    pooled = stats_pool_fwd(h)
+    if embedding:
+        return dense_fwd(pooled, p["segment1.W"], p["segment1.b"], relu=False), new_stats
+    s1 = dense_fwd(pooled, p["segment1.W"], p["segment1.b"])
+    s2 = dense_fwd(s1, p["segment2.W"], p["segment2.b"])
+    return log_softmax(dense_fwd(s2, p["output.W"], p["output.b"], relu=False)), new_stats

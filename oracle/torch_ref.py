@@ -135,3 +135,29 @@ class TrainStepCPU:
         loss.backward()
         self.opt.step()
         return float(loss.detach())
+
+
+def xvector_2d_fwd(p, x, training=True):
+    """lidbox/models/xvector_2d.py:66-93 (autograd cross-check of the BatchNorm / Conv2D backward).  p: torch parameter
+    dict in Keras layouts (model_np.xvector_2d_init), x [B,T,F].  Batch statistics when training."""
+    B, T, Fq = x.shape
+    h = x.reshape(B * T, 1, Fq)                                                   # frames are independent: [N, C_in, F]
+    for name, f, k, s in model_np.FRAMES_2D:
+        W = p[name + "_conv.W"][0].permute(2, 1, 0)                               # [k, C_in, C_out] -> [C_out, C_in, k]
+        h = F.relu(F.conv1d(h, W, p[name + "_conv.b"], stride=s))
+        if training:
+            mean = h.mean(dim=(0, 2), keepdim=True)
+            var = ((h - mean) ** 2).mean(dim=(0, 2), keepdim=True)
+        else:
+            mean = p[name + "_bn.moving_mean"][None, :, None]
+            var = p[name + "_bn.moving_variance"][None, :, None]
+        h = p[name + "_bn.gamma"][None, :, None] * (h - mean) / torch.sqrt(var + model_np.BN_EPSILON) \
+            + p[name + "_bn.beta"][None, :, None]
+    # [B*T, C, cols] -> [B, T, cols * C] (Keras flattens (cols, channels) with channels fastest)
+    h = h.permute(0, 2, 1).reshape(B, T, -1)
+    for name, f, k, s in model_np.XVECTOR_FRAMES:
+        h = conv1d_causal(h, p[name + ".W"], p[name + ".b"], s)
+    h = stats_pool(h)
+    h = F.relu(h @ p["segment1.W"] + p["segment1.b"])
+    h = F.relu(h @ p["segment2.W"] + p["segment2.b"])
+    return F.log_softmax(h @ p["output.W"] + p["output.b"], dim=-1)

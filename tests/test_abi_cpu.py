@@ -287,3 +287,29 @@ def test_gemm_plans_tuned_table_and_model(nv):
         nv.check(nv.lib.lidbox_gemm_plan_query(kind, M, N, K, 1 << 26, out))
         assert out[0] in (64, 128) and out[1] in (64, 128) and out[2] >= 1
         assert out[2] * out[3] >= (M if kind == 2 else K)
+
+
+def test_early_stopping_follows_keras_patience_semantics():
+    """tf.keras.callbacks.EarlyStopping: stop once `patience` consecutive epochs brought no improvement (wait >= patience)"""
+    from lidbox_amd.models.keras_utils import EarlyStopping
+
+    class W:
+        stop_training = False
+
+    for patience, expect_epochs in ((0, 2), (1, 2), (2, 3), (3, 4)):
+        cb, w = EarlyStopping(monitor="val_loss", patience=patience), W()
+        n = 0
+        for epoch, v in enumerate([1.0, 1.0, 1.0, 1.0, 1.0, 1.0]):
+            cb.on_epoch_end(w, epoch, {"val_loss": v})
+            n += 1
+            if w.stop_training:
+                break
+        assert n == expect_epochs, (patience, n)
+    cb, w = EarlyStopping(monitor="acc", patience=2, mode="max", min_delta=0.1), W()
+    for epoch, v in enumerate([0.5, 0.55, 0.7, 0.75, 0.72]):       # +0.05 is below min_delta, +0.15 resets the wait
+        cb.on_epoch_end(w, epoch, {"acc": v})
+    assert w.stop_training and cb.best == 0.7
+    import pytest
+    with pytest.raises(ValueError):
+        EarlyStopping(restore_best_weights=True)
+    EarlyStopping(restore_best_weights=False, baseline=None, verbose=1)

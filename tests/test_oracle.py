@@ -454,3 +454,35 @@ def test_oracle_frequency_attention_matches_torch_autograd():
         assert np.abs(got - ref.numpy()).max() < 1e-12
     with pytest.raises(AssertionError):                     # clstm.py:32: channels must divide into the bins
         mo.freq_attention_fwd(H, W1, rng.standard_normal((5, 5)))
+
+
+def test_xvector_2d_oracle_numpy_equals_torch_and_batchnorm_properties():
+    """8f.1: the numpy restatement of xvector_2d (Conv2D along frequency + BatchNormalization) against an independent torch
+    formulation (conv1d over the frequency axis of every frame), training and inference statistics; BatchNormalization
+    properties: normalised training output has zero mean / unit variance (up to epsilon) per channel, the running
+    statistics move by (1 - momentum)."""
+    import torch
+    from oracle import torch_ref as tr
+    rng = np.random.default_rng(21)
+    p = mo.xvector_2d_init(40, 5, seed=3, dtype=np.float64)
+    assert mo.xvector_2d_freq_dims(40) == [40, 36, 17, 5, 1] and p["frame1.W"].shape == (5, 32, 512)
+    assert p["frame2d_2_conv.W"].shape == (1, 3, 256, 128) and p["frame2d_4_bn.moving_variance"].shape == (32,)
+    for k in p:
+        if k.endswith("gamma"): p[k] = rng.uniform(0.5, 1.5, p[k].shape)
+        if k.endswith("beta") or k.endswith("_conv.b"): p[k] = rng.standard_normal(p[k].shape) * 0.1
+        if k.endswith("moving_mean"): p[k] = rng.uniform(0, 0.5, p[k].shape)
+    x = rng.standard_normal((2, 9, 40))
+    pt = tr.to_torch_params(p, False, torch.float64)
+    for training in (True, False):
+        out, stats = mo.xvector_2d_fwd(p, x, training=training)
+        ref = tr.xvector_2d_fwd(pt, torch.tensor(x), training=training).numpy()
+        assert out.shape == (2, 5) and np.abs(out - ref).max() < 1e-12
+        assert np.allclose(np.exp(out).sum(-1), 1.0)
+    a = np.maximum(rng.standard_normal((50, 7, 3)) * 2 + 1, 0)
+    g, b = np.ones(3), np.zeros(3)
+    y, mm, mv = mo.batchnorm_fwd(a, g, b, np.zeros(3), np.ones(3), True)
+    assert np.abs(y.mean(axis=(0, 1))).max() < 1e-12
+    assert np.abs(y.var(axis=(0, 1)) - a.var(axis=(0, 1)) / (a.var(axis=(0, 1)) + 1e-3)).max() < 1e-12
+    assert np.allclose(mm, 0.01 * a.mean(axis=(0, 1))) and np.allclose(mv, 0.99 + 0.01 * a.var(axis=(0, 1)))
+    y2, mm2, mv2 = mo.batchnorm_fwd(a, g, b, mm, mv, False)
+    assert mm2 is mm and np.allclose(y2, (a - mm) / np.sqrt(mv + 1e-3))

@@ -1,0 +1,154 @@
+"""
+GPU parity of BatchNormalization (csrc/batchnorm.hip) and the xvector_2d model (reference lidbox/models/xvector_2d.py)
+against the numpy oracle and torch autograd on the CPU restatement.  PARITY UNPINNED like every model row (no TensorFlow
+here): Keras BatchNormalization / Conv2D semantics are restated from their documented behaviour.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_np as mo
+from oracle import torch_ref as tr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype))).cuda()
+
+
+@pytest.mark.parametrize("R,C", [(1000, 64), (37, 5), (4097, 256), (1, 3), (20000, 32)])
+def test_batchnorm_kernels_forward_backward(R, C):
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(R + C)
+    st = nv.current_stream()
+    x = np.maximum(rng.standard_normal((R, C)) * rng.uniform(0.1, 3, C) + rng.uniform(-1, 5, C), 0)     # ReLU outputs
+    gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C)
+    mm0, mv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
+    xd, gd, bd = _dev(x), _dev(gamma), _dev(beta)
+    mm, mv = _dev(mm0), _dev(mv0)
+    consts = torch.zeros((4, C), device="cuda")
+    cp = [ctypes.c_void_p(consts.data_ptr() + 4 * j * C) for j in range(4)]
+    wsb = int(nv.lib.lidbox_bn_workspace(R, C))
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    nv.check(nv.lib.lidbox_bn_train_stats(nv.ptr(xd), R, C, nv.ptr(gd), nv.ptr(bd), 1e-3, 0.99, nv.ptr(mm), nv.ptr(mv),
+                                          cp[0], cp[1], cp[2], cp[3], nv.ptr(ws), wsb, st))
+    x32 = x.astype(np.float32).astype(np.float64)
+    ref_y, ref_mm, ref_mv = mo.batchnorm_fwd(x32, gamma, beta, mm0, mv0, True)
+    mean, var = x32.mean(0), x32.var(0)
+    assert np.abs(consts[0].cpu().numpy() - mean).max() <= 1e-6 * max(1.0, np.abs(mean).max())
+    assert np.abs(consts[1].cpu().numpy() - 1 / np.sqrt(var + 1e-3)).max() <= 2e-6 * (1 / np.sqrt(var + 1e-3)).max()
+    assert np.abs(mm.cpu().numpy() - ref_mm).max() < 1e-6 and np.abs(mv.cpu().numpy() - ref_mv).max() < 1e-5
+    # apply: dense and through a strided rows descriptor (rows of 2 land in a padded [R/2.., 3 + 2, C] buffer)
+    y = torch.zeros((R, C), device="cuda")
+    nv.check(nv.lib.lidbox_bn_apply(nv.ptr(xd), R, C, cp[2], cp[3], nv.Rows(y.data_ptr(), 0, C, 1, R), st))
+    assert np.abs(y.cpu().numpy() - ref_y).max() <= 2e-5 * max(1.0, np.abs(ref_y).max())
+    if R % 2 == 0:
+        padded = torch.zeros((R // 2, 5, C), device="cuda")
+        nv.check(nv.lib.lidbox_bn_apply(nv.ptr(xd), R, C, cp[2], cp[3], nv.Rows(padded.data_ptr() + 4 * 3 * C, 5 * C, C, R // 2, 2), st))
+        assert torch.equal(padded[:, 3:].reshape(R, C), y) and not bool(padded[:, :3].any())
+    # inference constants
+    nv.check(nv.lib.lidbox_bn_infer_consts(nv.ptr(gd), nv.ptr(bd), nv.ptr(mm), nv.ptr(mv), 1e-3, C, cp[2], cp[3], st))
+    nv.check(nv.lib.lidbox_bn_apply(nv.ptr(xd), R, C, cp[2], cp[3], nv.Rows(y.data_ptr(), 0, C, 1, R), st))
+    ref_inf, _, _ = mo.batchnorm_fwd(x32, gamma, beta, mm.cpu().numpy().astype(np.float64), mv.cpu().numpy().astype(np.float64), False)
+    assert np.abs(y.cpu().numpy() - ref_inf).max() <= 2e-5 * max(1.0, np.abs(ref_inf).max())
+    # backward vs torch autograd (float64) of gamma * (relu(z) - mean) / sqrt(var + eps) + beta at z = x (x > 0 where it counts)
+    dy = rng.standard_normal((R, C))
+    zt = torch.tensor(x32, requires_grad=True)
+    gt, bt = torch.tensor(gamma, requires_grad=True), torch.tensor(beta, requires_grad=True)
+    at = torch.relu(zt)
+    yt = gt * (at - at.mean(0)) / torch.sqrt(at.var(0, unbiased=False) + 1e-3) + bt
+    (yt * torch.tensor(dy)).sum().backward()
+    dgam, dbet, dx = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros((R, C), device="cuda")
+    dyd = _dev(dy)
+    nv.check(nv.lib.lidbox_bn_bwd(nv.ptr(xd), nv.Rows(dyd.data_ptr(), 0, C, 1, R), R, C, cp[0], cp[1], nv.ptr(gd), 1,
+                                  nv.ptr(dgam), nv.ptr(dbet), nv.ptr(dx), nv.ptr(ws), wsb, st))
+    for got, ref in ((dgam, gt.grad), (dbet, bt.grad), (dx, zt.grad)):
+        ref = ref.numpy()
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max())
+
+
+def _oracle_params(model):
+    return {k: v.astype(np.float64) for k, v in model.get_weights().items()}
+
+
+def test_xvector_2d_layout_forward_and_moving_statistics():
+    from lidbox_amd.models import xvector_2d
+    m = xvector_2d.create((30, 40), 4, seed=2)
+    ref_p = mo.xvector_2d_init(40, 4, seed=0)
+    assert {k: v.shape for k, v in m.get_weights().items()} == {k: v.shape for k, v in ref_p.items()}
+    assert m.count_params() == sum(v.size for v in ref_p.values()) and m.input_dim == 32 and m.model_input_dim == 40
+    rng = np.random.default_rng(3)
+    w = m.get_weights()
+    for k in w:                                           # non-trivial BatchNorm parameters and running statistics
+        if k.endswith("gamma"): w[k] = rng.uniform(0.5, 1.5, w[k].shape)
+        if k.endswith("beta") or k.endswith("_conv.b"): w[k] = rng.standard_normal(w[k].shape) * 0.1
+        if k.endswith("moving_mean"): w[k] = rng.uniform(0, 0.5, w[k].shape)
+        if k.endswith("moving_variance"): w[k] = rng.uniform(0.5, 1.5, w[k].shape)
+    m.set_weights(w)
+    p = _oracle_params(m)
+    x = rng.standard_normal((3, 30, 40))
+    # inference: running statistics, nothing moves
+    ref, _ = mo.xvector_2d_fwd(p, x, training=False)
+    got = m(_dev(x), training=False).cpu().numpy()
+    assert got.shape == (3, 4) and np.abs(got - ref).max() < 1e-3
+    assert all(np.array_equal(m.get_weights()[k], w[k].astype(np.float32)) for k in w if "moving" in k)
+    # training: batch statistics, running statistics move by (1 - 0.99) towards them
+    ref, new_stats = mo.xvector_2d_fwd(p, x, training=True)
+    got = m(_dev(x), training=True).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-3
+    after = m.get_weights()
+    for k, v in new_stats.items():
+        assert np.abs(after[k] - v).max() <= 1e-5 * max(1.0, np.abs(v).max()), k
+        assert not np.array_equal(after[k], w[k].astype(np.float32))
+    # embedding extractor: segment1's affine output with the running statistics
+    emb = xvector_2d.as_embedding_extractor(m)(_dev(x)).cpu().numpy()
+    ref_emb, _ = mo.xvector_2d_fwd(_oracle_params(m), x, training=False, embedding=True)
+    cos = (emb * ref_emb).sum(-1) / (np.linalg.norm(emb, axis=-1) * np.linalg.norm(ref_emb, axis=-1))
+    assert emb.shape == (3, 512) and cos.min() >= 0.9999
+    with pytest.raises(ValueError):
+        xvector_2d.create((30, 12), 4)                   # 12 channels do not survive the four valid convolutions
+
+
+@pytest.mark.parametrize("F", [40, 64])
+def test_xvector_2d_gradients_match_autograd_and_training_learns(F):
+    """F = 64 leaves cols = 3 positions of 32 channels after the front-end (flatten_channels, dgrad into strided rows)"""
+    from lidbox_amd.models import xvector_2d
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(5)
+    B, T = 4, 21
+    m = xvector_2d.create((T, F), 3, seed=7)
+    assert m.fe_dims[-1] == (1 if F == 40 else 3)
+    w = m.get_weights()
+    for k in w:
+        if k.endswith("gamma"): w[k] = rng.uniform(0.5, 1.5, w[k].shape)
+        if k.endswith("beta") or k.endswith(".b"): w[k] = rng.standard_normal(w[k].shape) * 0.1
+    m.set_weights(w)
+    x = rng.standard_normal((B, T, F))
+    y = rng.integers(0, 3, size=B).astype(np.int32)
+    p = _oracle_params(m)
+    pt = tr.to_torch_params({k: v for k, v in p.items()}, True, torch.float64)
+    loss_ref = tr.sparse_ce_from_logits(tr.xvector_2d_fwd(pt, torch.tensor(x), training=True), torch.tensor(y.astype(np.int64)))
+    loss_ref.backward()
+    t = Trainer(m, use_graph=False)
+    before = {k: v.copy() for k, v in m.get_weights().items() if "moving" in k}
+    loss, _ = t.loss_and_grads(_dev(x), _dev(y, np.int32))
+    assert abs(float(loss) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
+    for k in m.layout:
+        ref_g = pt[k].grad.numpy()
+        got_g = m.param(k, grad=True).cpu().numpy()
+        assert np.abs(got_g - ref_g).max() <= 2e-3 * max(1e-12, np.abs(ref_g).max()), k
+    # the captured step: running statistics move once per step (not in the warm-up pass), the loss goes down
+    m2 = xvector_2d.create((T, F), 3, seed=7)
+    t2 = Trainer(m2, use_graph=True)
+    xd, yd = _dev(x), _dev(y, np.int32)
+    l0 = float(t2.train_step(xd, yd))
+    s1 = m2.get_weights()["frame2d_1_bn.moving_variance"].copy()
+    _, stats = mo.xvector_2d_fwd({k: v.astype(np.float64) for k, v in xvector_2d.create((T, F), 3, seed=7).get_weights().items()}, x, training=True)
+    assert np.abs(s1 - stats["frame2d_1_bn.moving_variance"]).max() < 1e-5          # exactly one update after one step
+    for _ in range(10):
+        l1 = float(t2.train_step(xd, yd))
+    assert np.isfinite(l1) and l1 < l0
+    assert len(before) == 8
