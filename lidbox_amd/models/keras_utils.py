@@ -10,7 +10,9 @@ What differs from the reference, by necessity:
     replay); datasets are iterables of `(inputs [B,T,C], targets [B])` batches (what `as_supervised` + `batch` give);
   * optimizer: Adam (the train step's fused Keras-Adam kernel); loss: SparseCategoricalCrossentropy(from_logits=True)
     or `lidbox.losses.SparseAngularProximity`; metrics: (Sparse)AverageDetectionCost, SparseCategoricalAccuracy;
-  * checkpoints are `.npz` files of Keras-layout arrays (`get_weights()`), not HDF5 (no h5py in this build);
+  * checkpoints WRITTEN here are `.npz` files of Keras-layout arrays (`get_weights()`); the reference's own Keras HDF5
+    checkpoints (`epoch...hdf5`, keras_utils.py:57-64) are READ through `hdf5_reader` (no h5py in this build), so
+    `load_weights` and the embedding-extractor configs accept a checkpoint directory the reference produced;
   * callbacks: ModelCheckpoint, EarlyStopping, LearningRateDateLogger; TensorBoard is accepted and ignored.
 """
 import datetime
@@ -29,6 +31,29 @@ from ..train import Trainer
 
 MODELS_IMPORT_PATH = "lidbox_amd.models."
 CHECKPOINT_SUFFIX = ".npz"
+KERAS_HDF5_SUFFIXES = (".hdf5", ".h5")          # what the reference's ModelCheckpoint / save_weights write
+
+
+def read_weights_file(path):
+    """{parameter name: numpy array in the Keras layout} from a checkpoint of this build (.npz) or a Keras HDF5 weight /
+    model file written by the reference (keras_utils.py:57-64: `epoch{epoch:06d}__val_loss{val_loss:.12f}.hdf5`)."""
+    if path.endswith(KERAS_HDF5_SUFFIXES):
+        from .hdf5_reader import load_keras_weights
+        return load_keras_weights(path)
+    return dict(np.load(path))
+
+
+def _set_weights_checked(model, weights, path):
+    """every parameter of the model must be in the file with the model's shape (Keras `load_weights` raises likewise)"""
+    want = dict(list(model.layout.items()) + list(getattr(model, "state_layout", {}).items()))
+    missing = sorted(set(want) - set(weights))
+    extra = sorted(set(weights) - set(want))
+    if missing or extra:
+        raise ValueError("%s does not match the model: missing %s, unexpected %s" % (path, missing[:6], extra[:6]))
+    for name, (_, shape) in want.items():
+        if tuple(np.shape(weights[name])) != tuple(shape):
+            raise ValueError("%s: %s has shape %s, the model expects %s" % (path, name, np.shape(weights[name]), tuple(shape)))
+    model.set_weights(weights)
 
 
 def experiment_cache_from_config(config):
@@ -51,7 +76,10 @@ def best_model_checkpoint_from_config(config):
 
 def parse_checkpoint_value(checkpoint_path, key):
     """reference keras_utils.py:41-42 (with this build's checkpoint suffix)"""
-    return checkpoint_path.split(key)[-1].split("__")[0].split(CHECKPOINT_SUFFIX)[0]
+    value = checkpoint_path.split(key)[-1].split("__")[0]
+    for suffix in (CHECKPOINT_SUFFIX,) + KERAS_HDF5_SUFFIXES:
+        value = value.split(suffix)[0]
+    return value
 
 
 class SparseCategoricalAccuracy:
@@ -199,7 +227,8 @@ class KerasWrapper:
         """reference keras_utils.py:103-121"""
         if key is None:
             key = "epoch"
-        checkpoints = [p.path for p in os.scandir(checkpoints_dir) if p.is_file() and p.name.endswith(CHECKPOINT_SUFFIX)]
+        checkpoints = [p.path for p in os.scandir(checkpoints_dir)
+                       if p.is_file() and p.name.endswith((CHECKPOINT_SUFFIX,) + KERAS_HDF5_SUFFIXES)]
         key_fn = lambda p: parse_checkpoint_value(p, key)       # noqa: E731
         best_path = None
         if checkpoints:
@@ -245,7 +274,7 @@ class KerasWrapper:
                                             key=config["best_checkpoint"]["monitor"], mode=config["best_checkpoint"]["mode"])
         if path is None:
             raise FileNotFoundError("no checkpoint under %s" % os.path.join(experiment_cache, "checkpoints"))
-        model.set_weights(dict(np.load(path)))
+        _set_weights_checked(model, read_weights_file(path), path)
         return getattr(model_module, "as_embedding_extractor")(model)
 
     def __init__(self, keras_model, model_key, callbacks, loss="sparse_categorical_crossentropy", optimizer=None,
@@ -270,7 +299,7 @@ class KerasWrapper:
     def load_weights(self, path):
         """reference keras_utils.py:186-188"""
         self.initial_epoch = int(parse_checkpoint_value(path, key="epoch"))
-        self.keras_model.set_weights(dict(np.load(path)))
+        _set_weights_checked(self.keras_model, read_weights_file(path), path)
 
     # ------------------------------------------------------------------ fit / evaluate
     def _stage(self, x, y):
