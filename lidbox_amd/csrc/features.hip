@@ -844,6 +844,56 @@ __global__ __launch_bounds__(256) void generic_spectrogram_kernel(
     }
 }
 
+// Power-of-two fft_length other than the fused kernel's 512: one workgroup per frame, the real FFT as an H = nfft/2 point
+// complex FFT of the packed samples (radix-2 Stockham autosort between two LDS buffers, log2(H) passes of H/2
+// butterflies, twiddles from the plan's table e^{-2 pi i j / nfft}), then the conjugate-pair untangling and |.|^power.
+// O(N log N) per frame against the direct kernel's O(N^2 / 2); LDS = 2 * H * 8 bytes (128 KB at fft_length 16384).
+__global__ __launch_bounds__(256) void pow2_fft_spectrogram_kernel(
+    const float* __restrict__ signals, long sig_stride, int T, int L, int S, int nfft, int F,
+    const float* __restrict__ win, const float2* __restrict__ tw, float power, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = nfft >> 1;
+    float2* buf0 = reinterpret_cast<float2*>(smem);
+    float2* buf1 = buf0 + H;
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int Leff = L < nfft ? L : nfft;
+    const float* src = signals + (long)b * sig_stride + (long)t * S;
+    for (int n = tid; n < H; n += 256) {
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        buf0[n] = make_float2(i0 < Leff ? src[i0] * win[i0] : 0.f, i1 < Leff ? src[i1] * win[i1] : 0.f);
+    }
+    __syncthreads();
+    float2* in = buf0;
+    float2* outb = buf1;
+    const int half = H >> 1;
+    for (int Ns = 1; Ns < H; Ns <<= 1) {
+        const int tw_step = nfft / (2 * Ns);                 // e^{-2 pi i k / (2 Ns)} = tw[k * nfft / (2 Ns)]
+        for (int j = tid; j < half; j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 w = tw[k * tw_step];
+            const float2 u0 = in[j], v = in[j + half];
+            const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            const int j0 = ((j - k) << 1) + k;
+            outb[j0] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            outb[j0 + Ns] = make_float2(u0.x - u1.x, u0.y - u1.y);
+        }
+        __syncthreads();
+        float2* tmp = in; in = outb; outb = tmp;
+    }
+    // untangle: X[k] = (Z[k] + conj(Z[H-k])) / 2 - i w_k (Z[k] - conj(Z[H-k])) / 2, w_k = e^{-2 pi i k / nfft}, Z[H] = Z[0]
+    float* dst = out + ((long)b * T + t) * F;
+    for (int k = tid; k <= H; k += 256) {
+        const float2 zk = in[k == H ? 0 : k];
+        const float2 zm = in[k == 0 ? 0 : H - k];
+        const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+        const float orr = 0.5f * (zk.y + zm.y), oi = 0.5f * (zm.x - zk.x);
+        const float2 w = (k == H) ? make_float2(-1.f, 0.f) : tw[k];
+        const float xr = er + (w.x * orr - w.y * oi), xi = ei + (w.x * oi + w.y * orr);
+        const float p2 = xr * xr + xi * xi;
+        dst[k] = (power == 2.0f) ? p2 : powf(p2, 0.5f * power);
+    }
+}
+
 // thread per (frame, band): banded mel (+ optional log)
 __global__ void generic_mel_kernel(const float* __restrict__ spec, long nframes, int F, int M,
                                    const int* __restrict__ ms, const int* __restrict__ mc,
@@ -981,9 +1031,20 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
     const long nframes = (long)B * T;
     float* spec = (kind == LIDBOX_FEAT_SPECTROGRAM) ? out : (float*)workspace;
     const int Leff = p->L < p->nfft ? p->L : p->nfft;
-    hipLaunchKernelGGL(generic_spectrogram_kernel, dim3(T, B), dim3(256), (size_t)Leff * 4, st,
-                       signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN,
-                       p->power, spec);
+    const bool pow2 = p->nfft >= 4 && (p->nfft & (p->nfft - 1)) == 0;
+    static const bool force_dft = getenv("LIDBOX_FEAT_FORCE_DFT") != nullptr;          // A/B and test aid
+    if (pow2 && !force_dft) {
+        // LDS: two buffers of nfft / 2 complex values (<= 128 KB at the largest fft_length a plan accepts)
+        const size_t lds = (size_t)p->nfft * 8;
+        if (lds > 65536)
+            LBX_HIP(hipFuncSetAttribute((const void*)pow2_fft_spectrogram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pow2_fft_spectrogram_kernel, dim3(T, B), dim3(256), lds, st,
+                           signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN, p->power, spec);
+    } else {
+        hipLaunchKernelGGL(generic_spectrogram_kernel, dim3(T, B), dim3(256), (size_t)Leff * 4, st,
+                           signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN,
+                           p->power, spec);
+    }
     LBX_LAUNCH_OK();
     if (kind == LIDBOX_FEAT_SPECTROGRAM) return LIDBOX_OK;
     float* mel = (kind == LIDBOX_FEAT_MFCC) ? (float*)workspace + nframes * p->F : out;

@@ -159,3 +159,49 @@ def test_bench_line_contract_single_process():
     ff = r["roofline_feature"]
     assert ff["bound"] == "hbm" and ff["bytes_per_launch"] == 256 * 159680 and 0 < ff["frac"] < 1
     assert abs(r["value"] - 256 * 1e3 / r["ms_per_step"]) <= 1e-3 * r["value"]
+
+
+def test_uneven_shards_equal_the_global_batch_step(tmp_path):
+    """13 utterances over two ranks (7 + 6): every rank scales its loss gradient by 1 / GLOBAL batch (Trainer._loss_scale),
+    so the all-reduced sum is the single-process gradient (mean of per-rank means over-weights the small shard)"""
+    script = tmp_path / "worker13.py"
+    script.write_text((_WORKER % {"root": ROOT}).replace("B = 12", "B = 13"))
+    single = _run(script, 1, True, tmp_path / "single.npz", 2)
+    dual = _run(script, 2, True, tmp_path / "dual.npz", 2)
+    diff = np.abs(single["flat"] - dual["flat"])
+    assert np.median(diff) <= 1e-6 and (diff > 2e-4).mean() <= 1e-3 and diff.max() <= 3 * 2e-3 + 1e-6
+    assert np.array_equal(single["tp"] + single["fn"], dual["tp"] + dual["fn"])
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the box (RCCL refuses two ranks on one device)")
+
+
+@needs_two_gpus
+def test_two_rccl_ranks_on_two_gpus_bench_line():
+    """lights up on a multi-GPU box: `python bench.py --gpus 2` with NO launcher re-executes itself under
+    torch.distributed.run, two ranks all-reduce over RCCL / xGMI between the hipGraph segments, one JSON line comes back"""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "64",
+           "--no-cpu-baseline", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 128 and r["config"]["parallelism"] == "dp2" and r["value"] > 0
+
+
+@needs_two_gpus
+def test_two_rccl_ranks_step_equals_single_process_step(tmp_path):
+    """the equivalence test above with the real backend: one rank per GPU, RCCL all-reduce"""
+    script = tmp_path / "worker_rccl.py"
+    script.write_text((_WORKER % {"root": ROOT})
+                      .replace('os.environ["LOCAL_RANK"] = "0"', 'os.environ["LOCAL_RANK"] = os.environ["RANK"]')
+                      .replace('init_distributed(backend="gloo")', 'init_distributed(backend="nccl")')
+                      .replace("torch.cuda.set_device(0)", "torch.cuda.set_device(rank)"))
+    single = _run(script, 1, True, tmp_path / "single.npz", 3)
+    dual = _run(script, 2, True, tmp_path / "dual.npz", 3)
+    assert np.allclose(single["losses"], dual["losses"], rtol=1e-5, atol=1e-6)
+    diff = np.abs(single["flat"] - dual["flat"])
+    assert np.median(diff) <= 1e-6 and diff.max() <= 3 * 2e-3 + 1e-6
