@@ -76,7 +76,7 @@ class KernelTimer:
     i.e. by the names rocprofv3 --stats reports."""
 
     ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_extract_features_fwd": -1,
-             "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12}
+             "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13}
 
     def __init__(self, nv):
         self.nv = nv
@@ -88,6 +88,9 @@ class KernelTimer:
         kind = self.ENTRY[name]
         if kind < 0:
             return "fused_feat512_kernel", float(args[3]) * BYTES_PER_UTT_FEATURE
+        if kind == 13:                                        # bf16-storage kernel: (A16, B16, ldb, C, C16, K, N, ...)
+            A, K, N = args[0], args[5], args[6]
+            return "gemm16s_rows_kernel", 2.0 * A.batch * A.rows_per_batch * K * N
         A, K, N = args[0], args[4], args[5]
         M = A.batch * A.rows_per_batch
         if kind >= 10:                                        # bf16 family: one tile shape per entry point

@@ -222,6 +222,22 @@ int lidbox_gemm_bf16_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, i
                         int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                         lidbox_stream_t stream);
 
+/* ---- bf16-STORAGE variant (operands already bfloat16 in HBM) ------------------------------------
+ * C[M,N] = epi( A16[M,K] . B16^T ): A16 = implicit rows of a bf16 buffer (A16.base points at bfloat16 data, strides in
+ * bf16 ELEMENTS -- the bf16 "shadow" of an activation / gradient buffer, same element layout as the fp32 one), B16 =
+ * [N,K] bf16 row-major (ldb in elements): a weight shadow (dgrad reads the Keras kernel [k*C_in, C_out] as is, forward
+ * reads its transpose [C_out, k*C_in]).  C (fp32), epilogues, split decompositions and determinism as
+ * lidbox_gemm_bf16_nt; C16 (may be NULL) receives the bf16 shadow of every finished C value at C's element offsets.
+ * Numerically identical to lidbox_gemm_bf16_nn/_nt on the fp32 originals (rounding happens where the shadow is
+ * written instead of where it is read).  Needs 16-byte aligned bases and K, ldb, row / batch strides % 8 == 0. */
+int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16,
+                         int K, int N, int epilogue, const float* aux,
+                         void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+/* dst[i] = bf16(src[i]) (round-to-nearest-even), n elements; dst[c][r] = bf16(src[r][c]) for an R x C matrix */
+int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream);
+int lidbox_transpose_f32_to_bf16(const float* src, int R, int C, long ld_src, void* dst, long ld_dst,
+                                 lidbox_stream_t stream);
+
 /* out[n] (+)= sum_m rows[m, n]  -- bias gradient; deterministic two-stage reduction through
  * `workspace` (>= lidbox_colsum_workspace() bytes). */
 size_t lidbox_colsum_workspace(long M, int N);

@@ -108,6 +108,9 @@ _SIGS = {
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),
+    "lidbox_gemm_bf16s_nt": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
+    "lidbox_transpose_f32_to_bf16": (_i, [_vp, _i, _i, _l, _vp, _l, _vp]),
     "lidbox_scale": (_i, [_vp, _l, _f, _vp]),
     "lidbox_bn_workspace": (_sz, [_l, _i]),
     "lidbox_bn_train_stats": (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

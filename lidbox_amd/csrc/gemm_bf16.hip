@@ -394,6 +394,208 @@ __global__ __launch_bounds__(256, 2) void gemm16_tn_kernel(RowsD A, RowsD Bd, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16-STORAGE variant (lidbox_gemm_bf16s_nt): both operands already are bfloat16 in HBM with the contraction index
+// contiguous -- A = the bf16 shadow of an activation / gradient buffer (same [B, pad + T, C] element layout as the fp32
+// buffer, written by the producing GEMM's epilogue), B = a bf16 weight shadow [N][K].  Half the bytes of the fp32-source
+// kernels on the L2 -> LDS path (their bound), no convert / transpose work in staging: a thread moves two 16-byte pieces
+// (8 k each) per operand tile from global memory to LDS unchanged.  Same tile (128 x 128 x 32), LDS layout, MFMA loop,
+// split decompositions and epilogues as gemm16_rows_kernel; the epilogue can write the bf16 shadow of C as well.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef LBX16S_BK
+#define LBX16S_BK 64                        // K depth of one LDS tile of the storage kernel: 64 bf16 = one 128-byte line per row
+#endif
+constexpr int BKS = LBX16S_BK;
+constexpr int LDS_S = BKS + 8;              // LDS row stride in bf16 (80 or 144 bytes: conflict-free ds_read_b128 / ds_write_b128)
+constexpr int TILE_S = BT * LDS_S;
+constexpr int OCT = BKS / 8;                // 16-byte pieces per tile row (4 or 8 lanes cover one row)
+constexpr int RPP = 256 / OCT;              // tile rows per pass of the 256 threads
+constexpr int NPASS = BT / RPP;             // passes per operand tile (2 or 4)
+
+struct RowsH {
+    const __bf16* base;
+    long bs, rs;
+    int batch, rpb;
+};
+
+__device__ __forceinline__ long row_offset(const RowsH& r, unsigned m) {
+    if (r.batch == 1) return (long)m * r.rs;
+    const unsigned b = m / (unsigned)r.rpb;
+    return (long)b * r.bs + (long)(m - b * (unsigned)r.rpb) * r.rs;
+}
+
+struct TileS {
+    u32x4 v[NPASS];
+};
+
+// thread -> 16-byte piece (tid % OCT) of rows r0 + RPP * {0 .. NPASS-1}; with BKS = 64 the 8 lanes of a row fetch one whole
+// 128-byte line (a wave-load touches 8 lines; with 32-deep tiles it touched 16 half lines, which the L1/L2 path serves at
+// half the rate -- tools/micro/l2_rate.hip: 28 vs 52 B/clk/CU).  r0 permutes the low row bits so that the rows of an 8-lane
+// ds_write_b128 group land on different banks.
+struct KInner16S {
+    const __bf16* ptr[NPASS];
+    int ko, r0, k;
+
+    __device__ __forceinline__ void init(const RowsH& rows, long row_base, long nrows, int tid, int kbeg) {
+        ko = tid % OCT;
+        const int rs = tid / OCT;
+        r0 = OCT == 4 ? ((rs & ~7) | ((rs & 1) << 2) | ((rs >> 1) & 3)) : rs;
+        k = kbeg + 8 * ko;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const long r = row_base + r0 + RPP * p;
+            ptr[p] = rows.base + (r < nrows ? row_offset(rows, (unsigned)r) : 0) + k;     // outside rows: row 0 (never stored)
+        }
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void load(TileS& t, int kend) {
+        const bool in = !CHECK || k < kend;                     // K is a multiple of 8: an octet is inside or outside as a whole
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            t.v[p] = in ? *reinterpret_cast<const u32x4*>(ptr[p]) : z;
+            ptr[p] += BKS;
+        }
+        k += BKS;
+    }
+    __device__ __forceinline__ void store(__bf16* tile, const TileS& t) const {
+        __bf16* d = tile + r0 * LDS_S + 8 * ko;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) *reinterpret_cast<u32x4*>(d + p * RPP * LDS_S) = t.v[p];
+    }
+};
+
+// 64 x 64 per wave over one LDS tile pair of the storage kernel: BKS / 16 MFMAs per 32 x 32 block
+__device__ __forceinline__ void mma_tile16s(const __bf16* As, const __bf16* Bs, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+    const int h = lane >> 5, l = lane & 31;
+    const __bf16* ap = As + (wm * 64 + l) * LDS_S + 8 * h;
+    const __bf16* bp = Bs + (wn * 64 + l) * LDS_S + 8 * h;
+    constexpr int NKS = BKS / 16;
+    bf16x8 a[2][2], b[2][2];                                     // operand registers double-buffered over the k-slices
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[0][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDS_S);
+        b[0][i] = *reinterpret_cast<const bf16x8*>(bp + i * 32 * LDS_S);
+    }
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < NKS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[nxt][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDS_S + (ks + 1) * 16);
+                b[nxt][i] = *reinterpret_cast<const bf16x8*>(bp + i * 32 * LDS_S + (ks + 1) * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+#ifndef LBX16S_DEPTH
+#define LBX16S_DEPTH 2                      // operand tiles in flight per workgroup (register ring)
+#endif
+#ifndef LBX16S_WAVES
+#define LBX16S_WAVES (LBX16S_BK == 64 ? 2 : 3)   // waves per SIMD: 73 KB of LDS per workgroup at BKS = 64 (2 per CU), 40 KB at 32 (3)
+#endif
+__global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
+                                                              float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
+                                                              const float* __restrict__ aux, int tiles_n, unsigned ntiles,
+                                                              int k_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem16s[];      // 4 tiles: 40 KB (BKS 32) or 72 KB (BKS 64, above the static limit)
+    __bf16 (*As)[TILE_S] = reinterpret_cast<__bf16 (*)[TILE_S]>(smem16s);
+    __bf16 (*Bs)[TILE_S] = reinterpret_cast<__bf16 (*)[TILE_S]>(smem16s + 2 * TILE_S * sizeof(__bf16));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const int tn = chunk % tiles_n;
+    const long m0 = m_beg + (long)(chunk / tiles_n) * BT;
+    const int n0 = tn * BT;
+    const int split = blockIdx.y;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    KInner16S la, lb;
+    la.init(A, m0, M, tid, kbeg);
+    lb.init(Bw, n0, N, tid, kbeg);
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    // register ring of depth LBX16S_DEPTH: while tile kt is multiplied out of LDS, tiles kt+1 .. kt+DEPTH-1 sit in registers
+    // and the loads of tile kt+DEPTH are issued (16 VGPRs per tile in flight)
+    constexpr int D = LBX16S_DEPTH;
+    TileS ra[D], rb[D];
+    const int nk = (kend - kbeg + BKS - 1) / BKS;
+    auto fetch = [&](TileS& a, TileS& b, int t) {
+        if (t + 1 < nk) { la.load<false>(a, kend); lb.load<false>(b, kend); }
+        else { la.load<true>(a, kend); lb.load<true>(b, kend); }
+    };
+    if (nk > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nk) fetch(ra[d], rb[d], d);
+        la.store(As[0], ra[0]);
+        lb.store(Bs[0], rb[0]);
+    }
+    __syncthreads();
+    // step kt: LDS buffer kt & 1 holds tile kt; register slot (kt + 1) % D holds tile kt+1; tile kt+D goes into slot kt % D
+#define LBX16S_STEP(SLOT)                                                                     \
+    {                                                                                         \
+        constexpr int NXT = ((SLOT) + 1) % D;                                                 \
+        if (kt + D < nk) fetch(ra[SLOT], rb[SLOT], kt + D);                                   \
+        mma_tile16s(As[kt & 1], Bs[kt & 1], wm, wn, lane, acc);                                \
+        if (kt + 1 < nk) { la.store(As[(kt & 1) ^ 1], ra[NXT]); lb.store(Bs[(kt & 1) ^ 1], rb[NXT]); } \
+        __syncthreads();                                                                      \
+        ++kt;                                                                                 \
+    }
+    for (int kt = 0; kt < nk;) {
+        LBX16S_STEP(0)
+        if (D > 1 && kt < nk) LBX16S_STEP(1 % D)
+        if (D > 2 && kt < nk) LBX16S_STEP(2 % D)
+        if (D > 3 && kt < nk) LBX16S_STEP(3 % D)
+    }
+#undef LBX16S_STEP
+    store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16);
+}
+
+// elementwise fp32 -> bf16 (round-to-nearest-even), 4 values per thread when aligned
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        *reinterpret_cast<bf16x4*>(dst + 4 * i) = to_bf16(v);
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = __builtin_bit_cast(unsigned short, (__bf16)src[i]);
+}
+
+// dst[c][r] = bf16(src[r][c]): 32 x 32 tiles through LDS (coalesced on both sides)
+__global__ __launch_bounds__(256) void transpose_f32_to_bf16_kernel(const float* __restrict__ src, int R, int C, long ld_src,
+                                                                    unsigned short* __restrict__ dst, long ld_dst) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        t[j][tx] = (r < R && c < C) ? src[(long)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) dst[(long)c * ld_dst + r] = __builtin_bit_cast(unsigned short, (__bf16)t[tx][j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct Rows16Plan {
@@ -402,7 +604,7 @@ struct Rows16Plan {
 
 // One tile shape; small-M problems (Dense layers) are split along K until ~2 workgroups per CU (the resident
 // count: ~190 VGPRs with two tiles in flight) exist.
-Rows16Plan plan_rows16(long M, int N, int K, size_t ws_bytes) {
+Rows16Plan plan_rows16(long M, int N, int K, size_t ws_bytes, int BK = 32) {
     const long tiles = lbx_cdiv(M, BT) * lbx_cdiv(N, BT);
     Rows16Plan best{1, K};
     if (tiles >= 2 * NUM_CU) return best;
@@ -491,6 +693,96 @@ int launch_rows16(const char* fn, lidbox_rows_t A, const float* Bm, long ldb, li
     return launch_range(0, M, pl);
 }
 
+int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, lidbox_rows_out_t Cd, void* C16, int K, int N,
+                   int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
+    const long M = (long)A.batch * A.rows_per_batch;
+    if (M == 0 || N == 0) return LIDBOX_OK;
+    const lidbox_rows_t Cin{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    const bool a_ok = aligned16(A.base) && A.row_stride % 8 == 0 && (A.batch == 1 || A.batch_stride % 8 == 0);
+    if (!(a_ok && rows_aligned(Cin) && K % 8 == 0 && aligned16(B16) && ldb % 8 == 0 && aligned16(ws) &&
+          (C16 == nullptr || (((uintptr_t)C16) & 1) == 0))) {
+        lidbox_set_error("%s: invalid argument: bf16-storage operands need 16-byte aligned bases and K, ldb, row and batch "
+                         "strides (in bf16 elements) that are multiples of 8", fn);
+        return LIDBOX_E_INVALID;
+    }
+    const Rows16Plan pl = plan_rows16(M, N, K, ws ? ws_bytes : 0, BKS);
+    const size_t lds_bytes = 4 * (size_t)TILE_S * sizeof(__bf16);
+    static bool lds_attr_set = false;
+    if (lds_bytes > 65536 && !lds_attr_set) {
+        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        lds_attr_set = true;
+    }
+    const int tiles_n = (int)lbx_cdiv(N, BT);
+    const RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    const RowsH Ah{(const __bf16*)A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch};
+    const RowsH Bh{(const __bf16*)B16, 0, ldb, 1, 0};
+    float* P = (float*)ws;
+    unsigned short* S = (unsigned short*)C16;
+    auto launch_range = [&](long m_beg, long m_end, const Rows16Plan& q) -> int {
+        const long msub = m_end - m_beg;
+        const long ntiles = lbx_cdiv(msub, BT) * tiles_n;
+        hipLaunchKernelGGL(gemm16s_rows_kernel, dim3((unsigned)ntiles, (unsigned)q.splits), dim3(256), lds_bytes, st, Ah, Bh, Co, S, P,
+                           m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, q.k_per_split);
+        LBX_LAUNCH_OK();
+        if (q.splits > 1) {
+            long g = lbx_cdiv(msub * N, 256);
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, q.splits, m_beg, msub,
+                               N, Co, epi, aux, S);
+            LBX_LAUNCH_OK();
+        }
+        return LIDBOX_OK;
+    };
+    static const bool no_tail_split = getenv("LIDBOX_GEMM16_NO_TAIL_SPLIT") != nullptr;
+    static const long slots_per_cu = getenv("LIDBOX_GEMM16S_SLOTS") ? atol(getenv("LIDBOX_GEMM16S_SLOTS")) : LBX16S_WAVES;   // tuning aid
+    const long slots = slots_per_cu * NUM_CU;
+    const long tiles = lbx_cdiv(M, BT) * tiles_n;
+    if (!no_tail_split && pl.splits == 1 && tiles > slots && K >= LBX16_TAIL_MIN_K) {
+        const long rounds = tiles / slots, rem_tiles = tiles - rounds * slots;
+        const long main_tiles_m = rounds * slots / tiles_n;
+        const long m_main = main_tiles_m * BT, m_rem = M - m_main;
+        if (rounds >= LBX16_TAIL_MIN_ROUNDS && rem_tiles > 0 && rem_tiles <= slots / 4 && main_tiles_m >= 1 && m_rem > 0) {
+            const Rows16Plan rp = plan_rows16(m_rem, N, K, ws ? ws_bytes : 0, BKS);
+            if (rp.splits > 1) {
+                if (int rc = launch_range(0, m_main, pl)) return rc;
+                return launch_range(m_main, M, rp);
+            }
+        }
+    }
+    return launch_range(0, M, pl);
+}
+
+}  // namespace
+
+extern "C" int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16, int K,
+                                    int N, int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                                    lidbox_stream_t stream) {
+    if (validate_rows_call(__func__, A16, (const float*)B16, ldb, C, K, N, epilogue, aux, K)) return LIDBOX_E_INVALID;
+    return launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream) {
+    LBX_ARG(src && dst && n >= 0, "src, dst != NULL");
+    LBX_ARG(aligned16(src) && (((uintptr_t)dst) & 7) == 0, "src 16-byte, dst 8-byte aligned");
+    if (n == 0) return LIDBOX_OK;
+    long g = lbx_cdiv(n / 4 + 1, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_transpose_f32_to_bf16(const float* src, int R, int C, long ld_src, void* dst, long ld_dst,
+                                            lidbox_stream_t stream) {
+    LBX_ARG(src && dst && R >= 0 && C >= 0 && ld_src >= C && ld_dst >= R, "src, dst != NULL; leading dimensions cover the rows");
+    if (R == 0 || C == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3((unsigned)lbx_cdiv(C, 32), (unsigned)lbx_cdiv(R, 32)), dim3(256), 0,
+                       (hipStream_t)stream, src, R, C, ld_src, (unsigned short*)dst, ld_dst);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t lidbox_gemm_bf16_rows_workspace(long M, int N, int K) {

@@ -64,7 +64,10 @@ template <int MI, int NJ>
 __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], long m0, int n0, int wm, int wn, int lane,
                                                 long m_beg, long M, int N, int epi, const float* __restrict__ aux,
                                                 const RowsOutD& Cd, float* __restrict__ P, int split,
-                                                unsigned long long mask_bits = 0ull, bool have_mask_bits = false) {
+                                                unsigned long long mask_bits = 0ull, bool have_mask_bits = false,
+                                                unsigned short* __restrict__ shadow = nullptr) {
+    // shadow (bf16-storage GEMMs, gemm_bf16.hip): a bfloat16 copy of every finished value at the same element offset as C
+    // (round-to-nearest-even) -- the operand the next GEMM reads; never written for split-K partial sums.
     // Epilogue kind as four uniform flags (no per-element switch); bias and column state hoisted.
     const int h = lane >> 5, l = lane & 31;
     const bool partial = gridDim.y > 1;
@@ -112,6 +115,7 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
                     float x = acc[bi][bj][r] + bias[bj];
                     if (do_relu) x = fmaxf(x, 0.f);
                     out_base[off + col[bj]] = x;
+                    if (shadow && !partial) shadow[off + col[bj]] = __builtin_bit_cast(unsigned short, (__bf16)x);
                 }
             }
         }
@@ -168,7 +172,10 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int dr = ((r0 + i) & 3) + 8 * ((r0 + i) >> 2);
-                    if (rbase + dr < M && colok[bj]) out_base[row_off(dr) + c] = v[i];
+                    if (rbase + dr < M && colok[bj]) {
+                        out_base[row_off(dr) + c] = v[i];
+                        if (shadow) shadow[row_off(dr) + c] = __builtin_bit_cast(unsigned short, (__bf16)v[i]);
+                    }
                 }
             }
         }
@@ -180,7 +187,7 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
 
 // C rows [m_beg, m_beg + Msub) = epi( sum_s P[s][Msub][N] ), fixed order
 __global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long m_beg, long Msub, int N, RowsOutD Cd,
-                                   int epi, const float* __restrict__ aux) {
+                                   int epi, const float* __restrict__ aux, unsigned short* __restrict__ shadow = nullptr) {
     const long total = Msub * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -190,7 +197,9 @@ __global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long
         const long off = row_offset(Cd, (unsigned)(m_beg + row));
         const float bias = (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU) ? aux[col] : 0.f;
         float* dst = Cd.base + off + col;
-        *dst = apply_epi(s, epi, bias, aux, off + col, dst);
+        const float x = apply_epi(s, epi, bias, aux, off + col, dst);
+        *dst = x;
+        if (shadow) shadow[off + col] = __builtin_bit_cast(unsigned short, (__bf16)x);
     }
 }
 

@@ -133,6 +133,17 @@ class _Workspace:
         # activations (zero-initialised once: the pad rows stay zero forever)
         self.act = [torch.zeros((B, self.pads[i] + self.Ts[i], chans[i]), **f32) for i in range(len(chans))]
         self.dact = [None] + [torch.zeros_like(a) for a in self.act[1:]]
+        # bf16-storage GEMMs (compute_dtype "bfloat16"): bf16 shadows of the conv inputs (A of forward) and of the conv output
+        # gradients (A of dgrad), same element layout as the fp32 buffers; written by the producing GEMM's epilogue.
+        # A layer takes the shadow path when its operand strides / K are multiples of 8 bf16 elements.
+        self.act16 = [None] * len(self.act)
+        self.dact16 = [None] * len(self.act)
+        if model.bf16_storage:
+            for i, c in enumerate(convs):
+                if model.shadow_fwd_ok(i):
+                    self.act16[i] = torch.zeros(self.act[i].shape, dtype=torch.bfloat16, device=dev)
+                if i >= 1 and model.shadow_dgrad_ok(i):
+                    self.dact16[i + 1] = torch.zeros(self.act[i + 1].shape, dtype=torch.bfloat16, device=dev)
         fe = model.frontend
         if fe:
             # 2-D front-end (xvector_2d.py:69-73): model input [B, T, F]; layer i: a = relu(conv) [B*T*F_i+1, C_i+1] dense,
@@ -291,6 +302,21 @@ class SequentialTDNN:
                 self.state_layout[l.name + suffix] = (soff, (l.filters,)); soff = _align4(soff + l.filters)
         self.state = torch.zeros(max(soff, 4), dtype=torch.float32, device=self.device)
         self._init_weights(seed)
+        # bf16-storage GEMM path (LIDBOX_BF16_STORAGE=0 keeps the fp32-source bf16 kernels: A/B aid): bf16 weight shadows,
+        # refreshed from the fp32 master copy at the start of every forward pass -- `flat16` mirrors `flat` element for
+        # element (dgrad reads a Keras kernel [k*C_in, C_out] as the [N][K] operand it is), `w16t[i]` is conv i's kernel
+        # transposed to [C_out, k*C_in] (forward's [N][K] operand)
+        import os as _os
+        self.bf16_storage = self.compute_dtype == "bfloat16" and _os.environ.get("LIDBOX_BF16_STORAGE", "1") != "0" \
+            and attention is None and not self.frontend
+        if self.bf16_storage:
+            self.flat16 = torch.zeros(self.num_flat, dtype=torch.bfloat16, device=self.device)
+            cin = self.input_dim
+            self.w16t = []
+            for i, c in enumerate(self.convs):
+                self.w16t.append(torch.zeros((c.filters, c.k * cin), dtype=torch.bfloat16, device=self.device)
+                                 if self.shadow_fwd_ok(i) else None)
+                cin = c.filters
         self._ws = {}
         # optional second HIP stream: wgrad GEMMs run on it concurrently with the dgrad chain (they only
         # share read-only inputs), which fills the tail rounds and the nearly empty dense-layer launches
@@ -342,6 +368,38 @@ class SequentialTDNN:
     def set_weights(self, weights):
         for n, w in weights.items():
             self.param(n).copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device).reshape(self.param(n).shape))
+
+    def _cin(self, i):
+        return self.input_dim if i == 0 else self.convs[i - 1].filters
+
+    def shadow_fwd_ok(self, i):
+        """forward of conv i can read bf16 shadows: rows of k*C_in bf16 at strides that are multiples of 8 elements"""
+        c = self.convs[i]
+        return c.d == 1 and self._cin(i) % 8 == 0
+
+    def shadow_dgrad_ok(self, i):
+        """dgrad of conv i can read the bf16 shadow of its output gradient: C_out and C_in multiples of 8"""
+        c = self.convs[i]
+        return c.d == 1 and c.filters % 8 == 0 and self._cin(i) % 8 == 0
+
+    def _refresh_bf16_weights(self):
+        st = nv.current_stream()
+        nv.check(nv.lib.lidbox_f32_to_bf16(nv.ptr(self.flat), nv.ptr(self.flat16), self.num_flat, st))
+        for i, c in enumerate(self.convs):
+            if self.w16t[i] is not None:
+                K = c.k * self._cin(i)
+                nv.check(nv.lib.lidbox_transpose_f32_to_bf16(self._p(c.name + ".W"), K, c.filters, c.filters,
+                                                             nv.ptr(self.w16t[i]), K, st))
+
+    def _p16(self, name):
+        off, _ = self.layout[name]
+        return ctypes.c_void_p(self.flat16.data_ptr() + 2 * off)
+
+    @staticmethod
+    def _rows16(view_rows, t32, t16):
+        """the rows descriptor `view_rows` of fp32 tensor t32, re-based onto its bf16 shadow t16 (same element offsets)"""
+        off = (view_rows.base - t32.data_ptr()) // 4
+        return nv.Rows(t16.data_ptr() + 2 * off, view_rows.batch_stride, view_rows.row_stride, view_rows.batch, view_rows.rows_per_batch)
 
     def _sp(self, name):
         off, _ = self.state_layout[name]
@@ -475,14 +533,34 @@ class SequentialTDNN:
         lib = nv.lib
         if self.frontend:
             self._forward_frontend(ws, training, update_moving)
+        if self.bf16_storage:
+            self._refresh_bf16_weights()
+            if ws.act16[0] is not None:
+                nv.check(lib.lidbox_f32_to_bf16(nv.ptr(ws.act[0]), nv.ptr(ws.act16[0]), ws.act[0].numel(), st))
         cin = self.input_dim
+        fresh16 = False                                              # act16[i] holds bf16(act[i]) (written by conv i-1's epilogue)
         for i, c in enumerate(self.convs):
-            if ws.B * ws.Ts[i + 1] > 0 and c.d == 1:
+            if ws.B * ws.Ts[i + 1] > 0 and c.d == 1 and ws.act16[i] is not None:
+                # bf16-storage path: A = bf16 shadow of act[i], B = transposed bf16 kernel; the epilogue also writes the
+                # shadow of act[i+1] when the next conv reads it
+                if i > 0 and not fresh16:                            # the producer ran on the fp32-source path
+                    nv.check(lib.lidbox_f32_to_bf16(nv.ptr(ws.act[i]), nv.ptr(ws.act16[i]), ws.act[i].numel(), st))
+                fresh16 = ws.act16[i + 1] is not None
+                out_rows = self._rows_out(ws.act[i + 1], ws, i + 1)
+                nxt = ws.act16[i + 1]
+                sh = None if nxt is None else ctypes.c_void_p(nxt.data_ptr() + (out_rows.base - ws.act[i + 1].data_ptr()) // 2)
+                nv.check(lib.lidbox_gemm_bf16s_nt(self._rows16(self._conv_rows_in(ws, i), ws.act[i], ws.act16[i]),
+                                                  nv.ptr(self.w16t[i]), c.k * cin, out_rows, sh, c.k * cin, c.filters,
+                                                  nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
+                                                  nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
+            elif ws.B * ws.Ts[i + 1] > 0 and c.d == 1:
+                fresh16 = False
                 nv.check(self.gemm.nn(self._conv_rows_in(ws, i), self._p(c.name + ".W"), c.filters,
                                             self._rows_out(ws.act[i + 1], ws, i + 1), c.k * cin, c.filters,
                                             nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
                                             nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
             elif ws.B * ws.Ts[i + 1] > 0:
+                fresh16 = False
                 # dilated: tap j reads rows shifted by j*d; the first tap adds the bias, the last applies the ReLU
                 out = self._rows_out(ws.act[i + 1], ws, i + 1)
                 for j in range(c.k):
@@ -556,6 +634,7 @@ class SequentialTDNN:
         st = nv.current_stream()
         lib = nv.lib
         B = ws.B
+        ws.d16_fresh = set()                 # indices j whose dact16[j] holds bf16(dact[j]) (written by a dgrad epilogue)
         gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
         # ---- dense chain
         for j in range(len(self.denses) - 1, -1, -1):
@@ -640,6 +719,23 @@ class SequentialTDNN:
             nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), 4 * Tp * cin,
                                         4 * (Tp - To * c.s) * cin, B, st))
         ngroups = (c.k + c.s - 1) // c.s
+        # bf16-storage dgrad: A = bf16 shadow of dact[i+1] (written by conv i+1's dgrad epilogues, or converted here when
+        # it came from the pooling backward / a fp32-source launch), B = the Keras kernel rows of the tap group in flat16
+        use16 = self.bf16_storage and ws.dact16[i + 1] is not None and self.shadow_dgrad_ok(i)
+        d16 = ws.dact16[i] if use16 else None                   # shadow of this dgrad's output, for conv i-1's dgrad
+        if use16:
+            fresh = getattr(ws, "d16_fresh", set())
+            if (i + 1) not in fresh:
+                nv.check(lib.lidbox_f32_to_bf16(nv.ptr(ws.dact[i + 1]), nv.ptr(ws.dact16[i + 1]), ws.dact[i + 1].numel(), st))
+            if d16 is not None:
+                # rows no tap group writes must read as zero in the shadow too
+                if c.k < c.s:
+                    nv.check(lib.lidbox_zero_2d(nv.ptr(d16), 2 * d16.numel(), 2 * d16.numel(), 1, st))
+                elif To * c.s < Tp:
+                    nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(d16.data_ptr() + 2 * To * c.s * cin), 2 * Tp * cin,
+                                                2 * (Tp - To * c.s) * cin, B, st))
+                fresh.add(i)
+                ws.d16_fresh = fresh
         for g in range(ngroups):
             ntaps = min(c.s, c.k - g * c.s)
             base_off = 4 * g * c.s * cin                    # bytes
@@ -650,7 +746,13 @@ class SequentialTDNN:
                 epi = nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE
             else:
                 epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
-            nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+            if use16:
+                Wg16 = ctypes.c_void_p(self._p16(c.name + ".W").value + 2 * g * c.s * cin * c.filters)
+                sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + base_off // 2)
+                nv.check(lib.lidbox_gemm_bf16s_nt(self._rows16(dy, ws.dact[i + 1], ws.dact16[i + 1]), Wg16, c.filters, Cd, sh,
+                                                  c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+            else:
+                nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
         if i == 0:
             self._backward_frontend(ws)
 

@@ -136,3 +136,48 @@ def test_config5_bf16_train_step_tracks_fp32(use_graph):
     assert abs(lb[0] - ref) <= 2e-2 * abs(ref), (lb[0], ref)
     assert lb[-1] < lb[0]
     assert all(abs(a - b) <= 5e-2 * abs(b) for a, b in zip(lb, lf)), (lb, lf)
+
+
+def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
+    """the bf16-storage GEMMs (bf16 shadows of activations / gradients / weights, lidbox_gemm_bf16s_nt) compute what the
+    fp32-source bf16 kernels compute: rounding happens where a shadow is written instead of where an operand is read"""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    sig, y = synthetic_batch(16, num_labels=4, duration_s=1.0)
+    sd = torch.from_numpy(sig).cuda()
+    yd = torch.from_numpy(y.astype(np.int32)).cuda()
+    plan = audio.get_plan(16000, 400, 160)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LIDBOX_BF16_STORAGE", flag)
+        m = xvector.create((98, 40), 4, seed=0, compute_dtype="bfloat16")
+        assert m.bf16_storage == (flag == "1")
+        t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=(flag == "1"))
+        loss, g = t.loss_and_grads(sd, yd)
+        res[flag] = (float(loss), g.clone(), m)
+        if flag == "1":
+            ws = m.workspace(16, 98)
+            # the shadows are what they claim to be
+            for i in range(len(m.convs)):
+                if ws.act16[i] is not None:
+                    assert torch.equal(ws.act16[i], ws.act[i].bfloat16()), i
+            for j in range(len(ws.dact16)):
+                if ws.dact16[j] is not None and j in ws.d16_fresh | {len(m.convs) - 1}:
+                    assert torch.equal(ws.dact16[j], ws.dact[j].bfloat16()), j
+            assert sum(a is not None for a in ws.act16) == 5 and sum(a is not None for a in ws.dact16) == 3
+    # the two paths accumulate K in different chunk orders (64- vs 32-deep tiles), so an activation can land on the other
+    # side of a bf16 rounding boundary here and there: agreement far below one bf16 step (4e-3), not bit equality
+    assert abs(res["1"][0] - res["0"][0]) <= 1e-4 * abs(res["0"][0])
+    ga, gb = res["1"][1], res["0"][1]
+    assert float(torch.linalg.norm(ga - gb) / torch.linalg.norm(gb)) <= 1e-2          # vs 5e-2 allowed against the float64 oracle
+    # and the captured train step learns on the storage path
+    m = res["1"][2]
+    monkeypatch.setenv("LIDBOX_BF16_STORAGE", "1")
+    t = Trainer(xvector.create((98, 40), 4, seed=0, compute_dtype="bfloat16"), feature=dict(plan=plan, kind=nv.FEAT_LOGMEL))
+    l0 = float(t.train_step(sd, yd))
+    for _ in range(12):
+        l1 = float(t.train_step(sd, yd))
+    assert np.isfinite(l1) and l1 < l0

@@ -201,3 +201,79 @@ def test_bf16_gemm_tail_split_matches_single_launch(M, K, N):
     got = cb.cpu().numpy()
     _close(got[:, 3:, :].reshape(Bn * R, N), (_bf16(A[:Bn * R]) @ _bf16(Bt).T) * (mask[:Bn * R] > 0) + 7.0)
     assert np.all(got[:, :3, :] == 7.0)
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 32, 128), (200, 200, 512), (33, 1536, 512), (1000, 264, 40), (5, 8, 8),
+                                   (256, 3000, 512), (700, 512, 1024), (1, 8, 4), (50688 // 8, 200, 512)])
+def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N):
+    """lidbox_gemm_bf16s_nt: operands already bf16 in HBM ([M][K] and [N][K]); same numbers as the fp32-source kernel on the
+    unrounded originals; the bf16 shadow of C equals bf16(C); split-K, epilogues, converters"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M * 5 + K)
+    A, B, bias = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal(N)
+    ref = _bf16(A) @ _bf16(B).T
+    st = nv.current_stream()
+    a32, b32, bi = _dev(A), _dev(B), _dev(bias)
+    a16 = torch.empty((M, K), dtype=torch.bfloat16, device="cuda")
+    b16 = torch.empty((N, K), dtype=torch.bfloat16, device="cuda")
+    nv.check(nv.lib.lidbox_f32_to_bf16(nv.ptr(a32), nv.ptr(a16), M * K, st))
+    assert torch.equal(a16, a32.bfloat16())
+    # B through the transposing converter: from the [K][N] layout a forward weight has
+    bT = _dev(B.T)
+    nv.check(nv.lib.lidbox_transpose_f32_to_bf16(nv.ptr(bT), K, N, N, nv.ptr(b16), K, st))
+    assert torch.equal(b16, b32.bfloat16())
+    c = torch.full((M, N), 7.0, device="cuda")
+    c16 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+    ra = nv.Rows(a16.data_ptr(), 0, K, 1, M)
+    rc = _rows(c, 0, N, 1, M)
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, rc, nv.ptr(c16), K, N, nv.EPI_NONE, None, None, 0, st))
+    _close(c.cpu().numpy(), ref)
+    assert torch.equal(c16, c.bfloat16())
+    # the fp32-source kernel on the same data gives the same product (to summation order)
+    c_old = torch.zeros((M, N), device="cuda")
+    if K % 4 == 0:
+        nv.check(nv.lib.lidbox_gemm_bf16_nt(_rows(a32, 0, K, 1, M), nv.ptr(b32), K, _rows(c_old, 0, N, 1, M), K, N, nv.EPI_NONE,
+                                            None, None, 0, st))
+        _close(c.cpu().numpy(), c_old.cpu().double().numpy(), rel=1e-5)
+    # epilogues + split-K workspace; no shadow requested
+    wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(M, N, K))
+    ws = _ws(wsb)
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, rc, None, K, N, nv.EPI_BIAS_RELU, nv.ptr(bi), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), np.maximum(ref + np.float32(bias), 0))
+    mask = _dev(rng.standard_normal((M, N)))
+    c.fill_(1.0)
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, rc, nv.ptr(c16), K, N, nv.EPI_ACCUM_RELU_MASK, nv.ptr(mask), nv.ptr(ws), wsb, st))
+    want = 1.0 + ref * (mask.cpu().numpy() > 0)
+    _close(c.cpu().numpy(), want)
+    assert torch.equal(c16, c.bfloat16())
+
+
+def test_bf16_storage_gemm_implicit_rows_and_errors():
+    """strided causal windows over a bf16 shadow [B, pad + T, C] (Conv1D k = 3, stride 2) and the alignment rules"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(77)
+    Bn, T, C, k, s_, Co = 5, 21, 16, 3, 2, 24
+    pad = k - 1
+    x = np.zeros((Bn, pad + T, C))
+    x[:, pad:] = rng.standard_normal((Bn, T, C))
+    W = rng.standard_normal((k * C, Co))
+    To = (T - 1) // s_ + 1
+    idx = np.arange(To)[:, None] * s_ + np.arange(k)[None, :]
+    col = _bf16(x)[:, idx, :].reshape(Bn, To, k * C)
+    ref = col @ _bf16(W)
+    st = nv.current_stream()
+    x16 = _dev(x).bfloat16()
+    wT16 = _dev(W.T).bfloat16().contiguous()                 # [Co][k*C]
+    out = torch.zeros((Bn, To, Co), device="cuda")
+    out16 = torch.zeros((Bn, To, Co), dtype=torch.bfloat16, device="cuda")
+    ra = nv.Rows(x16.data_ptr(), (pad + T) * C, s_ * C, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(wT16), k * C, _rows(out, To * Co, Co, Bn, To), nv.ptr(out16), k * C, Co,
+                                         nv.EPI_NONE, None, None, 0, st))
+    _close(out.cpu().numpy(), ref)
+    assert torch.equal(out16, out.bfloat16())
+    with pytest.raises(ValueError):                          # K not a multiple of 8
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(wT16), k * C, _rows(out, To * Co, Co, Bn, To), None, k * C - 4, Co,
+                                             nv.EPI_NONE, None, None, 0, st))
+    with pytest.raises(ValueError):                          # row stride not a multiple of 8 elements
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(nv.Rows(x16.data_ptr(), (pad + T) * C, 12, Bn, To), nv.ptr(wT16), k * C,
+                                             _rows(out, To * Co, Co, Bn, To), None, k * C, Co, nv.EPI_NONE, None, None, 0, st))
