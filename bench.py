@@ -158,14 +158,14 @@ def source_hash():
     return h.hexdigest()
 
 
-def pmc_traffic(kernel_key):
+def pmc_traffic(kernel_key, bf16=False):
     """HBM bytes per launch of `kernel_key` from the newest committed PMC summary (profiles/*traffic*.json,
     produced by tools/traffic_from_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
     same command) -- bench.py cannot run rocprofv3 on itself.  Returns None unless the summary carries the hash of
     the kernel sources this process runs (a summary of older kernels is stale, not a measurement)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")) if f.endswith("_bf16.json") == bool(bf16))
     if not files:
         return None
     try:
@@ -355,7 +355,7 @@ def main():
             ach = d["rate"] / 1e12
             result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
                                   "peak": peak_mfma, "unit": "TFLOP/s",
-                                  "frac": round(ach / peak_mfma, 4), "traffic": pmc_traffic(dom),
+                                  "frac": round(ach / peak_mfma, 4), "traffic": pmc_traffic(dom, bf16),
                                   "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
                                   "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
                                   "note": "HIP-event brackets around the C-ABI calls that launch this instantiation, divided by "
@@ -375,7 +375,7 @@ def main():
                 gbs = f["rate"] / 1e9
                 result["roofline_feature"] = {"kernel": "fused_feat512_kernel", "bound": "hbm", "achieved": round(gbs, 1),
                                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                              "traffic": pmc_traffic("fused_feat512_kernel"), "avg_launch_us": round(f["avg_us"], 2),
+                                              "traffic": pmc_traffic("fused_feat512_kernel", bf16), "avg_launch_us": round(f["avg_us"], 2),
                                               "bytes_per_launch": int(f["work_per_launch"])}
         # whole-step view of the same roofline: algorithmic train flops / step time
         result["step_tflops"] = round(value / world * FLOPS_PER_UTT_TRAIN / 1e12, 2)
