@@ -152,3 +152,33 @@ def test_xvector_2d_gradients_match_autograd_and_training_learns(F):
         l1 = float(t2.train_step(xd, yd))
     assert np.isfinite(l1) and l1 < l0
     assert len(before) == 8
+
+
+def test_xvector_2d_train_step_from_waveforms_and_bf16_compute():
+    """the fused log-mel kernel writes straight into the 2-D front-end's input buffer; the bf16 GEMM family runs the
+    front-end's deeper layers and the TDNN (layer 1, K = 5 single-channel taps, always stays in the fp32 family)"""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector_2d
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    from oracle import features_np as fo
+    sig, y = synthetic_batch(6, num_labels=4, duration_s=0.5)
+    sd, yd = _dev(sig), _dev(y, np.int32)
+    plan = audio.get_plan(16000, 400, 160)
+    m = xvector_2d.create((48, 40), 4, seed=4)
+    t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=True)
+    feats = fo.extract_features(sig, [16000] * 6, "logmelspectrogram")
+    ref, _ = mo.xvector_2d_fwd(_oracle_params(m), feats, training=True)
+    ref_loss = mo.sparse_ce_from_logits(ref, y)
+    l0 = float(t.train_step(sd, yd))
+    assert abs(l0 - ref_loss) <= 2e-4 * abs(ref_loss), (l0, ref_loss)
+    assert np.abs(m.workspace(6, 48).input_view().cpu().numpy() - feats).max() < 1e-3
+    for _ in range(8):
+        l1 = float(t.train_step(sd, yd))
+    assert np.isfinite(l1) and l1 < l0
+    # bf16 compute: same model, operands rounded on chip; tracks the fp32 loss at bf16 accuracy
+    mb = xvector_2d.create((48, 40), 4, seed=4, compute_dtype="bfloat16")
+    assert not mb.bf16_storage                       # the shadow path is the plain TDNN's; the front-end model keeps fp32-source kernels
+    lb, _ = Trainer(mb, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=False).loss_and_grads(sd, yd)
+    assert abs(float(lb) - ref_loss) <= 3e-2 * abs(ref_loss)
