@@ -30,7 +30,7 @@ __device__ __forceinline__ long map_row(const RowMap& m, long r) {
 constexpr int BN_COLS = 64;       // columns per workgroup; 4 row groups of 64 threads
 
 // stage 1 of the column reductions.  MODE 0: s0 = sum x, s1 = sum x^2.  MODE 1: s0 = sum dy, s1 = sum dy * xhat with
-// xhat = (x - mean) * invstd.  partial [slices][2][C] doubles.
+// xhat = (x - mean) * invstd.  partial [2][C][slices] doubles (a channel's slices are contiguous: stage 2 reads them coalesced).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict__ x, const float* __restrict__ dy,
                                                         RowMap dmap, long R, int C, long rows_per_slice,
@@ -61,25 +61,48 @@ __global__ __launch_bounds__(256) void bn_reduce_stage1(const float* __restrict_
     red[1][threadIdx.x] = s1;
     __syncthreads();
     if (g == 0 && c < C) {
-        double* p = partial + (long)blockIdx.y * 2 * C;
-        p[c] = red[0][col] + red[0][col + 64] + red[0][col + 128] + red[0][col + 192];
-        p[C + c] = red[1][col] + red[1][col + 64] + red[1][col + 128] + red[1][col + 192];
+        const long slices = gridDim.y;
+        partial[(long)c * slices + blockIdx.y] = red[0][col] + red[0][col + 64] + red[0][col + 128] + red[0][col + 192];
+        partial[((long)C + c) * slices + blockIdx.y] = red[1][col] + red[1][col + 64] + red[1][col + 128] + red[1][col + 192];
     }
 }
 
-// stage 2 (training statistics): fixed-order sum of the slices -> batch mean, population variance, invstd, the
-// per-channel scale / shift of the apply kernel, and the moving-statistics update
-__global__ void bn_stats_stage2(const double* __restrict__ partial, int slices, long R, int C, const float* __restrict__ gamma,
+// Sum of one channel's slice partials by one workgroup of 256 threads: thread t adds slices t, t + 256, ... in order, then a
+// fixed-shape tree over the 256 thread sums -- the same association for every launch (deterministic), and the <= 1 024 slices of
+// a channel are read as one contiguous run instead of by a single thread (the first version's serial loop cost 230 us per call).
+__device__ __forceinline__ void bn_channel_sums(const double* __restrict__ partial, int slices, int C, int c, double& s0, double& s1) {
+    __shared__ double red[2][256];
+    const int t = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = t; k < slices; k += 256) {
+        a0 += partial[(long)c * slices + k];
+        a1 += partial[((long)C + c) * slices + k];
+    }
+    red[0][t] = a0;
+    red[1][t] = a1;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (t < h) {
+            red[0][t] += red[0][t + h];
+            red[1][t] += red[1][t + h];
+        }
+        __syncthreads();
+    }
+    s0 = red[0][0];
+    s1 = red[1][0];
+}
+
+// stage 2 (training statistics), one workgroup per channel: batch mean, population variance, invstd, the per-channel
+// scale / shift of the apply kernel, and the moving-statistics update
+__global__ __launch_bounds__(256) void bn_stats_stage2(const double* __restrict__ partial, int slices, long R, int C,
+                                const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, float momentum, float* __restrict__ moving_mean,
                                 float* __restrict__ moving_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                 float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < slices; ++k) {
-        s0 += partial[(long)k * 2 * C + c];
-        s1 += partial[(long)k * 2 * C + C + c];
-    }
+    const int c = blockIdx.x;
+    double s0, s1;
+    bn_channel_sums(partial, slices, C, c, s0, s1);
+    if (threadIdx.x != 0) return;
     const double mu = s0 / (double)R;
     double var = s1 / (double)R - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -128,18 +151,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-// stage 2 of backward: dgamma = sum dy * xhat, dbeta = sum dy (fixed order), plus the per-channel constants of
-// dx = gamma * invstd * (dy - dbeta / R - xhat * dgamma / R)
-__global__ void bn_bwd_stage2(const double* __restrict__ partial, int slices, long R, int C, const float* __restrict__ gamma,
+// stage 2 of backward, one workgroup per channel: dgamma = sum dy * xhat, dbeta = sum dy (fixed order), plus the per-channel
+// constants of dx = gamma * invstd * (dy - dbeta / R - xhat * dgamma / R)
+__global__ __launch_bounds__(256) void bn_bwd_stage2(const double* __restrict__ partial, int slices, long R, int C,
+                              const float* __restrict__ gamma,
                               const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                               float* __restrict__ k_dy, float* __restrict__ k_mean_dy, float* __restrict__ k_mean_dyx) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < slices; ++k) {
-        s0 += partial[(long)k * 2 * C + c];
-        s1 += partial[(long)k * 2 * C + C + c];
-    }
+    const int c = blockIdx.x;
+    double s0, s1;
+    bn_channel_sums(partial, slices, C, c, s0, s1);
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
     k_dy[c] = gamma[c] * invstd[c];
@@ -149,21 +170,38 @@ __global__ void bn_bwd_stage2(const double* __restrict__ partial, int slices, lo
 
 // dx[r][c] = k_dy * (dy - mean_dy - xhat * mean_dyx), times (x > 0) when the normalised tensor is a ReLU output
 // (Conv2D(activation="relu") feeds the BatchNormalization in FrameLayer2D): dx is then the gradient before the ReLU.
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, RowMap dmap,
                                                            long R, int C, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ k_dy,
                                                            const float* __restrict__ k_mean_dy,
                                                            const float* __restrict__ k_mean_dyx, int relu_mask,
                                                            float* __restrict__ dx) {
-    const long total = R * C;
+    const long per_row = VEC ? C / 4 : C;
+    const long total = R * per_row;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long r = i / C;
-        const int c = (int)(i - r * C);
-        const float xv = x[i];
-        const float xh = (xv - mean[c]) * invstd[c];
-        float g = k_dy[c] * (dy[map_row(dmap, r) + c] - k_mean_dy[c] - xh * k_mean_dyx[c]);
-        if (relu_mask && !(xv > 0.f)) g = 0.f;
-        dx[i] = g;
+        const long r = i / per_row;
+        const int j = (int)(i - r * per_row);
+        if (VEC) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[i];
+            const float4 dv = *reinterpret_cast<const float4*>(dy + map_row(dmap, r) + 4 * j);
+            const float4 mu = reinterpret_cast<const float4*>(mean)[j], is = reinterpret_cast<const float4*>(invstd)[j];
+            const float4 kd = reinterpret_cast<const float4*>(k_dy)[j], km = reinterpret_cast<const float4*>(k_mean_dy)[j];
+            const float4 kx = reinterpret_cast<const float4*>(k_mean_dyx)[j];
+            float4 g;
+#define LBX_BN1(c)                                                                   \
+            g.c = kd.c * (dv.c - km.c - (xv.c - mu.c) * is.c * kx.c);                \
+            if (relu_mask && !(xv.c > 0.f)) g.c = 0.f;
+            LBX_BN1(x) LBX_BN1(y) LBX_BN1(z) LBX_BN1(w)
+#undef LBX_BN1
+            reinterpret_cast<float4*>(dx)[i] = g;
+        } else {
+            const float xv = x[i];
+            const float xh = (xv - mean[j]) * invstd[j];
+            float g = k_dy[j] * (dy[map_row(dmap, r) + j] - k_mean_dy[j] - xh * k_mean_dyx[j]);
+            if (relu_mask && !(xv > 0.f)) g = 0.f;
+            dx[i] = g;
+        }
     }
 }
 
@@ -204,7 +242,7 @@ extern "C" int lidbox_bn_train_stats(const float* x, long R, int C, const float*
     hipLaunchKernelGGL(bn_reduce_stage1<0>, dim3((unsigned)lbx_cdiv(C, BN_COLS), (unsigned)slices), dim3(256), 0, st, x,
                        (const float*)nullptr, none, R, C, rps, (const float*)nullptr, (const float*)nullptr, partial);
     LBX_LAUNCH_OK();
-    hipLaunchKernelGGL(bn_stats_stage2, dim3((unsigned)lbx_cdiv(C, 64)), dim3(64), 0, st, partial, slices, R, C, gamma, beta,
+    hipLaunchKernelGGL(bn_stats_stage2, dim3((unsigned)C), dim3(256), 0, st, partial, slices, R, C, gamma, beta,
                        eps, momentum, moving_mean, moving_var, mean_out, invstd_out, scale_out, shift_out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
@@ -254,11 +292,18 @@ extern "C" int lidbox_bn_bwd(const float* x, lidbox_rows_t dy, long R, int C, co
     hipLaunchKernelGGL(bn_reduce_stage1<1>, dim3((unsigned)lbx_cdiv(C, BN_COLS), (unsigned)slices), dim3(256), 0, st, x,
                        dy.base, dm, R, C, rps, mean, invstd, partial);
     LBX_LAUNCH_OK();
-    hipLaunchKernelGGL(bn_bwd_stage2, dim3((unsigned)lbx_cdiv(C, 64)), dim3(64), 0, st, partial, slices, R, C, gamma, invstd,
+    hipLaunchKernelGGL(bn_bwd_stage2, dim3((unsigned)C), dim3(256), 0, st, partial, slices, R, C, gamma, invstd,
                        dgamma, dbeta, consts, consts + C, consts + 2 * C);
     LBX_LAUNCH_OK();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(R * C)), dim3(256), 0, st, x, dy.base, dm, R, C, mean, invstd, consts,
-                       consts + C, consts + 2 * C, relu_mask, dx);
+    // the three constant rows start C floats apart inside the workspace: float4 access needs C % 4 == 0 and 16-byte aligned bases
+    const bool vec = C % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy.base | (uintptr_t)dx | (uintptr_t)mean | (uintptr_t)invstd |
+                                     (uintptr_t)consts) & 15) == 0 && dy.row_stride % 4 == 0 && (dy.batch == 1 || dy.batch_stride % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(bn_grid(R * (C / 4))), dim3(256), 0, st, x, dy.base, dm, R, C, mean, invstd,
+                           consts, consts + C, consts + 2 * C, relu_mask, dx);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(bn_grid(R * C)), dim3(256), 0, st, x, dy.base, dm, R, C, mean, invstd,
+                           consts, consts + C, consts + 2 * C, relu_mask, dx);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

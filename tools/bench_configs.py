@@ -4,6 +4,9 @@
   configs[4]  100-language x-vector trunk -> segment1 -> L2 norm -> SparseAngularProximity + C_avg (100 thresholds),
               bf16 compute / fp32 master, ONE GPU's shard of the 8 x 512 batch (bs 512)
 
+  x2d         (not a BASELINE config) log-mel -> xvector_2d (Conv2D-along-frequency + BatchNormalization front-end
+              -> x-vector), bs 256, fp32: forward 1 043 MFLOP / utterance (front-end 731), train ~ 3 090
+
 Same timing discipline as bench.py: inputs resident in HBM, warm-up, K graph-replayed steps between synchronisations.
 Algorithmic train flops per utterance: CNN 2 135 MFLOP, x-vector (100 outputs replaced by the 512-d AP head) 918 MFLOP
 (SURVEY 8d).  usage: python tools/bench_configs.py [--steps K] [--warmup W]"""
@@ -19,7 +22,7 @@ from lidbox_amd import _native as nv
 from lidbox_amd.features import audio
 from lidbox_amd.losses import SparseAngularProximity
 from lidbox_amd.metrics import SparseAverageDetectionCost
-from lidbox_amd.models import cnn, xvector
+from lidbox_amd.models import cnn, xvector, xvector_2d
 from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
 from lidbox_amd.testutil import synthetic_batch
 from lidbox_amd.train import Trainer
@@ -46,7 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--only", choices=["cnn", "ap", "ap32"], default=None)
+    ap.add_argument("--only", choices=["cnn", "ap", "ap32", "x2d"], default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     plan = audio.get_plan(16000, 400, 160, device=dev)
@@ -57,6 +60,14 @@ def main():
         run("configs[3]: MFCC(1:13)+CMVN -> cnn, 4 languages, bs 256, fp32, 1 GPU", t, torch.from_numpy(sig).to(dev),
             torch.from_numpy(y.astype(np.int32)).to(dev), a.steps, a.warmup, 2135e6, dict(dtype="f32"))
         del t, m
+    if a.only in (None, "x2d"):
+        sig, y = synthetic_batch(256, 4, 16000, 2.0, seed=1234)
+        m = xvector_2d.create((198, 40), 4, seed=0, device=dev)
+        t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=True)
+        run("8f.1: log-mel -> xvector_2d (2-D front-end + BatchNorm), 4 languages, bs 256, fp32, 1 GPU", t, torch.from_numpy(sig).to(dev),
+            torch.from_numpy(y.astype(np.int32)).to(dev), a.steps, a.warmup, 3090e6, dict(dtype="f32"))
+        del t, m
+        torch.cuda.empty_cache()
     for tag, cd in (("ap", "bfloat16"), ("ap32", "float32")):
         if a.only not in (None, tag):
             continue
