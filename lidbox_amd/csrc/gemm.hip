@@ -243,6 +243,15 @@ __device__ __forceinline__ void mma_tile(const float* As, const float* Bs, int w
     if (LBX_GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
+#ifdef LBX_GEMM_TIMING
+// Debug builds only (tools/gemm_phases.py): per-wave s_memtime samples of the rows kernels.
+//   [0] kernel entry  [1] first tile staged (after the first barrier)  [2] K loop done  [3] epilogue done
+//   [4] cycles inside mma_tile, [5] issuing the next tile's global loads, [6] LDS stores (incl. the wait for those loads),
+//   [7] waiting at the barrier -- summed over the K steps; [8] SIMD/CU/XCD id word (HW_ID)
+__device__ long long* g_gemm_stamps = nullptr;
+#define LBX_T() ((long long)__builtin_amdgcn_s_memtime())
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] . B)    B_KINNER = false: B[K][N] (NN)   true: B[N][K] (NT)
 // grid.x = tiles (XCD-chunk remapped), grid.y = K splits.  splits > 1: raw partial sums go to
@@ -266,6 +275,9 @@ __device__ __forceinline__ void gemm_rows_body(const RowsD& A, const float* __re
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef LBX_GEMM_TIMING
+    long long ts0 = LBX_T(), t_mma = 0, t_ld = 0, t_st = 0, t_bar = 0;
+#endif
     const int wm = wave / WN, wn = wave % WN;
     const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
     const int tn = chunk % tiles_n;
@@ -302,6 +314,9 @@ __device__ __forceinline__ void gemm_rows_body(const RowsD& A, const float* __re
         else lbo.store(Bs[0]);
     }
     __syncthreads();
+#ifdef LBX_GEMM_TIMING
+    const long long ts1 = LBX_T();
+#endif
 
     // Backward epilogues multiply by the ReLU mask (aux > 0, aux = the forward activation, C's layout).  Reading
     // it in the epilogue costs one dependent HBM round trip per output row while the workgroup holds its slot
@@ -330,6 +345,10 @@ __device__ __forceinline__ void gemm_rows_body(const RowsD& A, const float* __re
             mv0 = *mask_ptr(2 * kt);
             mv1 = *mask_ptr(2 * kt + 1);
         }
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q0 = LBX_T();
+#endif
         if (kt + 2 < nk) {
             la.template load<false>(kend);
             if (B_KINNER) lbi.template load<false>(kend);
@@ -339,7 +358,15 @@ __device__ __forceinline__ void gemm_rows_body(const RowsD& A, const float* __re
             if (B_KINNER) lbi.template load<true>(kend);
             else lbo.template load_plain<true>(kend);
         }
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q1 = LBX_T();
+#endif
         mma_tile<MI, NJ, LDA, LDB>(As[cur], Bs[cur], wm, wn, lane, acc);
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q2 = LBX_T();
+#endif
         if (kt + 1 < nk) {
             la.store(As[cur ^ 1]);
             if (B_KINNER) lbi.store(Bs[cur ^ 1]);
@@ -347,12 +374,34 @@ __device__ __forceinline__ void gemm_rows_body(const RowsD& A, const float* __re
         }
         if (mload)
             mbits |= ((unsigned long long)(mv0 > 0.f) << (2 * kt)) | ((unsigned long long)(mv1 > 0.f) << (2 * kt + 1));
+#ifdef LBX_GEMM_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q3 = LBX_T();
+#endif
         __syncthreads();
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q4 = LBX_T();
+        t_ld += q1 - q0; t_mma += q2 - q1; t_st += q3 - q2; t_bar += q4 - q3;
+#endif
     }
+#ifdef LBX_GEMM_TIMING
+    const long long ts2 = LBX_T();
+#endif
     if (pre_mask)                                            // short K: the values no K-step fetched
         for (int idx = 2 * nk; idx < NPRE; ++idx) mbits |= (unsigned long long)(*mask_ptr(idx) > 0.f) << idx;
 
     store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, mbits, pre_mask);
+#ifdef LBX_GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && g_gemm_stamps) {
+        long long* o = g_gemm_stamps + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 10;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = LBX_T(); o[4] = t_mma; o[5] = t_ld; o[6] = t_st; o[7] = t_bar; o[8] = hwid; o[9] = nk;
+    }
+#endif
 }
 
 template <int BM, int BN, bool B_KINNER, bool ALIGNED>
@@ -812,6 +861,13 @@ extern "C" int lidbox_gemm_nn(lidbox_rows_t A, const float* Bm, long ldb, lidbox
     if (validate_rows_call(__func__, A, Bm, ldb, C, K, N, epilogue, aux, N)) return LIDBOX_E_INVALID;
     return launch_rows<false>(A, Bm, ldb, C, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+#ifdef LBX_GEMM_TIMING
+extern "C" int lidbox_gemm_debug_set_stamps(void* device_ptr) {          // timing builds only (not in include/lidbox_hip.h)
+    LBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &device_ptr, sizeof(void*)));
+    return LIDBOX_OK;
+}
+#endif
 
 extern "C" int lidbox_gemm_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N,
                               int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
