@@ -31,6 +31,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -303,6 +305,14 @@ namespace {
 #ifndef LBX_FEAT_NO_HOIST
 #define LBX_FEAT_NO_HOIST 1                  // keep the untangle's per-lane addresses out of loop-invariant registers
 #endif
+#ifndef LBX_FEAT_PRUNE13
+#define LBX_FEAT_PRUNE13 0                  // 1: skip the always-zero samples 416..511 of frames <= 416 samples (loads, window products, pass-1 inputs);
+                                            // measured SLOWER for log-mel (28.7 vs 28.0 us at B = 256, 160.6 vs 156.4 at 2048: the wave-uniform branch
+                                            // duplicates the load + pass-1 code and costs 8 registers), neutral for MFCC -- off
+#endif
+#ifndef LBX_FEAT_LANE0_V2
+#define LBX_FEAT_LANE0_V2 1                 // 0: round 1's lane-0 pairing of the untangling (A/B aid)
+#endif
 #ifndef LBX_FEAT_SEGMEL
 #define LBX_FEAT_SEGMEL 1                   // 0: always use the per-band CSR mel loop (A/B aid)
 #endif
@@ -375,14 +385,28 @@ __device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2&
     x3 = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i*t3
 }
 
+// the same with x3 = 0 on input (frames shorter than the transform: the window is zero there)
+__device__ __forceinline__ void dft4_z3(float2& x0, float2& x1, float2& x2, float2& x3) {
+    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), x1c = x1;
+    x0 = cadd(t0, x1c);
+    x2 = csub(t0, x1c);
+    x1 = make_float2(t1.x + x1c.y, t1.y - x1c.x);   // t1 - i*x1
+    x3 = make_float2(t1.x - x1c.y, t1.y + x1c.x);   // t1 + i*x1
+}
+
 // register that holds X[k] after dft16 (digit-reversed)
 #define R16(k) (4 * ((k) & 3) + ((k) >> 2))
 
-// forward 16-point DFT in place; input v[n] natural order, output X[k] in v[R16(k)]
+// forward 16-point DFT in place; input v[n] natural order, output X[k] in v[R16(k)].  NIN (13 ... 16): inputs v[NIN ...] are
+// zero and are never read (pass 1 of a frame of <= 32 * NIN samples: 25 ms at 16 kHz is 400 <= 416).
+template <int NIN = 16>
 __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    for (int b = 0; b < 4; ++b) {
+        if (12 + b < NIN) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+        else dft4_z3(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    }
     // twiddle Y[b][c] (held in v[4c+b]) by W16^(b*c)
     v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(C1, -S1));                              // W^1
     v[4 * 2 + 1] = make_float2((v[9].x + v[9].y) * H, (v[9].y - v[9].x) * H);             // W^2
@@ -502,56 +526,67 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
         // no per-load address selects and no window guards: the samples after a frame are the utterance's own
         // later samples and the window table is zero there.  The guarded path below handles an utterance's last tile.
         const bool interior = VEC4 && LBX_FEAT_FAST_INTERIOR && (long)(t0 + 7) * a.S + 512 <= a.N;
-        if (interior) {
-            const float* base = src + 4 * q;
+        // NL = float4 per lane that can be non-zero: 16, or 13 when frame_length <= 416 (the window table is zero behind the
+        // frame): the three loads, their window products and the zero inputs of pass 1's first radix-4 stage are skipped
+        auto load_window_pass1 = [&](auto nl_tag) {
+            constexpr int NL = decltype(nl_tag)::value;
+            if (interior) {
+                const float* base = src + 4 * q;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float4 x[8];
+                for (int half = 0; half < 2; ++half) {
+                    float4 x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4*>(base + 32 * (8 * half + j));
+                    for (int j = 0; j < 8; ++j)
+                        if (8 * half + j < NL) x[j] = *reinterpret_cast<const float4*>(base + 32 * (8 * half + j));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int n1 = 8 * half + j;
-                    const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);
-                    za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
-                    zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
+                    for (int j = 0; j < 8; ++j) {
+                        const int n1 = 8 * half + j;
+                        if (n1 >= NL) continue;
+                        const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);
+                        za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
+                        zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else
+            } else {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 x[8];
+                for (int half = 0; half < 2; ++half) {
+                    float4 x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int idx = 32 * (8 * half + j) + 4 * q;
-                // masked lanes read four zeros that sit behind the window table (finite whatever the signal holds),
-                // so the products below need no guards and the lane masks die here
-                const float* zero4 = a.win512 + 512;
-                if (VEC4) {
-                    x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : zero4);
-                } else {
-                    const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : zero4;
-                    const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : zero4;
-                    const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : zero4;
-                    const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : zero4;
-                    x[j] = make_float4(*p0, *p1, *p2, *p3);
+                    for (int j = 0; j < 8; ++j) {
+                        if (8 * half + j >= NL) continue;
+                        const int idx = 32 * (8 * half + j) + 4 * q;
+                        // masked lanes read four zeros that sit behind the window table (finite whatever the signal holds),
+                        // so the products below need no guards and the lane masks die here
+                        const float* zero4 = a.win512 + 512;
+                        if (VEC4) {
+                            x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : zero4);
+                        } else {
+                            const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : zero4;
+                            const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : zero4;
+                            const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : zero4;
+                            const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : zero4;
+                            x[j] = make_float4(*p0, *p1, *p2, *p3);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int n1 = 8 * half + j;
+                        if (n1 >= NL) continue;
+                        const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);      // zero beyond L
+                        za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
+                        zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n1 = 8 * half + j;
-                const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);      // zero beyond L
-                za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
-                zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        LBX_STAMP(1);
-        // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
-        dft16(za);
-        dft16(zb);
+            LBX_STAMP(1);
+            // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
+            dft16<NL>(za);
+            dft16<NL>(zb);
+        };
+        if (LBX_FEAT_PRUNE13 && a.L <= 416) load_window_pass1(std::integral_constant<int, 13>{});       // wave-uniform
+        else load_window_pass1(std::integral_constant<int, 16>{});
         LBX_STAMP(2);
         // ---- 3. twiddle by W256^(n2*k1)
 #pragma unroll
@@ -618,6 +653,32 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
             else Pf[bin] = v;
         };
         const bool q0 = (qv == 0);
+#if LBX_FEAT_LANE0_V2
+        // Lane 0 holds the two self-paired columns (k1 = 0 in ua, k1 = 8 in ub).  Its pairs are laid over the general
+        // pattern (ua[s] with ub[15-s]) so that only ONE operand of a slot differs: slots 0-7 pair ub[s] with ub[15-s]
+        // (bins 8 + 16 s and 248 - 16 s), slots 8-15 pair ua[s] with ua[16-s] (bins 16 s and 256 - 16 s; s = 8 pairs bin 128
+        // with itself), slot 16 pairs ua[0] with itself (bins 0 and 256): 33 selects per tile instead of 65.
+        const int qlo = q0 ? 8 : qv;
+#pragma unroll
+        for (int s = 0; s < 17; ++s) {
+            float2 zk, zm;
+            int bin;
+            if (s < 8) {
+                const float2 g = ua[R16(s)], l0 = ub[R16(s)];
+                zk = make_float2(q0 ? l0.x : g.x, q0 ? l0.y : g.y);
+                zm = ub[R16(15 - s)];
+                bin = qlo + 16 * s;
+            } else if (s < 16) {
+                zk = ua[R16(s)];
+                const float2 g = ub[R16(15 - s)], l0 = ua[R16((16 - s) & 15)];
+                zm = make_float2(q0 ? l0.x : g.x, q0 ? l0.y : g.y);
+                bin = qv + 16 * s;
+            } else {
+                zk = ua[R16(0)];
+                zm = ua[R16(0)];
+                bin = 0;
+            }
+#else
 #pragma unroll
         for (int s = 0; s < 17; ++s) {
             float2 zk, zm;
@@ -639,6 +700,7 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
                 zm = ub[R16(8)];
                 bin = 8 + 16 * 7;
             }
+#endif
             if (s < 16 || q0) {
                 const float2 w = s_tw512[bin];
                 float pk, pm;
