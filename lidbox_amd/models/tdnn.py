@@ -309,6 +309,8 @@ class SequentialTDNN:
         import os as _os
         self.bf16_storage = self.compute_dtype == "bfloat16" and _os.environ.get("LIDBOX_BF16_STORAGE", "1") != "0" \
             and attention is None and not self.frontend
+        if self.bf16_storage and not any(self.shadow_fwd_ok(i) for i in range(len(self.convs))):
+            self.bf16_storage = False                    # no layer qualifies (e.g. the CNN's 12- / 500-channel layers): nothing to shadow
         if self.bf16_storage:
             self.flat16 = torch.zeros(self.num_flat, dtype=torch.bfloat16, device=self.device)
             cin = self.input_dim

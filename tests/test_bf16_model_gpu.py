@@ -181,3 +181,20 @@ def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
     for _ in range(12):
         l1 = float(t.train_step(sd, yd))
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_bf16_models_without_qualifying_layers_keep_the_fp32_source_kernels():
+    """the CNN's 12- / 500-channel layers cannot be read as 16-byte bf16 pieces: no shadows are allocated and the bf16
+    compute path still trains (fp32-source kernels)"""
+    from lidbox_amd.models import cnn
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(31)
+    m = cnn.create((40, 12), 4, seed=1, compute_dtype="bfloat16")
+    assert not m.bf16_storage and not hasattr(m, "flat16")
+    x = torch.from_numpy(rng.standard_normal((8, 40, 12)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.integers(0, 4, size=8).astype(np.int32)).cuda()
+    t = Trainer(m, use_graph=True)
+    l0 = float(t.train_step(x, y))
+    for _ in range(10):
+        l1 = float(t.train_step(x, y))
+    assert np.isfinite(l1) and l1 < l0
