@@ -326,7 +326,9 @@ def main():
                    "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
                    "languages": NUM_LANGS, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world, "grad_buckets": trainer.sync.num_buckets if world > 1 else 1,
                    "hip_graph": not args.no_graph, "resident_batches": len(batches),
-                   "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6)},
+                   "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6),
+                   "loss_note": "SURVEY 8d's synthetic languages (one sine frequency each) are separable: the loss reaches ~0 within a "
+                                "few dozen Adam steps; every step still runs the full dense forward / backward / optimizer work"},
     }
 
     sys.stdout.flush()
