@@ -507,27 +507,58 @@ __global__ LBX_TN_BOUNDS(BM, BN) void gemm_tn_kernel(RowsD A, RowsD Bd, float* _
     const bool do_csum = (Pc != nullptr) && tk == 0 && tid < BN;
 
     const int nk = (int)((mend - mbeg + BK - 1) / BK);
+#ifdef LBX_GEMM_TIMING
+    long long ts0 = LBX_T(), t_mma = 0, t_ld = 0, t_st = 0, t_bar = 0;
+#endif
     if (nk > 0) {
         LBX_TN_FETCH(true)
         la.store(As[0]);
         lb.store(Bs[0]);
     }
     __syncthreads();
+#ifdef LBX_GEMM_TIMING
+    const long long ts1 = LBX_T();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q0 = LBX_T();
+#endif
         if (kt + 2 < nk) LBX_TN_FETCH(false)
         else if (kt + 1 < nk) LBX_TN_FETCH(true)
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q1 = LBX_T();
+#endif
         mma_tile<MI, NJ, LAo::LD, LBo::LD>(As[cur], Bs[cur], wm, wn, lane, acc);
         if (do_csum) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) csum += Bs[cur][kk * LBo::LD + tid];
         }
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q2 = LBX_T();
+#endif
         if (kt + 1 < nk) {
             la.store(As[cur ^ 1]);
             lb.store(Bs[cur ^ 1]);
         }
+#ifdef LBX_GEMM_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q3 = LBX_T();
+#endif
         __syncthreads();
+#ifdef LBX_GEMM_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long q4 = LBX_T();
+        t_ld += q1 - q0; t_mma += q2 - q1; t_st += q3 - q2; t_bar += q4 - q3;
+#endif
     }
+#ifdef LBX_GEMM_TIMING
+    const long long ts2 = LBX_T();
+#endif
 #undef LBX_TN_FETCH
     float* Pd = P + (long)split * K1 * N;
     const int h = lane >> 5, l = lane & 31;
@@ -544,6 +575,13 @@ __global__ LBX_TN_BOUNDS(BM, BN) void gemm_tn_kernel(RowsD A, RowsD Bd, float* _
             }
     }
     if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
+#ifdef LBX_GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && g_gemm_stamps) {
+        long long* o = g_gemm_stamps + ((long)blockIdx.x * 4 + wave) * 10;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = LBX_T(); o[4] = t_mma; o[5] = t_ld; o[6] = t_st; o[7] = t_bar; o[8] = 0; o[9] = nk;
+    }
+#endif
 }
 
 // column sums (standalone): stage 1 partial[rs][N] over row slices, stage 2 fixed-order reduce

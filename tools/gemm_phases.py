@@ -1,5 +1,6 @@
 """Per-wave phase timeline of the fp32 rows kernels (a -DLBX_GEMM_TIMING build of gemm.hip, tools/ab_build.py).
-usage: LIDBOX_HIP_LIB=tools/ab/libgtime.so python tools/gemm_phases.py M K N kind [bm,bn,splits]   kind: nn | nt | ntmask"""
+usage: LIDBOX_HIP_LIB=tools/ab/libgtime.so python tools/gemm_phases.py M K N kind [bm,bn,splits]   kind: nn | nt | ntmask | tn
+(tn: wgrad C[K,N] = A[M,K]^T B[M,N], contraction over the M rows; the plan string then goes to LIDBOX_GEMM_TN_PLAN)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,14 +10,17 @@ from lidbox_amd import _native as nv
 M, K, N = (int(v) for v in sys.argv[1:4])
 kind = sys.argv[4]
 if len(sys.argv) > 5:
-    os.environ["LIDBOX_GEMM_PLAN"] = sys.argv[5]
+    os.environ["LIDBOX_GEMM_TN_PLAN" if kind == "tn" else "LIDBOX_GEMM_PLAN"] = sys.argv[5]
 lib = nv.lib
 lib.lidbox_gemm_debug_set_stamps.restype = C.c_int
 lib.lidbox_gemm_debug_set_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros(10 * (1 << 19), dtype=torch.int64, device="cuda")
 nv.check(lib.lidbox_gemm_debug_set_stamps(stamps.data_ptr()))
 a = torch.randn(M, K, device="cuda")
-b = torch.randn((N, K) if kind != "nn" else (K, N), device="cuda")
+b = torch.randn((M, N) if kind == "tn" else ((N, K) if kind != "nn" else (K, N)), device="cuda")
+cw = torch.empty(K, N, device="cuda")
+bg = torch.empty(N, device="cuda")
+tws = torch.empty(max(16, lib.lidbox_gemm_tn_workspace(M, K, N)), dtype=torch.uint8, device="cuda")
 c = torch.empty(M, N, device="cuda")
 mask = torch.randn(M, N, device="cuda")
 st = nv.current_stream()
@@ -25,6 +29,8 @@ ws = torch.empty(max(16, lib.lidbox_gemm_rows_workspace(M, N, K)), dtype=torch.u
 
 
 def call():
+    if kind == "tn":
+        return lib.lidbox_gemm_tn(ra, nv.Rows(b.data_ptr(), 0, N, 1, M), nv.ptr(cw), N, K, N, 0, nv.ptr(bg), nv.ptr(tws), tws.numel(), st)
     if kind == "nn":
         return lib.lidbox_gemm_nn(ra, nv.ptr(b), N, rc, K, N, nv.EPI_BIAS_RELU, nv.ptr(c[0]), nv.ptr(ws), ws.numel(), st)
     epi, aux = (nv.EPI_RELU_MASK, nv.ptr(mask)) if kind == "ntmask" else (nv.EPI_NONE, None)
