@@ -450,3 +450,29 @@ def test_spatial_dropout_kernel():
     assert bool((x == 1).all())
     with pytest.raises(ValueError):
         nv.check(nv.lib.lidbox_spatial_dropout(nv.ptr(x), B, T, C, T * C, 1.0, 1, None, None, st))
+
+
+@pytest.mark.parametrize("plan", ["128,128,1", "128,64,5", "128,128,3", "64,64,7"])
+@pytest.mark.parametrize("M,K1,N", [(3000, 300, 200), (700, 1536, 512), (33, 257, 129)])
+def test_every_wgrad_decomposition_gives_the_same_product(plan, M, K1, N, monkeypatch):
+    """lidbox_gemm_tn under forced tile shapes / row splits (LIDBOX_GEMM_TN_PLAN)
+    on ragged shapes with implicit (gapped) utterance rows; weight gradient and fused bias gradient"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + K1 + N)
+    Bn = 3 if M % 3 == 0 else 1
+    rpb, pad = M // Bn, 2
+    A = rng.standard_normal((Bn, pad + rpb, K1))            # rows behind two pad rows per utterance
+    Bm = rng.standard_normal((Bn, rpb, N))
+    a, b = _dev(A), _dev(Bm)
+    st = nv.current_stream()
+    monkeypatch.setenv("LIDBOX_GEMM_TN_PLAN", plan)
+    wsb = nv.lib.lidbox_gemm_tn_workspace(M, K1, N)
+    ws = torch.empty(max(16, wsb), dtype=torch.uint8, device="cuda")
+    c = torch.full((K1, N), 5.0, device="cuda")
+    bg = torch.full((N,), 5.0, device="cuda")
+    ra = _rows(a, (pad + rpb) * K1, K1, Bn, rpb, off_floats=pad * K1)
+    rb = _rows(b, rpb * N, N, Bn, rpb)
+    nv.check(nv.lib.lidbox_gemm_tn(ra, rb, nv.ptr(c), N, K1, N, 0, nv.ptr(bg), nv.ptr(ws), ws.numel(), st))
+    A2, B2 = A[:, pad:].reshape(M, K1), Bm.reshape(M, N)
+    _close(c.cpu().numpy(), A2.T @ B2)
+    _close(bg.cpu().numpy(), B2.sum(axis=0))
