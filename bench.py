@@ -76,7 +76,8 @@ class KernelTimer:
     i.e. by the names rocprofv3 --stats reports."""
 
     ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_extract_features_fwd": -1,
-             "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13}
+             "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13,
+             "lidbox_gemm_bf16s_tn": 14}
 
     def __init__(self, nv):
         self.nv = nv
@@ -93,6 +94,8 @@ class KernelTimer:
             return "gemm16s_rows_kernel", 2.0 * A.batch * A.rows_per_batch * K * N
         A, K, N = args[0], args[4], args[5]
         M = A.batch * A.rows_per_batch
+        if kind == 14:                                        # bf16-storage wgrad: (A16, B16, C, ldc, K1, N, ...)
+            return "gemm16s_tn_kernel", 2.0 * M * K * N
         if kind >= 10:                                        # bf16 family: one tile shape per entry point
             return ("gemm16_tn_kernel", "gemm16_rows_kernel<NN>", "gemm16_rows_kernel<NT>")[(kind - 9) % 3], 2.0 * M * K * N
         ws_bytes = args[9] if kind < 2 else 0

@@ -233,6 +233,16 @@ int lidbox_gemm_bf16_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, i
 int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16,
                          int K, int N, int epilogue, const float* aux,
                          void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+/* wgrad on bf16 storage: C[K1,N] (+)= A16^T . B16 with both operands implicit rows of bf16 buffers (bases point at
+ * bfloat16 data, strides in bf16 elements): A16 = the shadow of the layer input (K1 = k*C_in contiguous elements per
+ * row), B16 = the shadow of the output gradient.  C, accumulate, bias_grad, workspace and determinism as
+ * lidbox_gemm_bf16_tn (xvector.py:38-43 under a bfloat16 policy); the bias gradient is the fp32 sum of the shadow's
+ * values.  Needs 16-byte aligned bases, row / batch strides % 8 == 0, and K1 / N % 8 == 0 or rows padded to a multiple
+ * of 8 elements (row_stride >= the width rounded up to 8: a 1500-channel gradient lives in a 1504-wide shadow). */
+size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N);
+int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ldc, int K1, int N,
+                         int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
+                         lidbox_stream_t stream);
 /* dst[i] = bf16(src[i]) (round-to-nearest-even), n elements; dst[c][r] = bf16(src[r][c]) for an R x C matrix */
 int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream);
 int lidbox_transpose_f32_to_bf16(const float* src, int R, int C, long ld_src, void* dst, long ld_dst,
@@ -309,6 +319,11 @@ int lidbox_stats_pool_fwd(const float* x, int B, int T, int C, long batch_stride
 int lidbox_stats_pool_bwd(const float* x, const float* pooled, const float* dout, int B, int T, int C,
                           long batch_stride, long row_stride, int relu_mask, float* dx,
                           lidbox_stream_t stream);
+/* as lidbox_stats_pool_bwd; additionally writes bf16(dx) (round-to-nearest-even) to the shadow buffer dx16 with its own
+ * batch / row strides in bf16 elements (row_stride16 >= C: a shadow padded to 8-element rows feeds lidbox_gemm_bf16s_tn) */
+int lidbox_stats_pool_bwd_shadow(const float* x, const float* pooled, const float* dout, int B, int T, int C,
+                                 long batch_stride, long row_stride, int relu_mask, float* dx,
+                                 void* dx16, long batch_stride16, long row_stride16, lidbox_stream_t stream);
 /* Keras GlobalAveragePooling1D (cnn.py:37) */
 int lidbox_avg_pool_fwd(const float* x, int B, int T, int C, long batch_stride, long row_stride,
                         float* out, lidbox_stream_t stream);

@@ -83,6 +83,7 @@ _SIGS = {
     "lidbox_colsum": (_i, [Rows, _i, _vp, _i, _vp, _sz, _vp]),
     "lidbox_stats_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_stats_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
+    "lidbox_stats_pool_bwd_shadow": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp, _l, _l, _vp]),
     "lidbox_avg_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_avg_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
     "lidbox_signal_chunk_plan": (_i, [_l, _i, _i, _i, _i, _vp]),
@@ -109,6 +110,8 @@ _SIGS = {
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),
     "lidbox_gemm_bf16s_nt": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_bf16s_tn_workspace": (_sz, [_i, _i, _i]),
+    "lidbox_gemm_bf16s_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
     "lidbox_transpose_f32_to_bf16": (_i, [_vp, _i, _i, _l, _vp, _l, _vp]),
     "lidbox_scale": (_i, [_vp, _l, _f, _vp]),

@@ -566,6 +566,214 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
     store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16-STORAGE wgrad (lidbox_gemm_bf16s_tn): P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N] with both operands bfloat16
+// in HBM and the contraction index = the ROW (A = the bf16 shadow of the layer input, read through the implicit-row
+// descriptor; B = the bf16 shadow of the output gradient).  Tiles go from global memory to LDS unchanged -- [64 contraction
+// rows][128 columns] as 16-byte pieces along the row, so a wave-load covers 4 rows x 256 B = 8 whole 128-byte lines -- and
+// the MFMA operands (lane -> column, 8 consecutive contraction rows) come out of LDS through the hardware transpose read
+// ds_read_b64_tr_b16: a 16-lane group reads a [4 rows][16 columns] block as 4-column pieces and lane j receives column j's
+// four values (measured in tools/micro/tr_read.hip).  No convert / transpose VALU work and half the L2 -> LDS bytes of
+// gemm16_tn_kernel.  LDS row stride 320 bytes: the 32-lane service group of the transpose read touches 4 rows x 64 B, which
+// lands on 4 disjoint quarters of the 256-byte bank row (320 = 64 mod 256).
+// The bias gradient (column sums of B) is summed in fp32 from the bf16 shadow's values.
+// ------------------------------------------------------------------------------------------------
+#ifndef LBX16T_LDS
+#define LBX16T_LDS 160                      // LDS row stride of the wgrad tiles, in bf16
+#endif
+constexpr int BKT = 64;                     // contraction rows of one LDS tile
+constexpr int LDS_T = LBX16T_LDS;
+constexpr int TILE_T = BKT * LDS_T;
+
+struct TileT {
+    u32x4 v[4];
+};
+
+// thread -> 16-byte piece pc = tid & 15 (8 columns) of contraction rows kr + 16 j, kr = tid >> 4, j = 0, 1, 2, ...: one
+// sequence of stride 16 across tiles (a tile takes four of them), followed by a single incremental (utterance row, pointer)
+// tracker -- adds only.
+struct KOuterRowsS {
+    const __bf16* p;
+    long m, step, wrap;
+    unsigned t, rpb;
+    int pc, kr;
+
+    __device__ __forceinline__ void init(const RowsH& r, long mbeg, int col0, int ncols, int tid) {
+        pc = tid & 15;
+        kr = tid >> 4;
+        const int c = col0 + 8 * pc;
+        const int cload = c < ncols ? c : 0;                    // clamped column piece (results never stored)
+        m = mbeg + kr;
+        rpb = r.batch == 1 ? 0xffffffffu : (unsigned)r.rpb;
+        const unsigned b = r.batch == 1 ? 0u : (unsigned)m / rpb;
+        t = (unsigned)m - (r.batch == 1 ? 0u : b * rpb);
+        p = r.base + (long)b * r.bs + (long)t * r.rs + cload;
+        step = 16 * r.rs;
+        wrap = r.batch == 1 ? 0 : r.bs - (long)r.rpb * r.rs;
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void load(TileT& x, long mend) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x.v[j] = (!CHECK || m < mend) ? *reinterpret_cast<const u32x4*>(p) : z;
+            m += 16;
+            t += 16;
+            p += step;
+            while (t >= rpb) { t -= rpb; p += wrap; }
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* tile, const TileT& x) const {
+        __bf16* d = tile + kr * LDS_T + 8 * pc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(d + j * 16 * LDS_T) = x.v[j];
+    }
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16* lo_rows) {
+    // rows r .. r+3 of the lane group's block, then rows r+4 .. r+7: 8 consecutive contraction indices of the lane's column
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lo_rows));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lo_rows + 4 * LDS_T));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// 64 x 64 per wave over one [64][128] tile pair: lane l = 16 g + j addresses the 4-column piece (j & 3) of row (j >> 2) in
+// the block of columns 16 (g & 1) .. +15 and contraction rows 8 (g >> 1) .. ; it receives column l & 31, rows 8 (l >> 5) ..+7,
+// which is the operand layout of v_mfma_f32_32x32x16_bf16.
+__device__ __forceinline__ void mma_tile16t(const __bf16* As, const __bf16* Bs, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+    const int g = lane >> 4, j = lane & 15;
+    const int off = ((j >> 2) + 8 * (g >> 1)) * LDS_T + 4 * (j & 3) + 16 * (g & 1);
+    const __bf16* ap = As + off + wm * 64;
+    const __bf16* bp = Bs + off + wn * 64;
+    constexpr int NKS = BKT / 16;
+    bf16x8 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[0][i] = tr_read8(ap + i * 32);
+        b[0][i] = tr_read8(bp + i * 32);
+    }
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < NKS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[nxt][i] = tr_read8(ap + (ks + 1) * 16 * LDS_T + i * 32);
+                b[nxt][i] = tr_read8(bp + (ks + 1) * 16 * LDS_T + i * 32);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][jj], acc[i][jj], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// fp32 sums of the 8 bf16 columns of a staged piece, over the thread's four rows
+__device__ __forceinline__ void colsum8(float (&s)[8], const TileT& x) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned u = x.v[j][w];
+            s[2 * w] += __builtin_bit_cast(float, u << 16);
+            s[2 * w + 1] += __builtin_bit_cast(float, u & 0xffff0000u);
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm16s_tn_kernel(RowsH A, RowsH Bd, float* __restrict__ P, float* __restrict__ Pc, long M,
+                                                         int K1, int N, int tiles_n, int ntiles, long rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem16t[];       // 4 tiles of 64 x LDS_T bf16 (80 KB at stride 160)
+    __bf16 (*As)[TILE_T] = reinterpret_cast<__bf16 (*)[TILE_T]>(smem16t);
+    __bf16 (*Bs)[TILE_T] = reinterpret_cast<__bf16 (*)[TILE_T]>(smem16t + 2 * TILE_T * sizeof(__bf16));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x % ntiles;                              // consecutive ids = the tiles of one M slice (L2 reuse)
+    const int split = blockIdx.x / ntiles;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int i0 = tk * BT, n0 = tn * BT;
+    const long mbeg = (long)split * rows_per_split;
+    long mend = mbeg + rows_per_split;
+    if (mend > M) mend = M;
+
+    KOuterRowsS la, lb;
+    la.init(A, mbeg, i0, K1, tid);
+    lb.init(Bd, mbeg, n0, N, tid);
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool do_csum = (Pc != nullptr) && tk == 0;
+
+    TileT ra[2], rb[2];                                                // register ring of depth 2
+    const int nk = (int)((mend - mbeg + BKT - 1) / BKT);
+    auto fetch = [&](TileT& a, TileT& b, int t) {
+        if (t + 1 < nk) { la.load<false>(a, mend); lb.load<false>(b, mend); }
+        else { la.load<true>(a, mend); lb.load<true>(b, mend); }
+    };
+    auto stage = [&](int buf, const TileT& a, const TileT& b) {
+        if (do_csum) colsum8(csum, b);                                 // every staged row exactly once
+        la.store(As[buf], a);
+        lb.store(Bs[buf], b);
+    };
+    if (nk > 0) {
+        fetch(ra[0], rb[0], 0);
+        if (nk > 1) fetch(ra[1], rb[1], 1);
+        stage(0, ra[0], rb[0]);
+    }
+    __syncthreads();
+#define LBX16T_STEP(PAR)                                                  \
+    {                                                                     \
+        if (kt + 2 < nk) fetch(ra[PAR], rb[PAR], kt + 2);                 \
+        mma_tile16t(As[PAR], Bs[PAR], wm, wn, lane, acc);                 \
+        if (kt + 1 < nk) stage((PAR) ^ 1, ra[(PAR) ^ 1], rb[(PAR) ^ 1]);  \
+        __syncthreads();                                                  \
+        ++kt;                                                             \
+    }
+    for (int kt = 0; kt < nk;) {
+        LBX16T_STEP(0)
+        if (kt < nk) LBX16T_STEP(1)
+    }
+#undef LBX16T_STEP
+    float* Pd = P + (long)split * K1 * N;
+    const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int col = n0 + wn * 64 + bj * 32 + l;
+        if (col >= N) continue;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
+            }
+    }
+    if (do_csum) {
+        // threads with the same column piece: lanes pc + 16 {0..3} of every wave -- fixed-order butterfly, then the four
+        // waves through LDS (free after the K loop's last barrier) in wave order
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            csum[c] += __shfl_xor(csum[c], 16, 64);
+            csum[c] += __shfl_xor(csum[c], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(smem16t);               // [4 waves][128 columns]
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) red[wave * BT + 8 * lane + c] = csum[c];
+        }
+        __syncthreads();
+        if (tid < BT && n0 + tid < N)
+            Pc[(long)split * N + n0 + tid] = (red[tid] + red[BT + tid]) + (red[2 * BT + tid] + red[3 * BT + tid]);
+    }
+}
+
 // elementwise fp32 -> bf16 (round-to-nearest-even), 4 values per thread when aligned
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
     const long n4 = n >> 2;
@@ -625,7 +833,7 @@ struct Tn16Plan {
     long rows_per_split;
 };
 
-Tn16Plan plan_tn16(long M, int K1, int N) {
+Tn16Plan plan_tn16(long M, int K1, int N, int BK = 32) {
     const long tiles = lbx_cdiv(K1, BT) * lbx_cdiv(N, BT);
     long target = 2 * NUM_CU;
     if (const char* e = getenv("LIDBOX_GEMM16_TN_SLOTS")) { const long v = atol(e); if (v >= 1) target = v; }   // tuning aid
@@ -759,6 +967,57 @@ extern "C" int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb
                                     lidbox_stream_t stream) {
     if (validate_rows_call(__func__, A16, (const float*)B16, ldb, C, K, N, epilogue, aux, K)) return LIDBOX_E_INVALID;
     return launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N) {
+    if (M <= 0 || K1 <= 0 || N <= 0) return 0;
+    const Tn16Plan pl = plan_tn16(M, K1, N, BKT);
+    return ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+}
+
+extern "C" int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* Cm, long ldc, int K1, int N, int accumulate,
+                                    float* bias_grad, void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
+    if (check_rows(__func__, A16.base, A16.batch_stride, A16.row_stride, A16.batch, A16.rows_per_batch)) return LIDBOX_E_INVALID;
+    if (check_rows(__func__, B16.base, B16.batch_stride, B16.row_stride, B16.batch, B16.rows_per_batch)) return LIDBOX_E_INVALID;
+    LBX_ARG(Cm && K1 >= 1 && N >= 1 && ldc >= N, "C != NULL, K1, N >= 1, ldc >= N");
+    const long M = (long)A16.batch * A16.rows_per_batch;
+    LBX_ARG(M == (long)B16.batch * B16.rows_per_batch, "A and B row counts differ");
+    LBX_ARG(M >= 1, "M >= 1");
+    auto ok16 = [](const lidbox_rows_t& r) {
+        return aligned16(r.base) && r.row_stride % 8 == 0 && (r.batch == 1 || r.batch_stride % 8 == 0);
+    };
+    // a row is read as whole 16-byte pieces: the last piece of a width that is not a multiple of 8 must still lie inside the
+    // row's stride (a shadow padded to 8-element rows); what it holds beyond the width only reaches outputs never stored
+    auto width_ok = [](const lidbox_rows_t& r, int w) { return w % 8 == 0 || r.row_stride >= (long)((w + 7) / 8) * 8; };
+    LBX_ARG(ok16(A16) && ok16(B16) && width_ok(A16, K1) && width_ok(B16, N) && aligned16(workspace),
+            "bf16-storage operands need 16-byte aligned bases, row and batch strides (in bf16 elements) that are multiples of 8, and "
+            "K1 / N that are multiples of 8 or rows padded to one");
+    const Tn16Plan pl = plan_tn16(M, K1, N, BKT);
+    const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+    LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_bf16s_tn_workspace)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_bytes = 4 * (size_t)TILE_T * sizeof(__bf16);
+    static bool lds_attr_set = false;
+    if (lds_bytes > 65536 && !lds_attr_set) {
+        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        lds_attr_set = true;
+    }
+    const int tiles_n = (int)lbx_cdiv(N, BT);
+    const int ntiles = (int)(lbx_cdiv(K1, BT) * tiles_n);
+    float* P = (float*)workspace;
+    float* Pc = bias_grad ? P + (size_t)pl.splits * K1 * N : nullptr;
+    const RowsH Ah{(const __bf16*)A16.base, A16.batch_stride, A16.row_stride, A16.batch, A16.rows_per_batch};
+    const RowsH Bh{(const __bf16*)B16.base, B16.batch_stride, B16.row_stride, B16.batch, B16.rows_per_batch};
+    hipLaunchKernelGGL(gemm16s_tn_kernel, dim3((unsigned)(ntiles * pl.splits)), dim3(256), lds_bytes, st, Ah, Bh, P, Pc, M, K1, N,
+                       tiles_n, ntiles, pl.rows_per_split);
+    LBX_LAUNCH_OK();
+    const long n = (long)K1 * N;
+    long g = lbx_cdiv(n + N, 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, (const float*)Pc, pl.splits, n, N,
+                       Cm, ldc, accumulate, bias_grad);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
 }
 
 extern "C" int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream) {

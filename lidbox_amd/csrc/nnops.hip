@@ -17,6 +17,9 @@
 
 namespace {
 
+// bfloat16 bits of x, round-to-nearest-even (what v_cvt_pk_bf16_f32 / the GEMM epilogue shadows produce)
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+
 constexpr float STDDEV_SQRT_MIN_CLIP = 1e-10f;    // xvector.py:22
 
 // grid (ceil(C / (16*V)), B); 256 threads = 16 channel groups of V channels x 16 time groups.  Two passes over the
@@ -167,7 +170,8 @@ void launch_pool_fwd(const float* x, int B, int T, int C, long bs, long rs, floa
 template <bool STATS, int V>
 __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
                                                       const float* __restrict__ dout, int T, int C, long bs, long rs,
-                                                      int relu_mask, float* __restrict__ dx) {
+                                                      int relu_mask, float* __restrict__ dx, unsigned short* __restrict__ dx16,
+                                                      long bs16, long rs16) {
     const int c = (blockIdx.x * 64 + threadIdx.x) * V;
     if (c >= C) return;
     const long b = blockIdx.y;
@@ -210,6 +214,10 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 #pragma unroll
             for (int v = 0; v < V; ++v) dp[(long)t * rs + v] = g[v];
         }
+        if (dx16) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) dx16[b * bs16 + (long)t * rs16 + c + v] = bf16_bits(g[v]);
+        }
     }
 }
 
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 template <bool STATS, int R>
 __global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
                                                            const float* __restrict__ dout, int T, int C, long bs, long rs,
-                                                           int relu_mask, float* __restrict__ dx) {
+                                                           int relu_mask, float* __restrict__ dx, unsigned short* __restrict__ dx16,
+                                                           long bs16, long rs16) {
     const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
     if (c >= C) return;
     const long b = blockIdx.y;
@@ -261,28 +270,36 @@ __global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const float* __restri
             g[j] = STATS ? fmaf(k[j], xv[j] - mean[j], a[j]) : a[j];
             if (relu_mask && !(xv[j] > 0.f)) g[j] = 0.f;
         }
-        if (t0 + i < T) *reinterpret_cast<float4*>(dp + (long)(t0 + i) * rs) = make_float4(g[0], g[1], g[2], g[3]);
+        if (t0 + i < T) {
+            *reinterpret_cast<float4*>(dp + (long)(t0 + i) * rs) = make_float4(g[0], g[1], g[2], g[3]);
+            if (dx16) {                                          // bf16 shadow (8-byte store: c, the strides and the base are multiples of 4)
+                const unsigned lo = bf16_bits(g[0]) | ((unsigned)bf16_bits(g[1]) << 16);
+                const unsigned hi = bf16_bits(g[2]) | ((unsigned)bf16_bits(g[3]) << 16);
+                *reinterpret_cast<uint2*>(dx16 + b * bs16 + (long)(t0 + i) * rs16 + c) = make_uint2(lo, hi);
+            }
+        }
     }
 }
 
 template <bool STATS>
 void launch_pool_bwd(const float* x, const float* pooled, const float* dout, int B, int T, int C, long bs, long rs,
-                     int relu_mask, float* dx, hipStream_t st) {
-    const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0;
+                     int relu_mask, float* dx, hipStream_t st, unsigned short* dx16 = nullptr, long bs16 = 0, long rs16 = 0) {
+    const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0 &&
+                     (dx16 == nullptr || (bs16 % 4 == 0 && rs16 % 4 == 0 && (((uintptr_t)dx16) & 7) == 0));
     // short utterances only (the x-vector pools 33 frames): at T = 99 (the CNN) the row loop below measured faster
     if (vec && T >= 1 && T <= 48 && ((((uintptr_t)pooled) | ((uintptr_t)dout)) & 15) == 0) {
         constexpr int R = 12;
         dim3 grid((unsigned)lbx_cdiv(C, 256), (unsigned)B, (unsigned)lbx_cdiv(T, R));
-        hipLaunchKernelGGL((pool_bwd_rows_kernel<STATS, R>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx);
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<STATS, R>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx, dx16, bs16, rs16);
         return;
     }
     const int V = vec ? 4 : 1;
     unsigned zs = (unsigned)(T < 8 ? T : 8);                 // time splits: more waves for the small-batch case
     dim3 grid((unsigned)lbx_cdiv(C, 64 * V), (unsigned)B, zs);
     if (vec)
-        hipLaunchKernelGGL((pool_bwd_kernel<STATS, 4>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx);
+        hipLaunchKernelGGL((pool_bwd_kernel<STATS, 4>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx, dx16, bs16, rs16);
     else
-        hipLaunchKernelGGL((pool_bwd_kernel<STATS, 1>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx);
+        hipLaunchKernelGGL((pool_bwd_kernel<STATS, 1>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx, dx16, bs16, rs16);
 }
 
 // one wave per row
@@ -629,6 +646,19 @@ extern "C" int lidbox_stats_pool_bwd(const float* x, const float* pooled, const 
     if (total == 0) return LIDBOX_OK;
     LBX_ARG(B <= 65535, "B <= 65535");
     launch_pool_bwd<true>(x, pooled, dout, B, T, C, bs, rs, relu_mask, dx, (hipStream_t)stream);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_stats_pool_bwd_shadow(const float* x, const float* pooled, const float* dout, int B, int T, int C, long bs,
+                                            long rs, int relu_mask, float* dx, void* dx16, long bs16, long rs16,
+                                            lidbox_stream_t stream) {
+    LBX_ARG(x && pooled && dout && dx && dx16 && T >= 1 && C >= 1, "pointers != NULL; T, C >= 1");
+    LBX_ARG(rs16 >= C && (B <= 1 || bs16 >= (long)(T - 1) * rs16 + C) && (((uintptr_t)dx16) & 1) == 0, "shadow strides cover the rows");
+    const long total = (long)B * T * C;
+    if (total == 0) return LIDBOX_OK;
+    LBX_ARG(B <= 65535, "B <= 65535");
+    launch_pool_bwd<true>(x, pooled, dout, B, T, C, bs, rs, relu_mask, dx, (hipStream_t)stream, (unsigned short*)dx16, bs16, rs16);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -138,12 +138,16 @@ class _Workspace:
         # A layer takes the shadow path when its operand strides / K are multiples of 8 bf16 elements.
         self.act16 = [None] * len(self.act)
         self.dact16 = [None] * len(self.act)
+        self.d16_fresh = set()               # indices j whose dact16[j] currently holds bf16(dact[j]) (reset by every backward pass)
         if model.bf16_storage:
             for i, c in enumerate(convs):
                 if model.shadow_fwd_ok(i):
                     self.act16[i] = torch.zeros(self.act[i].shape, dtype=torch.bfloat16, device=dev)
-                if i >= 1 and model.shadow_dgrad_ok(i):
-                    self.dact16[i + 1] = torch.zeros(self.act[i + 1].shape, dtype=torch.bfloat16, device=dev)
+                if (i >= 1 and model.shadow_dgrad_ok(i)) or model.shadow_wgrad_ok(i):
+                    # rows padded to 8 elements when the channel count is not a multiple of 8 (frame5's 1500): wgrad reads
+                    # whole 16-byte pieces; the pad columns stay zero
+                    shp = self.act[i + 1].shape
+                    self.dact16[i + 1] = torch.zeros((shp[0], shp[1], (shp[2] + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
         fe = model.frontend
         if fe:
             # 2-D front-end (xvector_2d.py:69-73): model input [B, T, F]; layer i: a = relu(conv) [B*T*F_i+1, C_i+1] dense,
@@ -195,6 +199,8 @@ class _Workspace:
                 kk = cin if c.d > 1 else c.k * cin               # dilated layers run one tap per GEMM
                 ws_bytes = max(ws_bytes, g.tn_workspace(M, kk, c.filters),
                                g.rows_workspace(M, c.filters, kk), g.rows_workspace(M, kk, c.filters))
+                if model.bf16_storage and model.shadow_wgrad_ok(i):
+                    ws_bytes = max(ws_bytes, nv.lib.lidbox_gemm_bf16s_tn_workspace(M, kk, c.filters))
             cin = c.filters
         if att is not None and B * self.Ts[-1] > 0:
             n = B * self.Ts[-1]
@@ -379,6 +385,11 @@ class SequentialTDNN:
         c = self.convs[i]
         return c.d == 1 and self._cin(i) % 8 == 0
 
+    def shadow_wgrad_ok(self, i):
+        """wgrad of conv i can read bf16 shadows of its input windows and of its output gradient"""
+        c = self.convs[i]
+        return c.d == 1 and self._cin(i) % 8 == 0 and c.filters % 4 == 0
+
     def shadow_dgrad_ok(self, i):
         """dgrad of conv i can read the bf16 shadow of its output gradient: C_out and C_in multiples of 8"""
         c = self.convs[i]
@@ -399,9 +410,17 @@ class SequentialTDNN:
 
     @staticmethod
     def _rows16(view_rows, t32, t16):
-        """the rows descriptor `view_rows` of fp32 tensor t32, re-based onto its bf16 shadow t16 (same element offsets)"""
+        """the rows descriptor `view_rows` of fp32 tensor t32 [B, R, C], re-based onto its bf16 shadow t16: same element
+        offsets, or -- for a shadow whose rows are padded to C16 > C -- the same (row, column) positions"""
         off = (view_rows.base - t32.data_ptr()) // 4
-        return nv.Rows(t16.data_ptr() + 2 * off, view_rows.batch_stride, view_rows.row_stride, view_rows.batch, view_rows.rows_per_batch)
+        C, C16 = t32.shape[-1], t16.shape[-1]
+        if C16 == C:
+            return nv.Rows(t16.data_ptr() + 2 * off, view_rows.batch_stride, view_rows.row_stride, view_rows.batch,
+                           view_rows.rows_per_batch)
+        assert view_rows.batch_stride % C == 0 and view_rows.row_stride % C == 0
+        r, col = divmod(off, C)
+        return nv.Rows(t16.data_ptr() + 2 * (r * C16 + col), view_rows.batch_stride // C * C16, view_rows.row_stride // C * C16,
+                       view_rows.batch, view_rows.rows_per_batch)
 
     def _sp(self, name):
         off, _ = self.state_layout[name]
@@ -660,7 +679,13 @@ class SequentialTDNN:
         T, C = last.shape[1], last.shape[2]
         relu_last = 1 if self.convs[-1].relu else 0
         pool_mask = relu_last if att is None else 0          # with attention the pooling input is not a ReLU output
-        if self.pool == "stats":
+        d16 = ws.dact16[-1] if att is None else None
+        if self.pool == "stats" and d16 is not None and B * T > 0:
+            # the last conv's output gradient and its bf16 shadow (rows possibly padded) in one pass
+            nv.check(lib.lidbox_stats_pool_bwd_shadow(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
+                                                      pool_mask, nv.ptr(dlast), nv.ptr(d16), T * d16.shape[2], d16.shape[2], st))
+            ws.d16_fresh.add(len(self.convs))
+        elif self.pool == "stats":
             nv.check(lib.lidbox_stats_pool_bwd(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
                                                pool_mask, nv.ptr(dlast), st))
         else:
@@ -704,8 +729,23 @@ class SequentialTDNN:
             self._backward_dilated(ws, i, dy)
             return
         A_rows = self._conv_rows_in(ws, i)
-        self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
-            A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
+        # bf16 shadow of dact[i+1]: written by conv i+1's dgrad epilogues / the pooling backward, or converted here when it
+        # came from a fp32-source launch (same-layout shadows only)
+        dy16 = ws.dact16[i + 1] if self.bf16_storage else None
+        if dy16 is not None and (i + 1) not in ws.d16_fresh:
+            if dy16.shape == ws.dact[i + 1].shape:
+                nv.check(lib.lidbox_f32_to_bf16(nv.ptr(ws.dact[i + 1]), nv.ptr(dy16), ws.dact[i + 1].numel(), st))
+                ws.d16_fresh.add(i + 1)
+            else:
+                dy16 = None
+        if dy16 is not None and ws.act16[i] is not None and self.shadow_wgrad_ok(i):
+            # wgrad on the shadows (transpose-read operands, half the bytes of the fp32-source kernel)
+            A16, B16 = self._rows16(A_rows, ws.act[i], ws.act16[i]), self._rows16(dy, ws.dact[i + 1], dy16)
+            self._launch_wgrad(ws, lambda w, n, s_: nv.check(lib.lidbox_gemm_bf16s_tn(
+                A16, B16, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
+        else:
+            self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
+                A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
         if i == 0 and not self.frontend:
             return
         # dgrad into dact[i].  Window t touches padded rows [t*s, t*s+k).  Group g = taps
@@ -723,12 +763,10 @@ class SequentialTDNN:
         ngroups = (c.k + c.s - 1) // c.s
         # bf16-storage dgrad: A = bf16 shadow of dact[i+1] (written by conv i+1's dgrad epilogues, or converted here when
         # it came from the pooling backward / a fp32-source launch), B = the Keras kernel rows of the tap group in flat16
-        use16 = self.bf16_storage and ws.dact16[i + 1] is not None and self.shadow_dgrad_ok(i)
+        use16 = self.bf16_storage and dy16 is not None and self.shadow_dgrad_ok(i)
         d16 = ws.dact16[i] if use16 else None                   # shadow of this dgrad's output, for conv i-1's dgrad
         if use16:
-            fresh = getattr(ws, "d16_fresh", set())
-            if (i + 1) not in fresh:
-                nv.check(lib.lidbox_f32_to_bf16(nv.ptr(ws.dact[i + 1]), nv.ptr(ws.dact16[i + 1]), ws.dact[i + 1].numel(), st))
+            fresh = ws.d16_fresh
             if d16 is not None:
                 # rows no tap group writes must read as zero in the shadow too
                 if c.k < c.s:

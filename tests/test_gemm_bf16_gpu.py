@@ -277,3 +277,82 @@ def test_bf16_storage_gemm_implicit_rows_and_errors():
     with pytest.raises(ValueError):                          # row stride not a multiple of 8 elements
         nv.check(nv.lib.lidbox_gemm_bf16s_nt(nv.Rows(x16.data_ptr(), (pad + T) * C, 12, Bn, To), nv.ptr(wT16), k * C,
                                              _rows(out, To * Co, Co, Bn, To), None, k * C, Co, nv.EPI_NONE, None, None, 0, st))
+
+
+@pytest.mark.parametrize("M,K1,N", [(4096, 200, 512), (1000, 1536, 512), (256, 3000, 512), (50, 8, 8), (8448, 512, 1504),
+                                    (37, 136, 264), (64, 128, 128), (65, 128, 128), (25344, 1536, 512)])
+def test_bf16_storage_gemm_tn_and_bias_grad(M, K1, N):
+    """lidbox_gemm_bf16s_tn (wgrad on bf16 shadows, transpose-read operands): the float64 product of the stored bf16
+    values to fp32 summation round-off; accumulate; deterministic; bias gradient = fp32 column sums of the shadow"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + N)
+    A, B = rng.standard_normal((M, K1)), rng.standard_normal((M, N))
+    # a transpose- / permutation-detecting pattern on top of the noise: every row and column gets its own scale
+    A *= (1.0 + 0.01 * np.arange(K1))[None, :]
+    B *= (1.0 + 0.013 * np.arange(N))[None, :]
+    ref = _bf16(A).T @ _bf16(B)
+    a16, b16 = _dev(A).bfloat16(), _dev(B).bfloat16()
+    c = torch.full((K1, N), 3.0, device="cuda")
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, N)
+    ws = _ws(wsb)
+    ra, rb = nv.Rows(a16.data_ptr(), 0, K1, 1, M), nv.Rows(b16.data_ptr(), 0, N, 1, M)
+    nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(c), N, K1, N, 0, None, nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), ref)
+    nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(c), N, K1, N, 1, None, nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), 2 * ref)
+    c2, c3 = torch.empty_like(c), torch.empty_like(c)
+    nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(c2), N, K1, N, 0, None, nv.ptr(ws), wsb, st))
+    bg = torch.full((N,), 9.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(c3), N, K1, N, 0, nv.ptr(bg), nv.ptr(ws), wsb, st))
+    assert torch.equal(c2, c3)
+    _close(bg.cpu().numpy(), _bf16(B).sum(axis=0), 1e-5)
+    # the fp32-source wgrad kernel on the same (already bf16-representable) values agrees to summation order
+    a32, b32 = a16.float(), b16.float()
+    wsb2 = nv.lib.lidbox_gemm_bf16_tn_workspace(M, K1, N)
+    ws2 = _ws(wsb2)
+    c_old = torch.empty_like(c)
+    nv.check(nv.lib.lidbox_gemm_bf16_tn(_rows(a32, 0, K1, 1, M), _rows(b32, 0, N, 1, M), nv.ptr(c_old), N, K1, N, 0, None,
+                                        nv.ptr(ws2), wsb2, st))
+    _close(c2.cpu().numpy(), c_old.cpu().double().numpy(), rel=1e-5)
+
+
+@pytest.mark.parametrize("Bn,T,C,k,s_,Co", [(5, 21, 16, 3, 2, 24), (3, 7, 8, 5, 1, 8), (40, 3, 32, 1, 1, 136), (2, 400, 64, 3, 3, 128)])
+def test_bf16_storage_gemm_tn_implicit_rows_and_errors(Bn, T, C, k, s_, Co):
+    """wgrad of a strided causal Conv1D over bf16 shadows: overlapping input windows [B, pad + T, C] (implicit rows) against
+    the output-gradient shadow [B, To, Co]; utterances shorter than the 16-row load stride included"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(Bn * 100 + T)
+    pad = k - 1
+    x = np.zeros((Bn, pad + T, C))
+    x[:, pad:] = rng.standard_normal((Bn, T, C))
+    To = (T - 1) // s_ + 1
+    dy = rng.standard_normal((Bn, To, Co))
+    idx = np.arange(To)[:, None] * s_ + np.arange(k)[None, :]
+    col = _bf16(x)[:, idx, :].reshape(Bn * To, k * C)
+    ref = col.T @ _bf16(dy).reshape(Bn * To, Co)
+    st = nv.current_stream()
+    x16, dy16 = _dev(x).bfloat16(), _dev(dy).bfloat16()
+    M, K1 = Bn * To, k * C
+    wsb = nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, Co)
+    ws = _ws(wsb)
+    dW = torch.full((K1, Co), -1.0, device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    ra = nv.Rows(x16.data_ptr(), (pad + T) * C, s_ * C, Bn, To)
+    rb = nv.Rows(dy16.data_ptr(), To * Co, Co, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws), wsb, st))
+    _close(dW.cpu().numpy(), ref)
+    _close(db.cpu().numpy(), _bf16(dy).reshape(M, Co).sum(axis=0), 1e-5)
+    # N not a multiple of 8 is fine when the rows are padded to one (the last 16-byte piece stays inside the row) ...
+    dW4 = torch.full((K1, Co - 4), -1.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW4), Co - 4, K1, Co - 4, 0, nv.ptr(db), nv.ptr(ws), wsb, st))
+    _close(dW4.cpu().numpy(), ref[:, :Co - 4])
+    _close(db.cpu().numpy()[:Co - 4], _bf16(dy).reshape(M, Co).sum(axis=0)[:Co - 4], 1e-5)
+    with pytest.raises(ValueError):                          # ... and refused when they are not
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, nv.Rows(dy16.data_ptr(), 0, Co - 8, 1, M), nv.ptr(dW), Co, K1, Co - 4, 0, None,
+                                             nv.ptr(ws), wsb, st))
+    with pytest.raises(ValueError):                          # row stride not a multiple of 8 elements
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(nv.Rows(x16.data_ptr(), (pad + T) * C, 12, Bn, To), rb, nv.ptr(dW), Co, K1, Co, 0,
+                                             None, nv.ptr(ws), wsb, st))
+    with pytest.raises(ValueError):                          # workspace too small
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW), Co, K1, Co, 0, None, nv.ptr(ws), 8, st))
