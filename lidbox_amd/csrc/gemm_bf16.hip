@@ -35,6 +35,9 @@
 //   * wgrad's bias gradient (column sums of dY) is accumulated in fp32 from the staged float4
 //     registers BEFORE rounding, so it is bit-for-bit the quantity the fp32 path computes up to
 //     summation order.
+//   * bf16-STORAGE variants further down (gemm16s_rows_kernel, gemm16s_tn_kernel): operands that already are bf16 in HBM
+//     (shadows written by the producing epilogues) go to LDS unchanged; wgrad's row-contracted operands come out of LDS
+//     through ds_read_b64_tr_b16.
 // Requirements (checked, LIDBOX_E_INVALID otherwise): 16-byte aligned bases, K (K1) and N multiples
 // of 4, row/batch strides multiples of 4 -- true of every layer of the x-vector / CNN models.
 // Roofline: MFMA bf16 dense, 2.5 PFLOP/s (MI355X_MICROARCH.md); practical bound = L2->LDS traffic.
