@@ -243,6 +243,17 @@ size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N);
 int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ldc, int K1, int N,
                          int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                          lidbox_stream_t stream);
+/* All bf16 weight shadows of a model in ONE launch (once per train step, after the optimizer): flat16[i] = bf16(flat[i]) for
+ * the n parameters, and for each of the nmats (<= 16) listed row-major [rows][cols] matrices at flat + offset its
+ * transpose [cols][rows] in bf16 at dst (a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand the
+ * forward GEMM reads). */
+typedef struct {
+    long  offset;       /* of the matrix inside flat, in floats */
+    int   rows, cols;
+    void* dst;          /* bf16 [cols][rows] */
+} lidbox_weight_transpose_t;
+int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_transpose_t* mats, int nmats,
+                                lidbox_stream_t stream);
 /* dst[i] = bf16(src[i]) (round-to-nearest-even), n elements; dst[c][r] = bf16(src[r][c]) for an R x C matrix */
 int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream);
 int lidbox_transpose_f32_to_bf16(const float* src, int R, int C, long ld_src, void* dst, long ld_dst,

@@ -806,6 +806,49 @@ __global__ __launch_bounds__(256) void transpose_f32_to_bf16_kernel(const float*
     }
 }
 
+// one launch for all bf16 weight shadows of a model: blocks [0, conv_blocks) convert the flat parameter vector elementwise,
+// the others each transpose one 32 x 32 tile of one listed [R][C] matrix of it into its own [C][R] bf16 buffer
+constexpr int MAX_WT = 16;
+struct WeightTransposes {
+    long src_off[MAX_WT];               // offset of the matrix inside the flat fp32 vector
+    unsigned short* dst[MAX_WT];
+    int R[MAX_WT], C[MAX_WT];
+    int tile_end[MAX_WT];               // running total of 32 x 32 tiles up to and including matrix i
+    int n;
+};
+
+__global__ __launch_bounds__(256) void refresh_bf16_weights_kernel(const float* __restrict__ flat, unsigned short* __restrict__ flat16,
+                                                                   long n, int conv_blocks, WeightTransposes w) {
+    __shared__ float t[32][33];
+    if ((int)blockIdx.x < conv_blocks) {
+        const long n4 = n >> 2;
+        const long stride = (long)conv_blocks * blockDim.x;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+            *reinterpret_cast<bf16x4*>(flat16 + 4 * i) = to_bf16(*reinterpret_cast<const f32x4*>(flat + 4 * i));
+        for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+            flat16[i] = __builtin_bit_cast(unsigned short, (__bf16)flat[i]);
+        return;
+    }
+    int tile = (int)blockIdx.x - conv_blocks, m = 0;
+    while (m + 1 < w.n && tile >= w.tile_end[m]) ++m;
+    if (m > 0) tile -= w.tile_end[m - 1];
+    const int R = w.R[m], C = w.C[m];
+    const float* src = flat + w.src_off[m];
+    unsigned short* dst = w.dst[m];
+    const int tiles_c = (C + 31) / 32;
+    const int c0 = (tile % tiles_c) * 32, r0 = (tile / tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        t[j][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) dst[(long)c * R + r] = __builtin_bit_cast(unsigned short, (__bf16)t[tx][j]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1030,6 +1073,32 @@ extern "C" int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_st
     long g = lbx_cdiv(n / 4 + 1, 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_transpose_t* mats, int nmats,
+                                          lidbox_stream_t stream) {
+    LBX_ARG(flat && flat16 && n >= 0 && nmats >= 0 && nmats <= MAX_WT && (nmats == 0 || mats), "flat, flat16 != NULL; 0 <= nmats <= 16");
+    LBX_ARG(aligned16(flat) && (((uintptr_t)flat16) & 7) == 0, "flat 16-byte, flat16 8-byte aligned");
+    WeightTransposes w{};
+    int tiles = 0;
+    for (int i = 0; i < nmats; ++i) {
+        LBX_ARG(mats[i].dst && mats[i].rows >= 1 && mats[i].cols >= 1 && mats[i].offset >= 0 &&
+                mats[i].offset + (long)mats[i].rows * mats[i].cols <= n, "every matrix lies inside the flat vector");
+        w.src_off[i] = mats[i].offset;
+        w.dst[i] = (unsigned short*)mats[i].dst;
+        w.R[i] = mats[i].rows;
+        w.C[i] = mats[i].cols;
+        tiles += (int)(lbx_cdiv(mats[i].rows, 32) * lbx_cdiv(mats[i].cols, 32));
+        w.tile_end[i] = tiles;
+    }
+    w.n = nmats;
+    if (n == 0 && tiles == 0) return LIDBOX_OK;
+    long cb = lbx_cdiv(n / 4 + 1, 256);
+    if (cb > 1024) cb = 1024;
+    hipLaunchKernelGGL(refresh_bf16_weights_kernel, dim3((unsigned)(cb + tiles)), dim3(256), 0, (hipStream_t)stream, flat,
+                       (unsigned short*)flat16, n, (int)cb, w);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

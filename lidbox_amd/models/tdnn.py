@@ -396,13 +396,17 @@ class SequentialTDNN:
         return c.d == 1 and c.filters % 8 == 0 and self._cin(i) % 8 == 0
 
     def _refresh_bf16_weights(self):
-        st = nv.current_stream()
-        nv.check(nv.lib.lidbox_f32_to_bf16(nv.ptr(self.flat), nv.ptr(self.flat16), self.num_flat, st))
-        for i, c in enumerate(self.convs):
-            if self.w16t[i] is not None:
-                K = c.k * self._cin(i)
-                nv.check(nv.lib.lidbox_transpose_f32_to_bf16(self._p(c.name + ".W"), K, c.filters, c.filters,
-                                                             nv.ptr(self.w16t[i]), K, st))
+        """flat16 and the transposed conv kernels from the fp32 master copy, one launch"""
+        mats = getattr(self, "_w16t_descs", None)
+        if mats is None:
+            items = [(self.layout[c.name + ".W"][0], c.k * self._cin(i), c.filters, self.w16t[i])
+                     for i, c in enumerate(self.convs) if self.w16t[i] is not None]
+            mats = (nv.WeightTranspose * max(1, len(items)))()
+            for j, (off, K, N, dst) in enumerate(items):
+                mats[j] = nv.WeightTranspose(off, K, N, dst.data_ptr())
+            self._w16t_descs, self._w16t_n = mats, len(items)
+        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(self.flat), nv.ptr(self.flat16), self.num_flat, mats, self._w16t_n,
+                                                    nv.current_stream()))
 
     def _p16(self, name):
         off, _ = self.layout[name]

@@ -356,3 +356,30 @@ def test_bf16_storage_gemm_tn_implicit_rows_and_errors(Bn, T, C, k, s_, Co):
                                              None, nv.ptr(ws), wsb, st))
     with pytest.raises(ValueError):                          # workspace too small
         nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW), Co, K1, Co, 0, None, nv.ptr(ws), 8, st))
+
+
+def test_refresh_bf16_weights_one_launch():
+    """flat -> flat16 plus the transposed bf16 copies of listed matrices inside it (the per-step weight-shadow refresh)"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(5)
+    shapes = [(200, 512), (1536, 512), (37, 5), (512, 1500)]
+    offs, off = [], 3 * 4                                       # matrices start on 4-float boundaries inside the flat vector
+    for r, c in shapes:
+        offs.append(off)
+        off += (r * c + 3) // 4 * 4 + 8
+    n = off + 5
+    flat = _dev(rng.standard_normal(n))
+    flat16 = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    dsts = [torch.zeros((c, r), dtype=torch.bfloat16, device="cuda") for r, c in shapes]
+    mats = (nv.WeightTranspose * len(shapes))()
+    for j, ((r, c), o, d) in enumerate(zip(shapes, offs, dsts)):
+        mats[j] = nv.WeightTranspose(o, r, c, d.data_ptr())
+    st = nv.current_stream()
+    nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(shapes), st))
+    assert torch.equal(flat16, flat.bfloat16())
+    for (r, c), o, d in zip(shapes, offs, dsts):
+        assert torch.equal(d, flat[o:o + r * c].reshape(r, c).t().bfloat16())
+    nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, None, 0, st))      # no matrices: convert only
+    with pytest.raises(ValueError):                              # a matrix that sticks out of the vector
+        mats[0] = nv.WeightTranspose(n - 10, 200, 512, dsts[0].data_ptr())
+        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(shapes), st))
