@@ -244,15 +244,18 @@ int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ld
                          int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                          lidbox_stream_t stream);
 /* All bf16 weight shadows of a model in ONE launch (once per train step, after the optimizer): flat16[i] = bf16(flat[i]) for
- * the n parameters, and for each of the nmats (<= 16) listed row-major [rows][cols] matrices at flat + offset its
- * transpose [cols][rows] in bf16 at dst (a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand the
- * forward GEMM reads). */
+ * the n parameters, and for each listed row-major [rows][cols] matrix at flat + offset a bf16 image at dst with its own
+ * leading dimension: transposed ([cols][rows]: a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand
+ * the forward GEMM reads) or as it is (rows padded to 8 elements, or several taps' [C_in][C_out] blocks side by side: the
+ * operand images dgrad reads).  More than 48 matrices take further launches. */
 typedef struct {
     long  offset;       /* of the matrix inside flat, in floats */
     int   rows, cols;
-    void* dst;          /* bf16 [cols][rows] */
-} lidbox_weight_transpose_t;
-int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_transpose_t* mats, int nmats,
+    void* dst;          /* bf16 destination */
+    long  ld_dst;       /* elements between destination rows */
+    int   transpose;    /* 1: dst[c * ld_dst + r] = src[r][c]   0: dst[r * ld_dst + c] = src[r][c] */
+} lidbox_weight_shadow_t;
+int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_shadow_t* mats, int nmats,
                                 lidbox_stream_t stream);
 /* dst[i] = bf16(src[i]) (round-to-nearest-even), n elements; dst[c][r] = bf16(src[r][c]) for an R x C matrix */
 int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream);

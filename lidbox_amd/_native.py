@@ -31,9 +31,10 @@ class Rows(C.Structure):
                 ("batch", C.c_int), ("rows_per_batch", C.c_int)]
 
 
-class WeightTranspose(C.Structure):
-    """lidbox_weight_transpose_t"""
-    _fields_ = [("offset", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("dst", C.c_void_p)]
+class WeightShadow(C.Structure):
+    """lidbox_weight_shadow_t"""
+    _fields_ = [("offset", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("dst", C.c_void_p), ("ld_dst", C.c_long),
+                ("transpose", C.c_int)]
 
 
 def _load():
@@ -116,7 +117,7 @@ _SIGS = {
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),
     "lidbox_gemm_bf16s_nt": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_bf16s_tn_workspace": (_sz, [_i, _i, _i]),
-    "lidbox_refresh_bf16_weights": (_i, [_vp, _vp, _l, C.POINTER(WeightTranspose), _i, _vp]),
+    "lidbox_refresh_bf16_weights": (_i, [_vp, _vp, _l, C.POINTER(WeightShadow), _i, _vp]),
     "lidbox_gemm_bf16s_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
     "lidbox_transpose_f32_to_bf16": (_i, [_vp, _i, _i, _l, _vp, _l, _vp]),

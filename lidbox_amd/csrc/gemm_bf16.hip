@@ -807,18 +807,19 @@ __global__ __launch_bounds__(256) void transpose_f32_to_bf16_kernel(const float*
 }
 
 // one launch for all bf16 weight shadows of a model: blocks [0, conv_blocks) convert the flat parameter vector elementwise,
-// the others each transpose one 32 x 32 tile of one listed [R][C] matrix of it into its own [C][R] bf16 buffer
-constexpr int MAX_WT = 16;
-struct WeightTransposes {
+// the others each handle one 32 x 32 tile of one listed [R][C] matrix of it: written transposed ([C][R]) or as it is, at
+// the destination's own leading dimension (padded / stacked operand images)
+constexpr int MAX_WT = 48;
+struct WeightShadows {
     long src_off[MAX_WT];               // offset of the matrix inside the flat fp32 vector
     unsigned short* dst[MAX_WT];
-    int R[MAX_WT], C[MAX_WT];
-    int tile_end[MAX_WT];               // running total of 32 x 32 tiles up to and including matrix i
+    int R[MAX_WT], C[MAX_WT], ld_dst[MAX_WT];
+    int tile_end[MAX_WT];               // running total of 32 x 32 tiles up to and including matrix i; bit 31 of R: transpose
     int n;
 };
 
 __global__ __launch_bounds__(256) void refresh_bf16_weights_kernel(const float* __restrict__ flat, unsigned short* __restrict__ flat16,
-                                                                   long n, int conv_blocks, WeightTransposes w) {
+                                                                   long n, int conv_blocks, WeightShadows w) {
     __shared__ float t[32][33];
     if ((int)blockIdx.x < conv_blocks) {
         const long n4 = n >> 2;
@@ -832,12 +833,21 @@ __global__ __launch_bounds__(256) void refresh_bf16_weights_kernel(const float* 
     int tile = (int)blockIdx.x - conv_blocks, m = 0;
     while (m + 1 < w.n && tile >= w.tile_end[m]) ++m;
     if (m > 0) tile -= w.tile_end[m - 1];
-    const int R = w.R[m], C = w.C[m];
+    const bool tr = w.R[m] < 0;
+    const int R = w.R[m] & 0x7fffffff, C = w.C[m];
+    const long ld = w.ld_dst[m];
     const float* src = flat + w.src_off[m];
     unsigned short* dst = w.dst[m];
     const int tiles_c = (C + 31) / 32;
     const int c0 = (tile % tiles_c) * 32, r0 = (tile / tiles_c) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (!tr) {
+        for (int j = ty; j < 32; j += 8) {
+            const int r = r0 + j, c = c0 + tx;
+            if (r < R && c < C) dst[(long)r * ld + c] = __builtin_bit_cast(unsigned short, (__bf16)src[(long)r * C + c]);
+        }
+        return;
+    }
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + j, c = c0 + tx;
         t[j][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
@@ -845,7 +855,7 @@ __global__ __launch_bounds__(256) void refresh_bf16_weights_kernel(const float* 
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, r = r0 + tx;
-        if (c < C && r < R) dst[(long)c * R + r] = __builtin_bit_cast(unsigned short, (__bf16)t[tx][j]);
+        if (c < C && r < R) dst[(long)c * ld + r] = __builtin_bit_cast(unsigned short, (__bf16)t[tx][j]);
     }
 }
 
@@ -1077,29 +1087,42 @@ extern "C" int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_st
     return LIDBOX_OK;
 }
 
-extern "C" int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_transpose_t* mats, int nmats,
+extern "C" int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_shadow_t* mats, int nmats,
                                           lidbox_stream_t stream) {
-    LBX_ARG(flat && flat16 && n >= 0 && nmats >= 0 && nmats <= MAX_WT && (nmats == 0 || mats), "flat, flat16 != NULL; 0 <= nmats <= 16");
+    LBX_ARG(flat && flat16 && n >= 0 && nmats >= 0 && (nmats == 0 || mats), "flat, flat16 != NULL; nmats >= 0");
     LBX_ARG(aligned16(flat) && (((uintptr_t)flat16) & 7) == 0, "flat 16-byte, flat16 8-byte aligned");
-    WeightTransposes w{};
-    int tiles = 0;
     for (int i = 0; i < nmats; ++i) {
-        LBX_ARG(mats[i].dst && mats[i].rows >= 1 && mats[i].cols >= 1 && mats[i].offset >= 0 &&
-                mats[i].offset + (long)mats[i].rows * mats[i].cols <= n, "every matrix lies inside the flat vector");
-        w.src_off[i] = mats[i].offset;
-        w.dst[i] = (unsigned short*)mats[i].dst;
-        w.R[i] = mats[i].rows;
-        w.C[i] = mats[i].cols;
-        tiles += (int)(lbx_cdiv(mats[i].rows, 32) * lbx_cdiv(mats[i].cols, 32));
-        w.tile_end[i] = tiles;
+        const lidbox_weight_shadow_t& m = mats[i];
+        LBX_ARG(m.dst && m.rows >= 1 && m.cols >= 1 && m.offset >= 0 && m.offset + (long)m.rows * m.cols <= n &&
+                m.ld_dst >= (m.transpose ? m.rows : m.cols) && m.ld_dst <= 0x7fffffffL,
+                "every matrix lies inside the flat vector and ld_dst covers a destination row");
     }
-    w.n = nmats;
-    if (n == 0 && tiles == 0) return LIDBOX_OK;
     long cb = lbx_cdiv(n / 4 + 1, 256);
     if (cb > 1024) cb = 1024;
-    hipLaunchKernelGGL(refresh_bf16_weights_kernel, dim3((unsigned)(cb + tiles)), dim3(256), 0, (hipStream_t)stream, flat,
-                       (unsigned short*)flat16, n, (int)cb, w);
-    LBX_LAUNCH_OK();
+    // the conversion of the flat vector rides with the first chunk of (at most 48) matrices
+    int done = 0;
+    do {
+        WeightShadows w{};
+        int tiles = 0, k = 0;
+        for (; k < MAX_WT && done + k < nmats; ++k) {
+            const lidbox_weight_shadow_t& m = mats[done + k];
+            w.src_off[k] = m.offset;
+            w.dst[k] = (unsigned short*)m.dst;
+            w.R[k] = m.rows | (m.transpose ? (int)0x80000000 : 0);
+            w.C[k] = m.cols;
+            w.ld_dst[k] = (int)m.ld_dst;
+            tiles += (int)(lbx_cdiv(m.rows, 32) * lbx_cdiv(m.cols, 32));
+            w.tile_end[k] = tiles;
+        }
+        w.n = k;
+        const long conv = done == 0 ? (n > 0 ? cb : 0) : 0;
+        if (conv + tiles > 0) {
+            hipLaunchKernelGGL(refresh_bf16_weights_kernel, dim3((unsigned)(conv + tiles)), dim3(256), 0, (hipStream_t)stream, flat,
+                               (unsigned short*)flat16, n, (int)conv, w);
+            LBX_LAUNCH_OK();
+        }
+        done += k;
+    } while (done < nmats);
     return LIDBOX_OK;
 }
 

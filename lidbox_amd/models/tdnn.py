@@ -130,8 +130,14 @@ class _Workspace:
             self.Ts.append(conv_out_len(self.Ts[-1], c.s))
         chans = [model.input_dim] + [c.filters for c in convs]
         self.pads = [c.pad for c in convs] + [0]
-        # activations (zero-initialised once: the pad rows stay zero forever)
-        self.act = [torch.zeros((B, self.pads[i] + self.Ts[i], chans[i]), **f32) for i in range(len(chans))]
+        # zero rows BEHIND an utterance's frames (bf16-storage path only): the output-stationary dgrad of a conv with k > s
+        # reads its output gradient through windows that run up to `trail` rows past the last frame (SequentialTDNN._dgrad_residues)
+        self.trail = [0] * len(chans)
+        if model.bf16_storage:
+            for i in range(1, len(convs) - 1):               # not the last conv: the pooling reads act[-1] as [B, T, C]
+                self.trail[i + 1] = model._dgrad_trail(i, self.Ts[i])
+        # activations (zero-initialised once: the pad / trail rows stay zero forever)
+        self.act = [torch.zeros((B, self.pads[i] + self.Ts[i] + self.trail[i], chans[i]), **f32) for i in range(len(chans))]
         self.dact = [None] + [torch.zeros_like(a) for a in self.act[1:]]
         # bf16-storage GEMMs (compute_dtype "bfloat16"): bf16 shadows of the conv inputs (A of forward) and of the conv output
         # gradients (A of dgrad), same element layout as the fp32 buffers; written by the producing GEMM's epilogue.
@@ -321,9 +327,22 @@ class SequentialTDNN:
             self.flat16 = torch.zeros(self.num_flat, dtype=torch.bfloat16, device=self.device)
             cin = self.input_dim
             self.w16t = []
+            # wd16[i]: dgrad's weight images of conv i where flat16 itself cannot serve -- {"fused": [k*C_in][C_out padded to
+            # 8]} for k <= s with a channel count that is not a multiple of 8 (frame5's 1500), {rho: [C_in][Q * C_out padded]}
+            # per row residue for k > s (the taps rho + q*s side by side, last tap first; _dgrad_residues)
+            self.wd16 = []
+            bf = dict(dtype=torch.bfloat16, device=self.device)
             for i, c in enumerate(self.convs):
-                self.w16t.append(torch.zeros((c.filters, c.k * cin), dtype=torch.bfloat16, device=self.device)
-                                 if self.shadow_fwd_ok(i) else None)
+                self.w16t.append(torch.zeros((c.filters, c.k * cin), **bf) if self.shadow_fwd_ok(i) else None)
+                img = {}
+                if i >= 1 and self.shadow_dgrad_ok(i):
+                    cp = (c.filters + 7) // 8 * 8
+                    if c.k > c.s and i < len(self.convs) - 1:
+                        for rho, Q, _, _ in self._dgrad_residues(i, 1 << 20):
+                            img[rho] = torch.zeros((cin, Q * cp), **bf)
+                    elif c.k <= c.s and cp != c.filters:
+                        img["fused"] = torch.zeros((c.k * cin, cp), **bf)
+                self.wd16.append(img)
                 cin = c.filters
         self._ws = {}
         # optional second HIP stream: wgrad GEMMs run on it concurrently with the dgrad chain (they only
@@ -391,19 +410,53 @@ class SequentialTDNN:
         return c.d == 1 and self._cin(i) % 8 == 0 and c.filters % 4 == 0
 
     def shadow_dgrad_ok(self, i):
-        """dgrad of conv i can read the bf16 shadow of its output gradient: C_out and C_in multiples of 8"""
+        """dgrad of conv i can read the bf16 shadow of its output gradient (rows padded to 8 channels where needed)"""
         c = self.convs[i]
-        return c.d == 1 and c.filters % 8 == 0 and self._cin(i) % 8 == 0
+        return c.d == 1 and c.filters % 4 == 0 and self._cin(i) % 8 == 0
+
+    def _dgrad_residues(self, i, T):
+        """Output-stationary dgrad of conv i (d = 1) over inputs of T frames: the padded input row p = u*s + rho receives
+        sum_q dY[u - q] . W[rho + q*s]^T over the taps j = rho + q*s < k, i.e. ONE GEMM per residue rho whose A rows are
+        windows of Q consecutive output-gradient rows and whose B stacks those taps -- every row written exactly once, no
+        accumulation passes, no zero fills.  Returns [(rho, Q, u_min, u_max)]: rows p >= pad only (the causal pad rows keep
+        their zeros); windows start at dY row u - Q + 1 >= 0 and may run past the last one (see _dgrad_trail)."""
+        c = self.convs[i]
+        res = []
+        for rho in range(min(c.s, c.k)):
+            Q = (c.k - rho + c.s - 1) // c.s
+            u_min = -((rho - c.pad) // c.s)                   # ceil((pad - rho) / s)
+            u_max = (c.pad + T - 1 - rho) // c.s
+            if T > 0 and u_max >= u_min:
+                res.append((rho, Q, u_min, u_max))
+        return res
+
+    def _dgrad_trail(self, i, T):
+        """zero rows needed behind the last output-gradient row of an utterance by conv i's output-stationary dgrad"""
+        c = self.convs[i]
+        if not (c.d == 1 and c.k > c.s and self.shadow_dgrad_ok(i)) or T <= 0:
+            return 0
+        To = conv_out_len(T, c.s)
+        return max(0, max(u_max for _, _, _, u_max in self._dgrad_residues(i, T)) - (To - 1))
 
     def _refresh_bf16_weights(self):
         """flat16 and the transposed conv kernels from the fp32 master copy, one launch"""
         mats = getattr(self, "_w16t_descs", None)
         if mats is None:
-            items = [(self.layout[c.name + ".W"][0], c.k * self._cin(i), c.filters, self.w16t[i])
-                     for i, c in enumerate(self.convs) if self.w16t[i] is not None]
-            mats = (nv.WeightTranspose * max(1, len(items)))()
-            for j, (off, K, N, dst) in enumerate(items):
-                mats[j] = nv.WeightTranspose(off, K, N, dst.data_ptr())
+            items = []
+            for i, c in enumerate(self.convs):
+                off, cin, co = self.layout[c.name + ".W"][0], self._cin(i), c.filters
+                if self.w16t[i] is not None:
+                    items.append((off, c.k * cin, co, self.w16t[i].data_ptr(), c.k * cin, 1))
+                for key, img in self.wd16[i].items():
+                    if key == "fused":
+                        items.append((off, c.k * cin, co, img.data_ptr(), img.shape[1], 0))
+                        continue
+                    Q = (c.k - key + c.s - 1) // c.s
+                    cp = img.shape[1] // Q
+                    for q in range(Q):                        # tap rho + q*s sits in column block Q-1-q
+                        items.append((off + (key + q * c.s) * cin * co, cin, co, img.data_ptr() + 2 * (Q - 1 - q) * cp,
+                                      img.shape[1], 0))
+            mats = (nv.WeightShadow * max(1, len(items)))(*[nv.WeightShadow(*it) for it in items])
             self._w16t_descs, self._w16t_n = mats, len(items)
         nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(self.flat), nv.ptr(self.flat16), self.num_flat, mats, self._w16t_n,
                                                     nv.current_stream()))
@@ -758,28 +811,39 @@ class SequentialTDNN:
         dprev, aprev = ws.dact[i], ws.act[i]
         Tp = dprev.shape[1]
         relu_prev = self.convs[i - 1].relu if i > 0 else False      # conv 0 behind a front-end reads a BatchNorm output
-        if c.k < c.s:
-            nv.check(lib.lidbox_zero_2d(nv.ptr(dprev), 4 * dprev.numel(), 4 * dprev.numel(), 1, st))   # holes inside every stride period
-        elif To * c.s < Tp:
-            # tail rows beyond group 0's coverage
-            nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), 4 * Tp * cin,
-                                        4 * (Tp - To * c.s) * cin, B, st))
         ngroups = (c.k + c.s - 1) // c.s
-        # bf16-storage dgrad: A = bf16 shadow of dact[i+1] (written by conv i+1's dgrad epilogues, or converted here when
-        # it came from the pooling backward / a fp32-source launch), B = the Keras kernel rows of the tap group in flat16
+        # bf16-storage dgrad: A = bf16 shadow of dact[i+1] (written by conv i+1's dgrad epilogues / the pooling backward, or
+        # converted above), B = a bf16 image of the Keras kernel
         use16 = self.bf16_storage and dy16 is not None and self.shadow_dgrad_ok(i)
         d16 = ws.dact16[i] if use16 else None                   # shadow of this dgrad's output, for conv i-1's dgrad
-        if use16:
-            fresh = ws.d16_fresh
+        if use16 and ngroups > 1 and self.wd16[i]:
+            # k > s, output-stationary (_dgrad_residues): one GEMM per row residue, every row of dact[i] behind the pad written
+            # exactly once; windows running past an utterance's last gradient row read the zero trail rows of dact16[i+1]
+            Tp2, cp = dy16.shape[1], dy16.shape[2]
+            for rho, Q, u_min, u_max in self._dgrad_residues(i, ws.Ts[i]):
+                nu, p0 = u_max - u_min + 1, u_min * c.s + rho
+                A16 = nv.Rows(dy16.data_ptr() + 2 * (ws.pads[i + 1] + u_min - Q + 1) * cp, Tp2 * cp, cp, B, nu)
+                Cd = _rows(dprev.data_ptr() + 4 * p0 * cin, Tp * cin, c.s * cin, B, nu)
+                mask = ctypes.c_void_p(aprev.data_ptr() + 4 * p0 * cin) if relu_prev else None
+                sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + 2 * p0 * cin)
+                nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin,
+                                                  nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE, mask, gws, gws_n, st))
             if d16 is not None:
-                # rows no tap group writes must read as zero in the shadow too
-                if c.k < c.s:
-                    nv.check(lib.lidbox_zero_2d(nv.ptr(d16), 2 * d16.numel(), 2 * d16.numel(), 1, st))
-                elif To * c.s < Tp:
-                    nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(d16.data_ptr() + 2 * To * c.s * cin), 2 * Tp * cin,
-                                                2 * (Tp - To * c.s) * cin, B, st))
-                fresh.add(i)
-                ws.d16_fresh = fresh
+                ws.d16_fresh.add(i)
+            return
+        if use16 and (ngroups > 1 or "fused" not in self.wd16[i]) and c.filters % 8 != 0:
+            use16, d16 = False, None                             # grouped taps read flat16 as it is: 8-channel rows only
+        # Rows no tap writes read as zero: they are zero since allocation and stay so when a single group writes (k <= s);
+        # with several groups the later ones ACCUMULATE into rows group 0 does not cover, which are cleared first.
+        if ngroups > 1 and To * c.s < Tp:
+            nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), 4 * Tp * cin,
+                                        4 * (Tp - To * c.s) * cin, B, st))
+            if d16 is not None:
+                nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(d16.data_ptr() + 2 * To * c.s * cin), 2 * Tp * cin,
+                                            2 * (Tp - To * c.s) * cin, B, st))
+        if d16 is not None:
+            ws.d16_fresh.add(i)
+        fused16 = self.wd16[i].get("fused") if use16 else None   # [k*C_in][C_out padded to 8]
         for g in range(ngroups):
             ntaps = min(c.s, c.k - g * c.s)
             base_off = 4 * g * c.s * cin                    # bytes
@@ -791,10 +855,14 @@ class SequentialTDNN:
             else:
                 epi = nv.EPI_ACCUM_RELU_MASK if relu_prev else nv.EPI_ACCUM
             if use16:
-                Wg16 = ctypes.c_void_p(self._p16(c.name + ".W").value + 2 * g * c.s * cin * c.filters)
                 sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + base_off // 2)
-                nv.check(lib.lidbox_gemm_bf16s_nt(self._rows16(dy, ws.dact[i + 1], ws.dact16[i + 1]), Wg16, c.filters, Cd, sh,
-                                                  c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+                A16 = self._rows16(dy, ws.dact[i + 1], dy16)
+                if fused16 is not None:                          # padded channel rows on both operands (pad columns are zero)
+                    cp = fused16.shape[1]
+                    nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(fused16), cp, Cd, sh, cp, ntaps * cin, epi, mask, gws, gws_n, st))
+                else:
+                    Wg16 = ctypes.c_void_p(self._p16(c.name + ".W").value + 2 * g * c.s * cin * c.filters)
+                    nv.check(lib.lidbox_gemm_bf16s_nt(A16, Wg16, c.filters, Cd, sh, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
             else:
                 nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
         if i == 0:

@@ -359,7 +359,8 @@ def test_bf16_storage_gemm_tn_implicit_rows_and_errors(Bn, T, C, k, s_, Co):
 
 
 def test_refresh_bf16_weights_one_launch():
-    """flat -> flat16 plus the transposed bf16 copies of listed matrices inside it (the per-step weight-shadow refresh)"""
+    """flat -> flat16 plus bf16 images of listed matrices inside it (the per-step weight-shadow refresh): transposed,
+    row-padded, and blocks side by side in one destination"""
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(5)
     shapes = [(200, 512), (1536, 512), (37, 5), (512, 1500)]
@@ -371,15 +372,33 @@ def test_refresh_bf16_weights_one_launch():
     flat = _dev(rng.standard_normal(n))
     flat16 = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
     dsts = [torch.zeros((c, r), dtype=torch.bfloat16, device="cuda") for r, c in shapes]
-    mats = (nv.WeightTranspose * len(shapes))()
-    for j, ((r, c), o, d) in enumerate(zip(shapes, offs, dsts)):
-        mats[j] = nv.WeightTranspose(o, r, c, d.data_ptr())
+    padded = torch.zeros((512, 1504), dtype=torch.bfloat16, device="cuda")             # (512, 1500) with rows padded to 1504
+    stacked = torch.zeros((200, 2 * 512), dtype=torch.bfloat16, device="cuda")          # (200, 512) twice, side by side
+    items = [(o, r, c, d.data_ptr(), r, 1) for (r, c), o, d in zip(shapes, offs, dsts)]
+    items.append((offs[3], 512, 1500, padded.data_ptr(), 1504, 0))
+    items.append((offs[0], 200, 512, stacked.data_ptr() + 2 * 512, 1024, 0))
+    items.append((offs[0], 200, 512, stacked.data_ptr(), 1024, 0))
+    mats = (nv.WeightShadow * len(items))(*[nv.WeightShadow(*it) for it in items])
     st = nv.current_stream()
-    nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(shapes), st))
+    nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(items), st))
     assert torch.equal(flat16, flat.bfloat16())
+    for (r, c), o, d in zip(shapes, offs, dsts):
+        assert torch.equal(d, flat[o:o + r * c].reshape(r, c).t().bfloat16())
+    w3 = flat[offs[3]:offs[3] + 512 * 1500].reshape(512, 1500).bfloat16()
+    assert torch.equal(padded[:, :1500], w3) and not padded[:, 1500:].any()
+    w0 = flat[offs[0]:offs[0] + 200 * 512].reshape(200, 512).bfloat16()
+    assert torch.equal(stacked[:, :512], w0) and torch.equal(stacked[:, 512:], w0)
+    # more matrices than one launch's table holds
+    many = (nv.WeightShadow * 100)(*[nv.WeightShadow(*items[i % 4]) for i in range(100)])
+    for d in dsts:
+        d.zero_()
+    nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, many, 100, st))
     for (r, c), o, d in zip(shapes, offs, dsts):
         assert torch.equal(d, flat[o:o + r * c].reshape(r, c).t().bfloat16())
     nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, None, 0, st))      # no matrices: convert only
     with pytest.raises(ValueError):                              # a matrix that sticks out of the vector
-        mats[0] = nv.WeightTranspose(n - 10, 200, 512, dsts[0].data_ptr())
-        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(shapes), st))
+        mats[0] = nv.WeightShadow(n - 10, 200, 512, dsts[0].data_ptr(), 200, 1)
+        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(items), st))
+    with pytest.raises(ValueError):                              # destination rows shorter than the data
+        mats[0] = nv.WeightShadow(offs[0], 200, 512, dsts[0].data_ptr(), 100, 1)
+        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(items), st))
