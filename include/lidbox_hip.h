@@ -156,7 +156,10 @@ enum {
     LIDBOX_EPI_ACCUM     = 4,   /* C += .                                                          */
     LIDBOX_EPI_ACCUM_RELU_MASK = 5, /* C += . * (mask > 0)                                         */
     LIDBOX_EPI_ACCUM_RELU = 6,  /* C = relu(C + .)       last tap of a dilated Conv1D (bias added by the first tap) */
-    LIDBOX_EPI_RELU      = 7    /* relu(.)               Dense(use_bias=False, activation="relu"), clstm.py:35 */
+    LIDBOX_EPI_RELU      = 7,   /* relu(.)               Dense(use_bias=False, activation="relu"), clstm.py:35 */
+    /* flag, lidbox_gemm_bf16s_nt only, OR-ed onto a *_RELU_MASK epilogue: the mask source `aux` is bfloat16 data at C's
+     * element offsets (the bf16 shadow of the activation; only sign / zero-ness is looked at) */
+    LIDBOX_EPI_MASK_BF16 = 0x100
 };
 
 /* Which decomposition the cost model picks (for profiling tools: it names the kernel instantiation a
@@ -229,7 +232,9 @@ int lidbox_gemm_bf16_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, i
  * reads its transpose [C_out, k*C_in]).  C (fp32), epilogues, split decompositions and determinism as
  * lidbox_gemm_bf16_nt; C16 (may be NULL) receives the bf16 shadow of every finished C value at C's element offsets.
  * Numerically identical to lidbox_gemm_bf16_nn/_nt on the fp32 originals (rounding happens where the shadow is
- * written instead of where it is read).  Needs 16-byte aligned bases and K, ldb, row / batch strides % 8 == 0. */
+ * written instead of where it is read).  Needs 16-byte aligned bases and K, ldb, row / batch strides % 8 == 0.
+ * C.base may be NULL (with C16 given and a non-accumulating epilogue): the result then exists only as the shadow -- the
+ * strides of C still describe the layout -- which halves to thirds the bytes an intermediate activation costs. */
 int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16,
                          int K, int N, int epilogue, const float* aux,
                          void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
@@ -334,7 +339,8 @@ int lidbox_stats_pool_bwd(const float* x, const float* pooled, const float* dout
                           long batch_stride, long row_stride, int relu_mask, float* dx,
                           lidbox_stream_t stream);
 /* as lidbox_stats_pool_bwd; additionally writes bf16(dx) (round-to-nearest-even) to the shadow buffer dx16 with its own
- * batch / row strides in bf16 elements (row_stride16 >= C: a shadow padded to 8-element rows feeds lidbox_gemm_bf16s_tn) */
+ * batch / row strides in bf16 elements (row_stride16 >= C: a shadow padded to 8-element rows feeds lidbox_gemm_bf16s_tn);
+ * dx may be NULL: only the shadow is written */
 int lidbox_stats_pool_bwd_shadow(const float* x, const float* pooled, const float* dout, int B, int T, int C,
                                  long batch_stride, long row_stride, int relu_mask, float* dx,
                                  void* dx16, long batch_stride16, long row_stride16, lidbox_stream_t stream);

@@ -510,7 +510,7 @@ __device__ __forceinline__ void mma_tile16s(const __bf16* As, const __bf16* Bs, 
 __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
                                                               float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
                                                               const float* __restrict__ aux, int tiles_n, unsigned ntiles,
-                                                              int k_per_split) {
+                                                              int k_per_split, const unsigned short* __restrict__ mask16) {
     extern __shared__ __attribute__((aligned(16))) char smem16s[];      // 4 tiles: 40 KB (BKS 32) or 72 KB (BKS 64, above the static limit)
     __bf16 (*As)[TILE_S] = reinterpret_cast<__bf16 (*)[TILE_S]>(smem16s);
     __bf16 (*Bs)[TILE_S] = reinterpret_cast<__bf16 (*)[TILE_S]>(smem16s + 2 * TILE_S * sizeof(__bf16));
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
         if (D > 3 && kt < nk) LBX16S_STEP(3 % D)
     }
 #undef LBX16S_STEP
-    store_rows_tile<2, 2>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16);
+    store_rows_tile<2, 2, true>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16, mask16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -958,7 +958,7 @@ int launch_rows16(const char* fn, lidbox_rows_t A, const float* Bm, long ldb, li
 }
 
 int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, lidbox_rows_out_t Cd, void* C16, int K, int N,
-                   int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t st, const unsigned short* mask16) {
     const long M = (long)A.batch * A.rows_per_batch;
     if (M == 0 || N == 0) return LIDBOX_OK;
     const lidbox_rows_t Cin{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
@@ -986,13 +986,13 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
         const long msub = m_end - m_beg;
         const long ntiles = lbx_cdiv(msub, BT) * tiles_n;
         hipLaunchKernelGGL(gemm16s_rows_kernel, dim3((unsigned)ntiles, (unsigned)q.splits), dim3(256), lds_bytes, st, Ah, Bh, Co, S, P,
-                           m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, q.k_per_split);
+                           m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, q.k_per_split, mask16);
         LBX_LAUNCH_OK();
         if (q.splits > 1) {
             long g = lbx_cdiv(msub * N, 256);
             if (g > 2048) g = 2048;
             hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, q.splits, m_beg, msub,
-                               N, Co, epi, aux, S);
+                               N, Co, epi, aux, S, mask16);
             LBX_LAUNCH_OK();
         }
         return LIDBOX_OK;
@@ -1021,8 +1021,20 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
 extern "C" int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16, int K,
                                     int N, int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
                                     lidbox_stream_t stream) {
-    if (validate_rows_call(__func__, A16, (const float*)B16, ldb, C, K, N, epilogue, aux, K)) return LIDBOX_E_INVALID;
-    return launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream);
+    // LIDBOX_EPI_MASK_BF16: the ReLU mask source (aux) is bfloat16 data at C's element offsets; C.base == NULL: the result
+    // exists only as the shadow C16 (no fp32 copy is written) -- not with the accumulating epilogues, which read C
+    const bool mask16 = (epilogue & LIDBOX_EPI_MASK_BF16) != 0;
+    const int epi = epilogue & ~LIDBOX_EPI_MASK_BF16;
+    lidbox_rows_out_t Cv = C;
+    if (!C.base) {
+        LBX_ARG(C16 && epi != LIDBOX_EPI_ACCUM && epi != LIDBOX_EPI_ACCUM_RELU && epi != LIDBOX_EPI_ACCUM_RELU_MASK,
+                "C.base == NULL needs the shadow C16 and a non-accumulating epilogue");
+        Cv.base = (float*)C16;                                      // descriptor checks only
+    }
+    LBX_ARG(!mask16 || epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK, "LIDBOX_EPI_MASK_BF16 goes with a ReLU-mask epilogue");
+    if (validate_rows_call(__func__, A16, (const float*)B16, ldb, Cv, K, N, epi, aux, K)) return LIDBOX_E_INVALID;
+    return launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epi, mask16 ? nullptr : aux, workspace, workspace_bytes,
+                          (hipStream_t)stream, mask16 ? (const unsigned short*)aux : nullptr);
 }
 
 extern "C" size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N) {

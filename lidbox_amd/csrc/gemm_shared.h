@@ -60,12 +60,16 @@ struct FarTag {
 // Epilogue of one workgroup tile held as MI x NJ accumulator blocks per wave (waves 2 x 2).
 // Rows of this launch are [m_beg, M).  gridDim.y > 1 = split along K: raw partial sums go to
 // P[split][row - m_beg][n] and rows_reduce_kernel applies the epilogue.
-template <int MI, int NJ>
+// EXT (bf16-storage kernels only; the fp32 instantiations compile exactly as before): Cd.base may be NULL -- the finished
+// values then exist only as the bf16 shadow -- and mask16, when given, is the ReLU mask source read as bfloat16 at C's
+// element offsets (the shadow of the activation) instead of the fp32 aux.
+template <int MI, int NJ, bool EXT = false>
 __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], long m0, int n0, int wm, int wn, int lane,
                                                 long m_beg, long M, int N, int epi, const float* __restrict__ aux,
                                                 const RowsOutD& Cd, float* __restrict__ P, int split,
                                                 unsigned long long mask_bits = 0ull, bool have_mask_bits = false,
-                                                unsigned short* __restrict__ shadow = nullptr) {
+                                                unsigned short* __restrict__ shadow = nullptr,
+                                                const unsigned short* __restrict__ mask16 = nullptr) {
     // shadow (bf16-storage GEMMs, gemm_bf16.hip): a bfloat16 copy of every finished value at the same element offset as C
     // (round-to-nearest-even) -- the operand the next GEMM reads; never written for split-K partial sums.
     // Epilogue kind as four uniform flags (no per-element switch); bias and column state hoisted.
@@ -114,7 +118,7 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
                     if (!colok[bj]) continue;
                     float x = acc[bi][bj][r] + bias[bj];
                     if (do_relu) x = fmaxf(x, 0.f);
-                    out_base[off + col[bj]] = x;
+                    if (!EXT || out_base) out_base[off + col[bj]] = x;
                     if (shadow && !partial) shadow[off + col[bj]] = __builtin_bit_cast(unsigned short, (__bf16)x);
                 }
             }
@@ -148,7 +152,11 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 float v[8], mv[8], ov[8];
-                if (has_mask && !have_mask_bits) {
+                if (EXT && has_mask && mask16) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)                  // sign and zero-ness are all that is looked at: bits << 16 is the value
+                        mv[i] = __builtin_bit_cast(float, (unsigned)mask16[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c] << 16);
+                } else if (has_mask && !have_mask_bits) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) mv[i] = aux[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c];
                 }
@@ -173,7 +181,7 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
                 for (int i = 0; i < 8; ++i) {
                     const int dr = ((r0 + i) & 3) + 8 * ((r0 + i) >> 2);
                     if (rbase + dr < M && colok[bj]) {
-                        out_base[row_off(dr) + c] = v[i];
+                        if (!EXT || out_base) out_base[row_off(dr) + c] = v[i];
                         if (shadow) shadow[row_off(dr) + c] = __builtin_bit_cast(unsigned short, (__bf16)v[i]);
                     }
                 }
@@ -186,8 +194,10 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
 }
 
 // C rows [m_beg, m_beg + Msub) = epi( sum_s P[s][Msub][N] ), fixed order
+// (bf16-storage launches: Cd.base may be NULL, mask16 = the ReLU mask source as bfloat16 -- see store_rows_tile)
 __global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long m_beg, long Msub, int N, RowsOutD Cd,
-                                   int epi, const float* __restrict__ aux, unsigned short* __restrict__ shadow = nullptr) {
+                                   int epi, const float* __restrict__ aux, unsigned short* __restrict__ shadow = nullptr,
+                                   const unsigned short* __restrict__ mask16 = nullptr) {
     const long total = Msub * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -197,8 +207,12 @@ __global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long
         const long off = row_offset(Cd, (unsigned)(m_beg + row));
         const float bias = (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU) ? aux[col] : 0.f;
         float* dst = Cd.base + off + col;
-        const float x = apply_epi(s, epi, bias, aux, off + col, dst);
-        *dst = x;
+        float x;
+        if (mask16 && epi == LIDBOX_EPI_RELU_MASK) x = __builtin_bit_cast(float, (unsigned)mask16[off + col] << 16) > 0.f ? s : 0.f;
+        else if (mask16 && epi == LIDBOX_EPI_ACCUM_RELU_MASK)
+            x = *dst + (__builtin_bit_cast(float, (unsigned)mask16[off + col] << 16) > 0.f ? s : 0.f);
+        else x = apply_epi(s, epi, bias, aux, off + col, dst);
+        if (Cd.base) *dst = x;
         if (shadow) shadow[off + col] = __builtin_bit_cast(unsigned short, (__bf16)x);
     }
 }

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
             g[v] = STATS ? fmaf(k[v], xv[v] - mean[v], a[v]) : a[v];
             if (relu_mask && !(xv[v] > 0.f)) g[v] = 0.f;
         }
-        if (V == 4) {
+        if (dx == nullptr) {
+            // shadow only
+        } else if (V == 4) {
             *reinterpret_cast<float4*>(dp + (long)t * rs) = make_float4(g[0], g[1], g[2], g[3]);
         } else {
 #pragma unroll
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const float* __restri
             if (relu_mask && !(xv[j] > 0.f)) g[j] = 0.f;
         }
         if (t0 + i < T) {
-            *reinterpret_cast<float4*>(dp + (long)(t0 + i) * rs) = make_float4(g[0], g[1], g[2], g[3]);
+            if (dx) *reinterpret_cast<float4*>(dp + (long)(t0 + i) * rs) = make_float4(g[0], g[1], g[2], g[3]);
             if (dx16) {                                          // bf16 shadow (8-byte store: c, the strides and the base are multiples of 4)
                 const unsigned lo = bf16_bits(g[0]) | ((unsigned)bf16_bits(g[1]) << 16);
                 const unsigned hi = bf16_bits(g[2]) | ((unsigned)bf16_bits(g[3]) << 16);
@@ -653,7 +655,7 @@ extern "C" int lidbox_stats_pool_bwd(const float* x, const float* pooled, const 
 extern "C" int lidbox_stats_pool_bwd_shadow(const float* x, const float* pooled, const float* dout, int B, int T, int C, long bs,
                                             long rs, int relu_mask, float* dx, void* dx16, long bs16, long rs16,
                                             lidbox_stream_t stream) {
-    LBX_ARG(x && pooled && dout && dx && dx16 && T >= 1 && C >= 1, "pointers != NULL; T, C >= 1");
+    LBX_ARG(x && pooled && dout && dx16 && T >= 1 && C >= 1, "x, pooled, dout, dx16 != NULL (dx may be NULL: shadow only); T, C >= 1");
     LBX_ARG(rs16 >= C && (B <= 1 || bs16 >= (long)(T - 1) * rs16 + C) && (((uintptr_t)dx16) & 1) == 0, "shadow strides cover the rows");
     const long total = (long)B * T * C;
     if (total == 0) return LIDBOX_OK;

@@ -331,6 +331,13 @@ class SequentialTDNN:
             # 8]} for k <= s with a channel count that is not a multiple of 8 (frame5's 1500), {rho: [C_in][Q * C_out padded]}
             # per row residue for k > s (the taps rho + q*s side by side, last tap first; _dgrad_residues)
             self.wd16 = []
+            # bf16_only: every conv runs forward, wgrad and dgrad on the shadows, so the fp32 copies of the intermediate
+            # activations act[1..n-1] and of all conv output gradients dact[1..n] have no reader -- they are not written at
+            # all (the ReLU masks come from the shadows' signs).  LIDBOX_BF16_FP32_COPIES=1 keeps writing them (tests, A/B).
+            n = len(self.convs)
+            self.bf16_only = _os.environ.get("LIDBOX_BF16_FP32_COPIES", "0") != "1" and self.pool == "stats" and all(
+                self.shadow_wgrad_ok(i) and (i == 0 or (self.shadow_dgrad_ok(i) and (self.convs[i].k <= self.convs[i].s or i < n - 1)))
+                for i in range(n))
             bf = dict(dtype=torch.bfloat16, device=self.device)
             for i, c in enumerate(self.convs):
                 self.w16t.append(torch.zeros((c.filters, c.k * cin), **bf) if self.shadow_fwd_ok(i) else None)
@@ -344,6 +351,8 @@ class SequentialTDNN:
                         img["fused"] = torch.zeros((c.k * cin, cp), **bf)
                 self.wd16.append(img)
                 cin = c.filters
+        if not self.bf16_storage:
+            self.bf16_only = False
         self._ws = {}
         # optional second HIP stream: wgrad GEMMs run on it concurrently with the dgrad chain (they only
         # share read-only inputs), which fills the tail rounds and the nearly empty dense-layer launches
@@ -627,6 +636,8 @@ class SequentialTDNN:
                 out_rows = self._rows_out(ws.act[i + 1], ws, i + 1)
                 nxt = ws.act16[i + 1]
                 sh = None if nxt is None else ctypes.c_void_p(nxt.data_ptr() + (out_rows.base - ws.act[i + 1].data_ptr()) // 2)
+                if self.bf16_only and nxt is not None and i + 1 < len(self.convs):
+                    out_rows = nv.Rows(None, out_rows.batch_stride, out_rows.row_stride, out_rows.batch, out_rows.rows_per_batch)
                 nv.check(lib.lidbox_gemm_bf16s_nt(self._rows16(self._conv_rows_in(ws, i), ws.act[i], ws.act16[i]),
                                                   nv.ptr(self.w16t[i]), c.k * cin, out_rows, sh, c.k * cin, c.filters,
                                                   nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
@@ -740,7 +751,8 @@ class SequentialTDNN:
         if self.pool == "stats" and d16 is not None and B * T > 0:
             # the last conv's output gradient and its bf16 shadow (rows possibly padded) in one pass
             nv.check(lib.lidbox_stats_pool_bwd_shadow(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
-                                                      pool_mask, nv.ptr(dlast), nv.ptr(d16), T * d16.shape[2], d16.shape[2], st))
+                                                      pool_mask, None if self.bf16_only else nv.ptr(dlast), nv.ptr(d16),
+                                                      T * d16.shape[2], d16.shape[2], st))
             ws.d16_fresh.add(len(self.convs))
         elif self.pool == "stats":
             nv.check(lib.lidbox_stats_pool_bwd(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
@@ -816,6 +828,7 @@ class SequentialTDNN:
         # converted above), B = a bf16 image of the Keras kernel
         use16 = self.bf16_storage and dy16 is not None and self.shadow_dgrad_ok(i)
         d16 = ws.dact16[i] if use16 else None                   # shadow of this dgrad's output, for conv i-1's dgrad
+        only16 = self.bf16_only and use16 and d16 is not None   # no fp32 copy of dact[i]; ReLU mask from act16[i]'s signs
         if use16 and ngroups > 1 and self.wd16[i]:
             # k > s, output-stationary (_dgrad_residues): one GEMM per row residue, every row of dact[i] behind the pad written
             # exactly once; windows running past an utterance's last gradient row read the zero trail rows of dact16[i+1]
@@ -823,11 +836,14 @@ class SequentialTDNN:
             for rho, Q, u_min, u_max in self._dgrad_residues(i, ws.Ts[i]):
                 nu, p0 = u_max - u_min + 1, u_min * c.s + rho
                 A16 = nv.Rows(dy16.data_ptr() + 2 * (ws.pads[i + 1] + u_min - Q + 1) * cp, Tp2 * cp, cp, B, nu)
-                Cd = _rows(dprev.data_ptr() + 4 * p0 * cin, Tp * cin, c.s * cin, B, nu)
-                mask = ctypes.c_void_p(aprev.data_ptr() + 4 * p0 * cin) if relu_prev else None
+                Cd = _rows(None if only16 else dprev.data_ptr() + 4 * p0 * cin, Tp * cin, c.s * cin, B, nu)
+                epi, mask = nv.EPI_NONE, None
+                if relu_prev and only16:
+                    epi, mask = nv.EPI_RELU_MASK | nv.EPI_MASK_BF16, ctypes.c_void_p(ws.act16[i].data_ptr() + 2 * p0 * cin)
+                elif relu_prev:
+                    epi, mask = nv.EPI_RELU_MASK, ctypes.c_void_p(aprev.data_ptr() + 4 * p0 * cin)
                 sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + 2 * p0 * cin)
-                nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin,
-                                                  nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE, mask, gws, gws_n, st))
+                nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin, epi, mask, gws, gws_n, st))
             if d16 is not None:
                 ws.d16_fresh.add(i)
             return
@@ -857,6 +873,10 @@ class SequentialTDNN:
             if use16:
                 sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + base_off // 2)
                 A16 = self._rows16(dy, ws.dact[i + 1], dy16)
+                if only16 and ngroups == 1:
+                    Cd = _rows(None, Tp * cin, c.s * cin, B, To)
+                    if relu_prev:
+                        epi, mask = epi | nv.EPI_MASK_BF16, ctypes.c_void_p(ws.act16[i].data_ptr() + base_off // 2)
                 if fused16 is not None:                          # padded channel rows on both operands (pad columns are zero)
                     cp = fused16.shape[1]
                     nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(fused16), cp, Cd, sh, cp, ntaps * cin, epi, mask, gws, gws_n, st))

@@ -139,8 +139,10 @@ def test_config5_bf16_train_step_tracks_fp32(use_graph):
 
 
 def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
-    """the bf16-storage GEMMs (bf16 shadows of activations / gradients / weights, lidbox_gemm_bf16s_nt) compute what the
-    fp32-source bf16 kernels compute: rounding happens where a shadow is written instead of where an operand is read"""
+    """the bf16-storage GEMMs (bf16 shadows of activations / gradients / weights: lidbox_gemm_bf16s_nt / _tn) compute what the
+    fp32-source bf16 kernels compute: rounding happens where a shadow is written instead of where an operand is read.
+    Three builds of the same model: shadows next to fp32 copies (LIDBOX_BF16_FP32_COPIES=1), shadows only (the default: the
+    fp32 copies of the intermediates have no reader and are not written), and the fp32-source kernels."""
     from lidbox_amd import _native as nv
     from lidbox_amd.features import audio
     from lidbox_amd.models import xvector
@@ -151,35 +153,45 @@ def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
     yd = torch.from_numpy(y.astype(np.int32)).cuda()
     plan = audio.get_plan(16000, 400, 160)
     res = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("LIDBOX_BF16_STORAGE", flag)
+    for tag, storage, copies in (("copies", "1", "1"), ("only", "1", "0"), ("source", "0", "0")):
+        monkeypatch.setenv("LIDBOX_BF16_STORAGE", storage)
+        monkeypatch.setenv("LIDBOX_BF16_FP32_COPIES", copies)
         m = xvector.create((98, 40), 4, seed=0, compute_dtype="bfloat16")
-        assert m.bf16_storage == (flag == "1")
-        t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=(flag == "1"))
+        assert m.bf16_storage == (storage == "1") and m.bf16_only == (tag == "only")
+        t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=(tag != "source"))
         loss, g = t.loss_and_grads(sd, yd)
-        res[flag] = (float(loss), g.clone(), m)
-        if flag == "1":
-            ws = m.workspace(16, 98)
+        res[tag] = (float(loss), g.clone())
+        ws = m.workspace(16, 98)
+        if tag == "copies":
             # the shadows are what they claim to be
             for i in range(len(m.convs)):
-                if ws.act16[i] is not None:
-                    assert torch.equal(ws.act16[i], ws.act[i].bfloat16()), i
-            for j in range(len(ws.dact16)):
-                if ws.dact16[j] is not None:
-                    C = ws.dact[j].shape[2]
-                    assert j in ws.d16_fresh
-                    assert torch.equal(ws.dact16[j][:, :, :C], ws.dact[j].bfloat16()), j
-                    assert not ws.dact16[j][:, :, C:].any()                      # pad columns of a widened shadow stay zero
+                assert torch.equal(ws.act16[i], ws.act[i].bfloat16()), i
+            for j in range(1, len(ws.dact16)):
+                C = ws.dact[j].shape[2]
+                assert j in ws.d16_fresh
+                assert torch.equal(ws.dact16[j][:, :, :C], ws.dact[j].bfloat16()), j
+                assert not ws.dact16[j][:, :, C:].any()                      # pad columns of a widened shadow stay zero
             # every conv input and every conv output gradient has a shadow; frame5's 1500 channels live in 1504-wide rows
             assert sum(a is not None for a in ws.act16) == 5 and sum(a is not None for a in ws.dact16) == 5
             assert ws.dact16[5].shape[2] == 1504
-    # the two paths accumulate K in different chunk orders (64- vs 32-deep tiles), so an activation can land on the other
-    # side of a bf16 rounding boundary here and there: agreement far below one bf16 step (4e-3), not bit equality
-    assert abs(res["1"][0] - res["0"][0]) <= 1e-4 * abs(res["0"][0])
-    ga, gb = res["1"][1], res["0"][1]
+            # frame2 (k = 3 > s = 2) takes the output-stationary dgrad: its output gradient carries one zero trail row per
+            # utterance, and the causal pad rows of dact[1] are never written
+            assert ws.trail == [0, 0, 1, 0, 0, 0] and not ws.dact[2][:, -1, :].any() and not ws.dact[1][:, :2, :].any()
+            shadows = [a.clone() for a in ws.act16[:5]] + [d.clone() for d in ws.dact16[1:]]
+        elif tag == "only":
+            # same shadows bit for bit, and the fp32 copies of the intermediates were never touched
+            now = list(ws.act16[:5]) + list(ws.dact16[1:])
+            assert all(torch.equal(a, b) for a, b in zip(shadows, now))
+            assert all(not ws.act[j].any() for j in range(1, 5)) and all(not ws.dact[j].any() for j in range(1, 6))
+    # shadows-only changes where the ReLU masks are read (signs of the bf16 values): nothing else
+    assert res["only"][0] == res["copies"][0] and torch.equal(res["only"][1], res["copies"][1])
+    # the storage and fp32-source paths accumulate K in different chunk orders (64- vs 32-deep tiles), so an activation can
+    # land on the other side of a bf16 rounding boundary here and there: agreement far below one bf16 step (4e-3), not bit
+    # equality; the bias gradients of the storage path are summed from the shadows
+    assert abs(res["only"][0] - res["source"][0]) <= 1e-4 * abs(res["source"][0])
+    ga, gb = res["only"][1], res["source"][1]
     assert float(torch.linalg.norm(ga - gb) / torch.linalg.norm(gb)) <= 1e-2          # vs 5e-2 allowed against the float64 oracle
     # and the captured train step learns on the storage path
-    m = res["1"][2]
     monkeypatch.setenv("LIDBOX_BF16_STORAGE", "1")
     t = Trainer(xvector.create((98, 40), 4, seed=0, compute_dtype="bfloat16"), feature=dict(plan=plan, kind=nv.FEAT_LOGMEL))
     l0 = float(t.train_step(sd, yd))

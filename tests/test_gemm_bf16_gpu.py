@@ -402,3 +402,36 @@ def test_refresh_bf16_weights_one_launch():
     with pytest.raises(ValueError):                              # destination rows shorter than the data
         mats[0] = nv.WeightShadow(offs[0], 200, 512, dsts[0].data_ptr(), 100, 1)
         nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(items), st))
+
+
+@pytest.mark.parametrize("M,K,N", [(700, 512, 1024), (33, 1536, 512), (8448 // 4, 1504, 512)])
+def test_bf16_storage_gemm_shadow_only_output_and_bf16_mask(M, K, N):
+    """C.base == NULL: the result exists only as the shadow; LIDBOX_EPI_MASK_BF16: the ReLU mask is read from bf16 data.
+    Same numbers as the launch that also writes fp32 and reads a fp32 mask -- including the split / tail-split plans"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + K)
+    a16, b16 = _dev(rng.standard_normal((M, K))).bfloat16(), _dev(rng.standard_normal((N, K))).bfloat16()
+    mask32 = _dev(np.maximum(rng.standard_normal((M, N)), 0))          # a ReLU output: zeros and positives
+    mask16 = mask32.bfloat16()
+    st = nv.current_stream()
+    ra = nv.Rows(a16.data_ptr(), 0, K, 1, M)
+    wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(M, N, K))
+    ws = _ws(wsb)
+    for epi, aux in ((nv.EPI_NONE, None), (nv.EPI_RELU_MASK, mask32)):
+        c = torch.zeros((M, N), device="cuda")
+        c16 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, _rows(c, 0, N, 1, M), nv.ptr(c16), K, N, epi, nv.ptr(aux),
+                                             nv.ptr(ws), wsb, st))
+        only = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
+        epi2, aux2 = (epi | nv.EPI_MASK_BF16, mask16) if aux is not None else (epi, None)
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, nv.Rows(None, 0, N, 1, M), nv.ptr(only), K, N, epi2, nv.ptr(aux2),
+                                             nv.ptr(ws), wsb, st))
+        assert torch.equal(only, c16) and torch.equal(c16, c.bfloat16())
+    with pytest.raises(ValueError):                              # no fp32 C and no shadow
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, nv.Rows(None, 0, N, 1, M), None, K, N, nv.EPI_NONE, None, None, 0, st))
+    with pytest.raises(ValueError):                              # accumulating epilogues read C
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, nv.Rows(None, 0, N, 1, M), nv.ptr(only), K, N, nv.EPI_ACCUM, None,
+                                             None, 0, st))
+    with pytest.raises(ValueError):                              # the flag without a mask epilogue
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, nv.Rows(None, 0, N, 1, M), nv.ptr(only), K, N,
+                                             nv.EPI_BIAS | nv.EPI_MASK_BF16, nv.ptr(mask16), None, 0, st))

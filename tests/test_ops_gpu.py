@@ -223,6 +223,15 @@ def test_stats_and_avg_pool():
         nv.check(nv.lib.lidbox_stats_pool_bwd(nv.ptr(xd), nv.ptr(out), nv.ptr(_dev(dout)), B, T, C, T * C, C, 1,
                                               nv.ptr(dx), st))
         _close(dx.cpu().numpy(), mo.stats_pool_bwd(x, dout) * (x > 0), 1e-4)
+        # the variant that also writes the bf16 shadow of dx (rows padded to 8 channels), with and without the fp32 output
+        Cp = (C + 7) // 8 * 8
+        for keep32 in (True, False):
+            dx2 = torch.full_like(xd, 7.0)
+            sh = torch.zeros((B, T, Cp), dtype=torch.bfloat16, device="cuda")
+            nv.check(nv.lib.lidbox_stats_pool_bwd_shadow(nv.ptr(xd), nv.ptr(out), nv.ptr(_dev(dout)), B, T, C, T * C, C, 1,
+                                                         nv.ptr(dx2) if keep32 else None, nv.ptr(sh), T * Cp, Cp, st))
+            assert torch.equal(sh[:, :, :C], dx.bfloat16()) and not sh[:, :, C:].any()
+            assert torch.equal(dx2, dx) if keep32 else bool((dx2 == 7.0).all())
         avg = torch.zeros((B, C), device="cuda")
         nv.check(nv.lib.lidbox_avg_pool_fwd(nv.ptr(xd), B, T, C, T * C, C, nv.ptr(avg), st))
         _close(avg.cpu().numpy(), x.mean(axis=1), 1e-5)
