@@ -5,7 +5,8 @@
 //   lidbox/models/xvector.py:38-43,53-64 (frame_layer / segment_layer), lidbox/models/cnn.py:32-41
 // when the model is run under a bfloat16 compute policy.  The reference has no such switch of its
 // own (Keras' mixed_bfloat16 policy would be set outside lidbox); the numerical contract here is:
-//   * every tensor in HBM stays fp32 (weights = the fp32 master copy, activations, gradients);
+//   * with the fp32-source entry points (lidbox_gemm_bf16_nn/_nt/_tn) every tensor in HBM stays fp32 (weights = the fp32
+//     master copy, activations, gradients); the storage entry points further down read and write bf16 shadows instead;
 //   * both GEMM operands are rounded to bfloat16, round-to-nearest-even, as they are staged into
 //     LDS (v_cvt_pk_bf16_f32);
 //   * products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; bias / ReLU / mask / accumulate
@@ -876,6 +877,7 @@ Rows16Plan plan_rows16(long M, int N, int K, size_t ws_bytes, int BK = 32) {
     const long max_s = K / (2 * BK);                 // at least two K-steps per split
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
+    if (const char* e = getenv("LIDBOX_GEMM16_SPLITS")) { const long v = atol(e); if (v >= 1) s = v < max_s ? v : (max_s > 1 ? max_s : 1); }   // tuning aid
     while (s > 1 && (size_t)s * M * N * sizeof(float) > ws_bytes) --s;
     if (s <= 1) return best;
     const int kps = (int)(lbx_cdiv(lbx_cdiv(K, s), BK) * BK);
@@ -892,10 +894,15 @@ struct Tn16Plan {
 Tn16Plan plan_tn16(long M, int K1, int N, int BK = 32) {
     const long tiles = lbx_cdiv(K1, BT) * lbx_cdiv(N, BT);
     long target = 2 * NUM_CU;
+    // few output tiles = many M slices = a partial-sum volume (slices x K1 x N floats, written and re-read by the reduce) that
+    // outweighs filling the second workgroup slot of every CU: measured on the storage kernel, frame1 (8 tiles) 58 -> 52 us and
+    // frame4 (16 tiles) 25 -> 22 us with one round of 256 instead of 512 workgroups (profiles/r02_bf16_storage_wgrad.txt)
+    if (BK == 64 && tiles <= 16) target = NUM_CU;
     if (const char* e = getenv("LIDBOX_GEMM16_TN_SLOTS")) { const long v = atol(e); if (v >= 1) target = v; }   // tuning aid
     long s = target / tiles;                         // whole rounds only: one workgroup too many costs a full round
     const long max_s = lbx_cdiv(M, 4 * BK);          // at least four K-steps per slice
     if (s > max_s) s = max_s;
+    if (const char* e = getenv("LIDBOX_GEMM16_TN_SPLITS")) { const long v = atol(e); if (v >= 1) s = v; }                                 // tuning aid
     if (s < 1) s = 1;
     const long rps = lbx_cdiv(lbx_cdiv(M, s), BK) * BK;
     return Tn16Plan{(int)lbx_cdiv(M, rps), rps};
