@@ -357,6 +357,7 @@ class SequentialTDNN:
         # optional second HIP stream: wgrad GEMMs run on it concurrently with the dgrad chain (they only
         # share read-only inputs), which fills the tail rounds and the nearly empty dense-layer launches
         self.wgrad_stream = None
+        self.head_wgrad_stream = None        # dense-head wgrads only (see _launch_wgrad)
 
     # ------------------------------------------------------------------ parameters
     def _init_weights(self, seed):
@@ -695,10 +696,14 @@ class SequentialTDNN:
         return ws.logp
 
     # ------------------------------------------------------------------ backward
-    def _launch_wgrad(self, ws, launch):
+    def _launch_wgrad(self, ws, launch, head=False):
         """launch(workspace_ptr, workspace_bytes, stream): on the side stream (after everything enqueued so
-        far on the current stream) when one is configured, else inline."""
+        far on the current stream) when one is configured, else inline.  head: a dense-head wgrad -- those few-workgroup
+        launches go to `head_wgrad_stream` when only that one is configured (Trainer's default): they then run beside the
+        head's dgrad chain instead of between its links."""
         side = self.wgrad_stream
+        if side is None and head:
+            side = self.head_wgrad_stream
         if side is None:
             launch(nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), nv.current_stream())
             return
@@ -710,6 +715,8 @@ class SequentialTDNN:
         """make the side stream's wgrad results visible to the current stream"""
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        if self.head_wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.head_wgrad_stream)
 
     def backward_ws(self, ws):
         """dh[-1] must hold d loss / d logits.  Fills flat_grad (overwrites)."""
@@ -733,7 +740,8 @@ class SequentialTDNN:
             dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
             A_rows = _rows(x.data_ptr(), 0, din, 1, B)
             self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(self.gemm.tn(
-                A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)))
+                A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)),
+                head=True)
             dst = ws.dpooled if j == 0 else ws.dh[j - 1]
             relu_prev = j > 0 and self.denses[j - 1].relu
             nv.check(self.gemm.nt(dy, self._p(d.name + ".W"), d.units,

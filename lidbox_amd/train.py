@@ -143,7 +143,7 @@ class Trainer:
     """
 
     def __init__(self, model, loss="sparse_categorical_crossentropy", optimizer=None, feature=None,
-                 use_graph=True, num_buckets=2, group=None, metric=None, overlap_wgrad=False):
+                 use_graph=True, num_buckets=2, group=None, metric=None, overlap_wgrad=False, overlap_head_wgrad=False):
         self.model = model
         self.device = model.device
         opt = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
@@ -173,6 +173,11 @@ class Trainer:
         # (96.1k vs 97.1k utt/s at bs 256): both are bound by the same matrix pipes.  Off by default.
         if overlap_wgrad and model.wgrad_stream is None:
             model.wgrad_stream = torch.cuda.Stream(device=self.device)
+        # overlap_head_wgrad: only the dense head's wgrads (a few workgroups each, M = batch) on a second stream, beside the
+        # head's dgrad chain.  Measured SLOWER inside the captured step (fp32 2.387 -> 2.439 ms, bf16 0.913 -> 0.951 ms at
+        # bs 256): the three fork / join edges cost the graph more than the ~35 us of small kernels they could hide.  Off.
+        if overlap_head_wgrad and model.head_wgrad_stream is None:
+            model.head_wgrad_stream = torch.cuda.Stream(device=self.device)
         self.use_graph = bool(use_graph)
         self._warming = False            # True during the pre-capture warm-up pass: streaming metrics must not count it
         self._graphs = {}

@@ -99,6 +99,24 @@ def test_xvector_loss_and_gradients_match_oracle():
         assert abs(got - norm) <= 1e-3 * max(norm, 1e-6), name
 
 
+@pytest.mark.parametrize("kw", [dict(overlap_wgrad=True), dict(overlap_head_wgrad=True)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_side_stream_wgrad_options_give_the_same_gradients(kw, use_graph):
+    """wgrad GEMMs on a second HIP stream (all of them, or the dense head's only): same bits as the single-stream step,
+    eager and inside a captured graph (fork / join edges)"""
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer
+    g = np.load(os.path.join(GOLDEN, "xvector_synth.npz"))
+    x, y = _dev(g["logmel"]), _dev(g["labels"], np.int32)
+    ref_m = xvector.create((198, 40), 4, seed=0)
+    ref_t = Trainer(ref_m, use_graph=False)
+    ref_losses = [float(ref_t.train_step(x, y)) for _ in range(3)]
+    m = xvector.create((198, 40), 4, seed=0)
+    t = Trainer(m, use_graph=use_graph, **kw)
+    losses = [float(t.train_step(x, y)) for _ in range(3)]
+    assert losses == ref_losses and torch.equal(m.flat, ref_m.flat)
+
+
 def test_train_steps_match_oracle_adam_and_graph_equals_eager():
     from lidbox_amd.models import xvector
     from lidbox_amd.train import Trainer
