@@ -324,7 +324,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": "log-mel + x-vector 4-lang train step, bs=%d per GPU, %s (BASELINE configs[%d]%s)"
-                               % (B, "bf16 MFMA operands / fp32 accumulate, storage and master weights" if bf16 else "fp32",
+                               % (B, "bf16 MFMA operands and bf16 activations / gradients in the Conv1D layers, fp32 accumulate, fp32 dense head and master weights" if bf16 else "fp32",
                                   1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""),
                    "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
                    "languages": NUM_LANGS, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world, "grad_buckets": trainer.sync.num_buckets if world > 1 else 1,

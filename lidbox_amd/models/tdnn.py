@@ -214,8 +214,9 @@ class _Workspace:
                 ws_bytes = max(ws_bytes, g.tn_workspace(n, kk, nn_), g.rows_workspace(n, nn_, kk), g.rows_workspace(n, kk, nn_))
         din = P
         for d in model.denses:
-            ws_bytes = max(ws_bytes, g.tn_workspace(B, din, d.units), g.rows_workspace(B, d.units, din),
-                           g.rows_workspace(B, din, d.units))
+            for gd in {g, model.dense_gemm}:
+                ws_bytes = max(ws_bytes, gd.tn_workspace(B, din, d.units), gd.rows_workspace(B, d.units, din),
+                               gd.rows_workspace(B, din, d.units))
             din = d.units
         self.gemm_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.gemm_ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)     # wgrad side stream's own workspace
@@ -274,6 +275,12 @@ class SequentialTDNN:
         # accumulate; all buffers, the master weights and every non-GEMM kernel stay fp32)
         self.gemm = _GemmFamily(compute_dtype)
         self.compute_dtype = self.gemm.name
+        # The dense head (M = batch rows: three layers, < 0.5 % of the flops) stays on the fp32 family under bf16 compute:
+        # its launches are latency-bound and the fp32 family's 64 x 64 tiles + tuned splits run them faster than the bf16
+        # family's 128 x 128 tile (0.910 -> 0.871 ms/step at bs 256, neutral at bs 512).  LIDBOX_BF16_DENSE=1
+        # puts the head on the bf16 family as well (A/B aid).
+        import os as _os0
+        self.dense_gemm = self.gemm if _os0.environ.get("LIDBOX_BF16_DENSE") == "1" else _GemmFamily("float32")
         if self.compute_dtype == "bfloat16":
             widths = [self.input_dim] + [c.filters for c in self.convs] + [d.units for d in self.denses]
             if attention is not None:
@@ -684,7 +691,7 @@ class SequentialTDNN:
             emb = upto_embedding and j == 0
             out = ws.emb if emb else ws.h[j]
             epi = nv.EPI_BIAS_RELU if (d.relu and not emb) else nv.EPI_BIAS
-            nv.check(self.gemm.nn(_rows(x.data_ptr(), 0, din, 1, ws.B), self._p(d.name + ".W"), d.units,
+            nv.check(self.dense_gemm.nn(_rows(x.data_ptr(), 0, din, 1, ws.B), self._p(d.name + ".W"), d.units,
                                         _rows(out.data_ptr(), 0, d.units, 1, ws.B), din, d.units, epi,
                                         self._p(d.name + ".b"), nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), st))
             if emb:
@@ -739,12 +746,12 @@ class SequentialTDNN:
             din = x.shape[1]
             dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
             A_rows = _rows(x.data_ptr(), 0, din, 1, B)
-            self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(self.gemm.tn(
+            self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(self.dense_gemm.tn(
                 A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)),
                 head=True)
             dst = ws.dpooled if j == 0 else ws.dh[j - 1]
             relu_prev = j > 0 and self.denses[j - 1].relu
-            nv.check(self.gemm.nt(dy, self._p(d.name + ".W"), d.units,
+            nv.check(self.dense_gemm.nt(dy, self._p(d.name + ".W"), d.units,
                                         _rows(dst.data_ptr(), 0, din, 1, B), d.units, din,
                                         nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE,
                                         nv.ptr(x) if relu_prev else None, gws, gws_n, st))

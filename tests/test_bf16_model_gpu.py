@@ -37,28 +37,33 @@ def _oracle_params(model):
     return {k: v.astype(np.float64) for k, v in model.get_weights().items()}
 
 
-def _emulated_forward(p, x):
-    """oracle forward with the bf16 contract: operands of every GEMM rounded, everything else float64"""
+def _emulated_forward(p, x, dense16=False):
+    """oracle forward with the bf16 contract: both operands of every Conv1D GEMM rounded, everything else float64 (the
+    dense head computes in fp32; dense16: LIDBOX_BF16_DENSE=1 rounds its operands as well)"""
+    r = _bf16 if dense16 else (lambda v: v)
     h = x
     for name, f, k, s in mo.XVECTOR_FRAMES:
         h = mo.conv1d_causal_fwd(_bf16(h), _bf16(p[name + ".W"]), p[name + ".b"], s)
     pooled = mo.stats_pool_fwd(h)
-    emb = mo.dense_fwd(_bf16(pooled), _bf16(p["segment1.W"]), p["segment1.b"], relu=False)
+    emb = mo.dense_fwd(r(pooled), r(p["segment1.W"]), p["segment1.b"], relu=False)
     h1 = np.maximum(emb, 0)
-    h2 = mo.dense_fwd(_bf16(h1), _bf16(p["segment2.W"]), p["segment2.b"], relu=True)
-    z = mo.dense_fwd(_bf16(h2), _bf16(p["outputs.W"]), p["outputs.b"], relu=False)
+    h2 = mo.dense_fwd(r(h1), r(p["segment2.W"]), p["segment2.b"], relu=True)
+    z = mo.dense_fwd(r(h2), r(p["outputs.W"]), p["outputs.b"], relu=False)
     return mo.log_softmax(z), emb
 
 
-def test_bf16_xvector_forward_is_exactly_the_rounded_operand_model():
+@pytest.mark.parametrize("dense16", [False, True])
+def test_bf16_xvector_forward_is_exactly_the_rounded_operand_model(dense16, monkeypatch):
     from lidbox_amd.models import xvector
     g = np.load(os.path.join(GOLDEN, "xvector_synth.npz"))
+    monkeypatch.setenv("LIDBOX_BF16_DENSE", "1" if dense16 else "0")
     m = xvector.create((198, 40), 4, seed=0, compute_dtype="bfloat16")
     assert m.compute_dtype == "bfloat16" and m.flat.dtype == torch.float32        # fp32 master weights
+    assert m.dense_gemm.name == ("bfloat16" if dense16 else "float32")
     x = g["logmel"]
     logp = m(_dev(x)).cpu().numpy()
     emb = xvector.as_embedding_extractor(m)(_dev(x)).cpu().numpy()
-    ref_logp, ref_emb = _emulated_forward(_oracle_params(m), x.astype(np.float64))
+    ref_logp, ref_emb = _emulated_forward(_oracle_params(m), x.astype(np.float64), dense16)
     # fp32 hidden activations sit within an ulp of a bf16 rounding boundary now and then, so a handful of
     # elements round the other way than in float64; that moves outputs by ~1e-4 at most, far below the
     # 1e-2 .. 1e-1 distance between the bf16 and fp32 models measured next
