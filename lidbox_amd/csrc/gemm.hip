@@ -951,10 +951,7 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
 #undef LBX_TN
     LBX_LAUNCH_OK();
     const long n = (long)K1 * N;
-    long g = lbx_cdiv(n + N, 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, (const float*)Pc,
-                       pl.splits, n, N, Cm, ldc, accumulate, bias_grad);
+    launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad, st);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -1087,10 +1087,7 @@ extern "C" int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float*
                        tiles_n, ntiles, pl.rows_per_split);
     LBX_LAUNCH_OK();
     const long n = (long)K1 * N;
-    long g = lbx_cdiv(n + N, 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, (const float*)Pc, pl.splits, n, N,
-                       Cm, ldc, accumulate, bias_grad);
+    launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad, st);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
@@ -1208,10 +1205,7 @@ extern "C" int lidbox_gemm_bf16_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm,
                        Pc, M, K1, N, tiles_n, ntiles, pl.rows_per_split);
     LBX_LAUNCH_OK();
     const long n = (long)K1 * N;
-    long g = lbx_cdiv(n + N, 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, (const float*)Pc,
-                       pl.splits, n, N, Cm, ldc, accumulate, bias_grad);
+    launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad, st);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

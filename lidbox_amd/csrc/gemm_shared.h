@@ -237,7 +237,55 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, const float* _
     }
 }
 
+// the same sums, four consecutive elements per thread as 16-byte accesses (every element still adds its slices in the
+// order 0 .. splits-1: bit-identical to the scalar kernel); the slices of a quad are issued four at a time
+__global__ void splitk_reduce4_kernel(const float* __restrict__ P, const float* __restrict__ Pc, int splits, long n, int N,
+                                      float* __restrict__ Cm, long ldc, int accumulate, float* __restrict__ bias_grad) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const long n4 = n >> 2, N4 = N >> 2;
+    const long total = n4 + (bias_grad ? N4 : 0);
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const bool body = q < n4;
+        const float* src = body ? P + 4 * q : Pc + 4 * (q - n4);
+        const long stride = body ? n : (long)N;
+        f4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const f4 a = *reinterpret_cast<const f4*>(src + (long)k * stride);
+            const f4 b = *reinterpret_cast<const f4*>(src + (long)(k + 1) * stride);
+            const f4 c = *reinterpret_cast<const f4*>(src + (long)(k + 2) * stride);
+            const f4 d = *reinterpret_cast<const f4*>(src + (long)(k + 3) * stride);
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; k < splits; ++k) s += *reinterpret_cast<const f4*>(src + (long)k * stride);
+        float* dst;
+        if (body) {
+            const long i = 4 * q, row = i / N, col = i - row * N;
+            dst = Cm + row * ldc + col;
+        } else {
+            dst = bias_grad + 4 * (q - n4);
+        }
+        f4* d4 = reinterpret_cast<f4*>(dst);
+        *d4 = accumulate ? *d4 + s : s;
+    }
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// C (+)= sum of the wgrad slices, bias gradient likewise: the 16-byte kernel when every quad is aligned and inside one row
+inline void launch_splitk_reduce(const float* P, const float* Pc, int splits, long n, int N, float* Cm, long ldc, int accumulate,
+                                 float* bias_grad, hipStream_t st) {
+    const bool vec = N % 4 == 0 && ldc % 4 == 0 && n % 4 == 0 && aligned16(P) && aligned16(Cm) && (!bias_grad || (aligned16(Pc) && aligned16(bias_grad)));
+    if (vec) {
+        long g = lbx_cdiv((n + N) / 4, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)g), dim3(256), 0, st, P, Pc, splits, n, N, Cm, ldc, accumulate, bias_grad);
+        return;
+    }
+    long g = lbx_cdiv(n + N, 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, P, Pc, splits, n, N, Cm, ldc, accumulate, bias_grad);
+}
 
 inline bool rows_aligned(const lidbox_rows_t& r) {
     return aligned16(r.base) && r.row_stride % 4 == 0 && (r.batch == 1 || r.batch_stride % 4 == 0);
