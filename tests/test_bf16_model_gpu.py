@@ -262,3 +262,34 @@ def test_bf16_storage_extended_xvector_strided_layers(T, monkeypatch):
     # ten bf16-rounded layers at random initialisation: ~9 % in norm for either path (measured 9.2 / 9.0 % at T = 61); the
     # storage path must not be further from fp32 than the fp32-source path is, beyond noise
     assert ea <= 0.15 and eb <= 0.15 and ea <= 1.25 * eb + 1e-3, (ea, eb)
+
+
+def test_bf16_storage_with_a_first_layer_that_does_not_qualify(monkeypatch):
+    """12 MFCC channels: conv 0 cannot read 16-byte bf16 pieces, so it stays on the fp32-source kernels while the other four
+    layers run on the shadows (its output and its wgrad operands are converted on the way); the fp32 copies are kept"""
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(12)
+    B, T = 8, 50
+    x = _dev(rng.standard_normal((B, T, 12)))
+    y = _dev(rng.integers(0, 4, size=B), np.int32)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LIDBOX_BF16_STORAGE", flag)
+        m = xvector.create((T, 12), 4, seed=5, compute_dtype="bfloat16")
+        assert m.bf16_storage == (flag == "1") and not m.bf16_only
+        t = Trainer(m, use_graph=False)
+        loss, g = t.loss_and_grads(x, y)
+        res[flag] = (float(loss), g.clone())
+        if flag == "1":
+            ws = m.workspace(B, T)
+            assert ws.act16[0] is None and ws.act16[1] is not None and ws.dact16[1] is None and ws.dact16[2] is not None
+            assert ws.act[2].any() and ws.dact[2].any()              # fp32 copies written
+    assert abs(res["1"][0] - res["0"][0]) <= 1e-4 * abs(res["0"][0])
+    assert float(torch.linalg.norm(res["1"][1] - res["0"][1]) / torch.linalg.norm(res["0"][1])) <= 1e-2
+    monkeypatch.setenv("LIDBOX_BF16_STORAGE", "1")
+    t = Trainer(xvector.create((T, 12), 4, seed=5, compute_dtype="bfloat16"))
+    l0 = float(t.train_step(x, y))
+    for _ in range(10):
+        l1 = float(t.train_step(x, y))
+    assert np.isfinite(l1) and l1 < l0
