@@ -369,6 +369,17 @@ int lidbox_log_softmax_fwd(const float* z, int B, int N, float* logp, lidbox_str
 int lidbox_nll_fwd_bwd(const float* logp, const int32_t* labels, int B, int N, float scale,
                        float* loss_out, float* dz, lidbox_stream_t stream);
 
+/* Output layer + loss of a classifier and their backward in two small launches (train step, few classes): logp =
+ * log_softmax(h W + b) with h [B,K] the previous layer's output, W [K,N] a Keras Dense kernel (xvector.py:62-65); loss_out[0]
+ * and dz as lidbox_nll_fwd_bwd (scale = 1/global_batch; labels outside [0,N): NaN loss, zero gradient row); dW [K,N] =
+ * h^T dz, db [N] = column sums of dz, dh [B,K] = dz W^T, multiplied by (h > 0) when relu_mask != 0 (dh may be NULL).
+ * fp32 FMA arithmetic, fixed summation orders (deterministic, no atomics).  lidbox_softmax_head_supported(K, N): N <= 32. */
+size_t lidbox_softmax_head_workspace(int B, int K, int N);
+int lidbox_softmax_head_supported(int K, int N);
+int lidbox_softmax_head_fwd_bwd(const float* h, const float* W, const float* bias, const int32_t* labels, int B, int K, int N,
+                                float scale, int relu_mask, float* logp, float* loss_out, float* dW, float* db, float* dh,
+                                void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+
 /* tf.math.l2_normalize(axis=1) forward / backward on [B,D] */
 int lidbox_l2_normalize_fwd(const float* x, int B, int D, float* out, lidbox_stream_t stream);
 int lidbox_l2_normalize_bwd(const float* x, const float* dout, int B, int D, float* dx,

@@ -90,6 +90,9 @@ _SIGS = {
     "lidbox_colsum": (_i, [Rows, _i, _vp, _i, _vp, _sz, _vp]),
     "lidbox_stats_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_stats_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
+    "lidbox_softmax_head_workspace": (_sz, [_i, _i, _i]),
+    "lidbox_softmax_head_supported": (_i, [_i, _i]),
+    "lidbox_softmax_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lidbox_stats_pool_bwd_shadow": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp, _l, _l, _vp]),
     "lidbox_avg_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_avg_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),

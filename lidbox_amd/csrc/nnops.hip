@@ -349,6 +349,187 @@ __global__ __launch_bounds__(256) void nll_kernel(const float* __restrict__ logp
     if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Output layer + loss of a classifier in TWO small launches (train step only) instead of nine: z = h W + b (Dense(N),
+// xvector.py:62-64), logp = log_softmax(z) (xvector.py:65), Keras SparseCategoricalCrossentropy(from_logits=True) on logp
+// (keras_utils.py:141-147) and the whole backward of those three: dW = h^T dz, db = sum dz, dh = (dz W^T) (* (h > 0)).
+// For few classes (N <= 32) the launches this replaces (GEMM + split reduce, log-softmax, NLL, wgrad + reduce, dgrad +
+// reduce) are latency, not work: 0.5 MFLOP per utterance row.
+//   rows kernel : a wave shares a row's dot products (fp32 FMA, fixed shuffle butterfly); the row-local softmax, loss,
+//                 dz and dh follow in registers; dz [B,N] and the per-row losses go to the workspace.
+//   wgrad kernel: a workgroup owns 16 consecutive k of one class n; 16 lanes per output each add the rows r = s, s+16, ...
+//                 and one lane adds the 16 partial sums in lane order; the last workgroup does db and the mean loss
+//                 (a wave per quantity, fixed butterfly).
+// No atomics, fixed summation orders: deterministic.
+// ------------------------------------------------------------------------------------------------
+// row k of W [K][N] into NP registers (zero beyond N / outside K)
+template <int NP>
+__device__ __forceinline__ void load_w_row(float (&w)[NP], const float* __restrict__ W, int k, int N, bool in, bool vec) {
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const float4 v = in ? *reinterpret_cast<const float4*>(W + (long)k * NP + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NP; ++n) w[n] = (in && n < N) ? W[(long)k * N + n] : 0.f;
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void softmax_head_rows_kernel(const float* __restrict__ h, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, const int32_t* __restrict__ labels,
+                                                                int B, int K, int N, float scale, int relu_mask,
+                                                                float* __restrict__ logp, float* __restrict__ dh,
+                                                                float* __restrict__ dzbuf, float* __restrict__ lossrow) {
+    // one wave per row, four rows per workgroup; lane l owns k = l, l + 64, ...  Loads are issued U k-values at a time
+    // before their FMAs: written one k per iteration the loop paid a memory round trip per k (35 us for K = 512).
+    constexpr int U = NP <= 4 ? 8 : (NP <= 8 ? 4 : (NP <= 16 ? 2 : 1));
+    const bool wvec = N == NP && ((((uintptr_t)W) & 15) == 0);       // rows of W are NP aligned floats: 16-byte loads
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;                                           // wave-uniform
+    const float* hr = h + r * K;
+    const int y = labels[r];                                      // issued with the first batch of loads, used after the reduce
+    float bv[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) bv[n] = n < N ? bias[n] : 0.f;
+    float z[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) z[n] = 0.f;
+    float hv[U], wv[U][NP];                                       // the last trip's values stay live for the dh pass
+    for (int k0 = lane; k0 < K; k0 += 64 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u;
+            const bool in = k < K;
+            hv[u] = in ? hr[k] : 0.f;
+            load_w_row<NP>(wv[u], W, k, N, in, wvec);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int n = 0; n < NP; ++n) z[n] = fmaf(hv[u], wv[u][n], z[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) z[n] += __shfl_xor(z[n], o, 64);     // fixed butterfly over the row's wave
+    }
+    // every lane now holds the row's logits
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+        if (n < N) { z[n] += bv[n]; m = fmaxf(m, z[n]); }
+    float se = 0.f;
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+        if (n < N) se += expf(z[n] - m);
+    const float lse = m + logf(se);
+    // Keras applies softmax cross-entropy to the log-probabilities themselves (nll_kernel): logsumexp(logp) is 0 up to rounding
+    float m2 = -FLT_MAX;
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+        if (n < N) { z[n] -= lse; m2 = fmaxf(m2, z[n]); }          // z = logp from here on
+    float s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+        if (n < N) s2 += expf(z[n] - m2);
+    const float lse2 = m2 + logf(s2);
+    const bool ok = y >= 0 && y < N;                              // outside [0, N): NaN loss, zero gradient row (nll_kernel)
+    float lp_y = 0.f;
+    float dz[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        dz[n] = 0.f;
+        if (n < N) {
+            if (n == y) lp_y = z[n];
+            if (ok) dz[n] = (expf(z[n] - lse2) - (n == y ? 1.f : 0.f)) * scale;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int n = 0; n < NP; ++n)
+            if (n < N) { logp[r * N + n] = z[n]; dzbuf[r * N + n] = dz[n]; }
+        lossrow[r] = ok ? lse2 - lp_y : NAN;
+    }
+    if (dh && lane < K) {
+        auto emit = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 64 * u;
+                float acc = 0.f;
+#pragma unroll
+                for (int n = 0; n < NP; ++n) acc = fmaf(dz[n], wv[u][n], acc);
+                if (relu_mask && !(hv[u] > 0.f)) acc = 0.f;
+                if (k < K) dh[r * K + k] = acc;
+            }
+        };
+        // this lane's last trip first -- the registers still hold it -- then the earlier ones, loaded again
+        const int klast = lane + ((K - 1 - lane) / (64 * U)) * (64 * U);
+        emit(klast);
+        for (int k0 = lane; k0 < klast; k0 += 64 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 64 * u;                         // < K: a full trip
+                hv[u] = hr[k];
+                load_w_row<NP>(wv[u], W, k, N, true, wvec);
+            }
+            emit(k0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_head_wgrad_kernel(const float* __restrict__ h, const float* __restrict__ dzbuf,
+                                                                 const float* __restrict__ lossrow, int B, int K, int N,
+                                                                 float* __restrict__ dW, float* __restrict__ db,
+                                                                 float* __restrict__ loss_out) {
+    __shared__ float red[16][17];
+    const int tid = threadIdx.x;
+    const int kblocks = (K + 15) / 16;
+    if ((int)blockIdx.x == kblocks * N) {
+        // db[n] and the mean loss: wave w takes the quantities w, w + 4, ...; lane l adds rows l, l + 64, ..., then a fixed
+        // butterfly adds the 64 lanes
+        const int lane = tid & 63;
+        for (int q = tid >> 6; q <= N; q += 4) {
+            float acc = 0.f;
+            for (int r = lane; r < B; r += 64) acc += q < N ? dzbuf[(long)r * N + q] : lossrow[r];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == 0) {
+                if (q < N) db[q] = acc;
+                else loss_out[0] = acc / (float)B;
+            }
+        }
+        return;
+    }
+    const int n = blockIdx.x / kblocks, kl = tid & 15, sub = tid >> 4;
+    const int k = (blockIdx.x - n * kblocks) * 16 + kl;
+    const int kc = k < K ? k : 0;
+    float acc = 0.f;
+    for (int r0 = sub; r0 < B; r0 += 16 * 8) {                    // eight rows' loads in flight
+        float hv[8], dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 16 * u;
+            const bool in = r < B;
+            hv[u] = in ? h[(long)r * K + kc] : 0.f;
+            dv[u] = in ? dzbuf[(long)r * N + n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(hv[u], dv[u], acc);
+    }
+    red[kl][sub] = acc;
+    __syncthreads();
+    if (sub == 0 && k < K) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s += red[kl][t];
+        dW[(long)k * N + n] = s;
+    }
+}
+
 constexpr float L2_EPS = 1e-12f;   // tf.math.l2_normalize default epsilon
 
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int B, int D,
@@ -690,6 +871,39 @@ extern "C" int lidbox_nll_fwd_bwd(const float* logp, const int32_t* labels, int 
     LBX_ARG(logp && labels && loss_out && B >= 1 && N >= 1, "logp, labels, loss_out != NULL; B, N >= 1");
     hipLaunchKernelGGL(nll_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, labels, B, N, scale,
                        loss_out, dz);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" size_t lidbox_softmax_head_workspace(int B, int K, int N) {
+    if (B <= 0 || K <= 0 || N <= 0) return 0;
+    return ((size_t)B * N + (size_t)B) * sizeof(float);          // dz [B,N], per-row losses [B]
+}
+
+extern "C" int lidbox_softmax_head_supported(int K, int N) { return N >= 1 && N <= 32 && K >= 1; }
+
+extern "C" int lidbox_softmax_head_fwd_bwd(const float* h, const float* W, const float* bias, const int32_t* labels, int B, int K,
+                                           int N, float scale, int relu_mask, float* logp, float* loss_out, float* dW, float* db,
+                                           float* dh, void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
+    LBX_ARG(h && W && bias && labels && logp && loss_out && dW && db && B >= 1, "h, W, bias, labels, logp, loss, dW, db != NULL; B >= 1");
+    LBX_ARG(lidbox_softmax_head_supported(K, N), "1 <= N <= 32 classes (lidbox_softmax_head_supported)");
+    LBX_ARG(workspace && (((uintptr_t)workspace) & 3) == 0 && workspace_bytes >= lidbox_softmax_head_workspace(B, K, N),
+            "workspace too small (lidbox_softmax_head_workspace)");
+    float* dzbuf = (float*)workspace;
+    float* lossrow = dzbuf + (size_t)B * N;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned G = (unsigned)lbx_cdiv(B, 4);
+#define LBX_SH(NP)                                                                                                       \
+    hipLaunchKernelGGL(softmax_head_rows_kernel<NP>, dim3(G), dim3(256), 0, st, h, W, bias, labels, B, K, N, scale, relu_mask, \
+                       logp, dh, dzbuf, lossrow)
+    if (N <= 4) LBX_SH(4);
+    else if (N <= 8) LBX_SH(8);
+    else if (N <= 16) LBX_SH(16);
+    else LBX_SH(32);
+#undef LBX_SH
+    LBX_LAUNCH_OK();
+    hipLaunchKernelGGL(softmax_head_wgrad_kernel, dim3((unsigned)(lbx_cdiv(K, 16) * N + 1)), dim3(256), 0, st, h, (const float*)dzbuf,
+                       (const float*)lossrow, B, K, N, dW, db, loss_out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -620,10 +620,20 @@ class SequentialTDNN:
                 nv.check(g.nt(dz, Wg, Co, Cd, Co, ntaps * cin, nv.EPI_NONE if grp == 0 else nv.EPI_ACCUM, None, gws, gws_n, st))
         self.join_wgrad()
 
-    def forward_ws(self, ws, upto_embedding=False, training=False, update_moving=True):
+    def fused_output_ok(self):
+        """the last Dense + log_softmax + sparse cross-entropy (and their backward) can run as lidbox_softmax_head_fwd_bwd:
+        few classes, a plain Dense on the fp32 family behind at least one other Dense"""
+        if self.output_activation != "log_softmax" or len(self.denses) < 2 or self.denses[-1].relu:
+            return False
+        if self.dense_gemm.name != "float32":
+            return False
+        return bool(nv.lib.lidbox_softmax_head_supported(self.denses[-2].units, self.denses[-1].units))
+
+    def forward_ws(self, ws, upto_embedding=False, training=False, update_moving=True, stop_before_output=False):
         """The model input buffer (ws.input_view()) must already hold the input.  Returns logp (or the embedding).
         training selects batch statistics in BatchNormalization layers (update_moving=False leaves the running
-        statistics alone: warm-up passes before a graph capture)."""
+        statistics alone: warm-up passes before a graph capture).  stop_before_output: return the input of the last Dense
+        instead (the train step fuses that layer with the loss)."""
         st = nv.current_stream()
         lib = nv.lib
         if self.frontend:
@@ -688,6 +698,8 @@ class SequentialTDNN:
         nv.check(fn(nv.ptr(last), ws.B, T, C, T * C, C, nv.ptr(ws.pooled), st))
         x, din = ws.pooled, ws.pooled.shape[1]
         for j, d in enumerate(self.denses):
+            if stop_before_output and j == len(self.denses) - 1:
+                return x
             emb = upto_embedding and j == 0
             out = ws.emb if emb else ws.h[j]
             epi = nv.EPI_BIAS_RELU if (d.relu and not emb) else nv.EPI_BIAS
@@ -739,8 +751,12 @@ class SequentialTDNN:
         B = ws.B
         ws.d16_fresh = set()                 # indices j whose dact16[j] holds bf16(dact[j]) (written by a dgrad epilogue)
         gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
-        # ---- dense chain
-        for j in range(len(self.denses) - 1, -1, -1):
+        # ---- dense chain (the output layer's share is already there when the train step fused it with the loss)
+        top = len(self.denses) - 1
+        if getattr(ws, "output_layer_done", False):
+            ws.output_layer_done = False
+            top -= 1
+        for j in range(top, -1, -1):
             d = self.denses[j]
             x = ws.pooled if j == 0 else ws.h[j - 1]
             din = x.shape[1]

@@ -171,6 +171,10 @@ class Trainer:
         self.sync = GradSync(model.flat_grad, bounds, group)
         # overlap_wgrad: run wgrad GEMMs on a second stream concurrently with the dgrad chain.  Measured neutral
         # (96.1k vs 97.1k utt/s at bs 256): both are bound by the same matrix pipes.  Off by default.
+        # fuse_output: the last Dense, log_softmax, the cross-entropy and their backward as two small launches when the model allows
+        # it (SequentialTDNN.fused_output_ok); LIDBOX_NO_FUSED_OUTPUT=1 keeps the nine separate launches (A/B aid)
+        import os as _os
+        self.fuse_output = self.loss_kind == "nll" and _os.environ.get("LIDBOX_NO_FUSED_OUTPUT") != "1" and model.fused_output_ok()
         if overlap_wgrad and model.wgrad_stream is None:
             model.wgrad_stream = torch.cuda.Stream(device=self.device)
         # overlap_head_wgrad: only the dense head's wgrads (a few workgroups each, M = batch) on a second stream, beside the
@@ -210,12 +214,27 @@ class Trainer:
             nv.check(lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, in_bs, model.channel_dropout_rate,
                                                 model.dropout_seed, nv.ptr(self.adam_state), None, st))
         # BatchNormalization layers: batch statistics; the running statistics move once per real step (not in warm-up passes)
-        out = model.forward_ws(ws, training=True, update_moving=not self._warming)
         B = ws.B
         scale = self._loss_scale(B)
+        if self.loss_kind == "nll" and self.fuse_output and B > 0:
+            # output Dense + log_softmax + cross-entropy and their backward in two small launches (few classes: latency, not work)
+            x = model.forward_ws(ws, training=True, update_moving=not self._warming, stop_before_output=True)
+            d = model.denses[-1]
+            K, N = x.shape[1], d.units
+            if not hasattr(ws, "head_ws"):
+                ws.head_ws = torch.empty(nv.lib.lidbox_softmax_head_workspace(B, K, N), dtype=torch.uint8, device=self.device)
+            nv.check(lib.lidbox_softmax_head_fwd_bwd(nv.ptr(x), model._p(d.name + ".W"), model._p(d.name + ".b"), nv.ptr(labels), B, K, N,
+                                                     scale, 1 if model.denses[-2].relu else 0, nv.ptr(ws.logp), nv.ptr(ws.loss),
+                                                     model._p(d.name + ".W", True), model._p(d.name + ".b", True), nv.ptr(ws.dh[-2]),
+                                                     nv.ptr(ws.head_ws), ws.head_ws.numel(), st))
+            ws.output_layer_done = True
+            out = ws.logp
+        else:
+            out = model.forward_ws(ws, training=True, update_moving=not self._warming)
         if self.loss_kind == "nll":
-            nv.check(lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, out.shape[1], scale,
-                                            nv.ptr(ws.loss), nv.ptr(ws.dh[-1]), st))
+            if not getattr(ws, "output_layer_done", False):
+                nv.check(lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, out.shape[1], scale,
+                                                nv.ptr(ws.loss), nv.ptr(ws.dh[-1]), st))
         else:
             D = out.shape[1]
             zn, dzn, per = self._ap_buffers(ws, D)

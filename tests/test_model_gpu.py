@@ -117,6 +117,33 @@ def test_side_stream_wgrad_options_give_the_same_gradients(kw, use_graph):
     assert losses == ref_losses and torch.equal(m.flat, ref_m.flat)
 
 
+def test_fused_output_layer_equals_the_separate_launches(monkeypatch):
+    """Trainer fuses the last Dense + log_softmax + cross-entropy and their backward (lidbox_softmax_head_fwd_bwd) when the
+    model allows it; LIDBOX_NO_FUSED_OUTPUT=1 keeps the GEMM / log-softmax / NLL launches: same loss and gradients to fp32
+    summation order, same trajectory over a few Adam steps"""
+    from lidbox_amd.models import cnn, xvector
+    from lidbox_amd.train import Trainer
+    g = np.load(os.path.join(GOLDEN, "xvector_synth.npz"))
+    x, y = _dev(g["logmel"]), _dev(g["labels"], np.int32)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LIDBOX_NO_FUSED_OUTPUT", flag)
+        m = xvector.create((198, 40), 4, seed=0)
+        t = Trainer(m, use_graph=True)
+        assert t.fuse_output == (flag == "0")
+        loss, grads = t.loss_and_grads(x, y)
+        res[flag] = (float(loss), grads.clone(), [float(t.train_step(x, y)) for _ in range(3)])
+    assert abs(res["0"][0] - res["1"][0]) <= 1e-6 * abs(res["1"][0])
+    assert float(torch.linalg.norm(res["0"][1] - res["1"][1]) / torch.linalg.norm(res["1"][1])) <= 1e-5
+    # Adam divides by sqrt(v) ~ |g|: once the loss collapses (third step of this separable toy batch) the last bits of the
+    # gradients are amplified, so only the first steps are compared tightly
+    assert np.allclose(res["0"][2][:2], res["1"][2][:2], rtol=1e-5) and np.allclose(res["0"][2][2], res["1"][2][2], rtol=2e-2)
+    # models the fusion does not apply to keep the separate launches: 100 classes, a single Dense
+    monkeypatch.setenv("LIDBOX_NO_FUSED_OUTPUT", "0")
+    assert not Trainer(xvector.create((50, 40), 100, seed=0)).fuse_output
+    assert Trainer(cnn.create((40, 12), 4, seed=1)).fuse_output == (len(cnn.create((40, 12), 4, seed=1).denses) >= 2)
+
+
 def test_train_steps_match_oracle_adam_and_graph_equals_eager():
     from lidbox_amd.models import xvector
     from lidbox_amd.train import Trainer

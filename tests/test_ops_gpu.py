@@ -485,3 +485,61 @@ def test_every_wgrad_decomposition_gives_the_same_product(plan, M, K1, N, monkey
     A2, B2 = A[:, pad:].reshape(M, K1), Bm.reshape(M, N)
     _close(c.cpu().numpy(), A2.T @ B2)
     _close(bg.cpu().numpy(), B2.sum(axis=0))
+
+
+@pytest.mark.parametrize("B,K,N,relu", [(256, 512, 4, 1), (37, 512, 4, 1), (16, 64, 3, 0), (1, 8, 1, 1), (300, 512, 32, 1),
+                                          (50, 1500, 17, 0), (2048, 512, 4, 1)])
+def test_softmax_head_fused_matches_the_separate_ops(B, K, N, relu):
+    """lidbox_softmax_head_fwd_bwd = Dense(N) + log_softmax + sparse cross-entropy and their backward, against the float64
+    restatement; invalid labels, row counts that are not a multiple of 16, determinism"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(B + K + N)
+    h = np.maximum(rng.standard_normal((B, K)), 0) if relu else rng.standard_normal((B, K))
+    W, b = rng.standard_normal((K, N)) * 0.1, rng.standard_normal(N)
+    y = rng.integers(0, N, size=B).astype(np.int32)
+    scale = 1.0 / (B + 3)                                        # a global batch larger than the shard
+    hd, Wd, bd, yd = _dev(h), _dev(W), _dev(b), _dev(y, np.int32)
+    st = nv.current_stream()
+    assert nv.lib.lidbox_softmax_head_supported(K, N) == 1
+    wsb = nv.lib.lidbox_softmax_head_workspace(B, K, N)
+    ws = torch.full((wsb,), 0xff, dtype=torch.uint8, device="cuda")          # the workspace needs no initialisation
+    outs = []
+    for rep in range(2):
+        logp = torch.full((B, N), 9.0, device="cuda")
+        loss = torch.zeros(4, device="cuda")
+        dW, db, dh = torch.full((K, N), 9.0, device="cuda"), torch.full((N,), 9.0, device="cuda"), torch.full((B, K), 9.0, device="cuda")
+        nv.check(nv.lib.lidbox_softmax_head_fwd_bwd(nv.ptr(hd), nv.ptr(Wd), nv.ptr(bd), nv.ptr(yd), B, K, N, scale, relu, nv.ptr(logp),
+                                                    nv.ptr(loss), nv.ptr(dW), nv.ptr(db), nv.ptr(dh), nv.ptr(ws), wsb, st))
+        outs.append((logp, loss.clone(), dW, db, dh))
+    assert all(torch.equal(a, b_) for a, b_ in zip(outs[0], outs[1]))               # deterministic
+    logp, loss, dW, db, dh = outs[0]
+    h32, W32, b32 = h.astype(np.float32).astype(np.float64), W.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    ref_logp = mo.log_softmax(h32 @ W32 + b32)
+    assert np.abs(logp.cpu().numpy() - ref_logp).max() < 2e-5
+    assert abs(float(loss[0]) - mo.sparse_ce_from_logits(ref_logp, y)) < 2e-5
+    dz = mo.sparse_ce_from_logits_grad(ref_logp, y) * B * scale                     # the oracle's gradient is of the shard mean
+    _close(dW.cpu().numpy(), h32.T @ dz, 2e-5)
+    _close(db.cpu().numpy(), dz.sum(axis=0), 2e-5)
+    ref_dh = dz @ W32.T
+    if relu:
+        ref_dh = ref_dh * (h32 > 0)
+    _close(dh.cpu().numpy(), ref_dh, 2e-5)
+    # a label outside [0, N): NaN loss, zero gradient row, everything else untouched by it
+    y2 = y.copy(); y2[0] = N
+    nv.check(nv.lib.lidbox_softmax_head_fwd_bwd(nv.ptr(hd), nv.ptr(Wd), nv.ptr(bd), nv.ptr(_dev(y2, np.int32)), B, K, N, scale, relu,
+                                                nv.ptr(logp), nv.ptr(loss), nv.ptr(dW), nv.ptr(db), nv.ptr(dh), nv.ptr(ws), wsb, st))
+    assert np.isnan(float(loss[0])) and not dh[0].any() and torch.isfinite(dW).all()
+    if B > 1:
+        _close(dh[1:].cpu().numpy(), ref_dh[1:], 2e-5)
+
+
+def test_softmax_head_limits():
+    from lidbox_amd import _native as nv
+    assert nv.lib.lidbox_softmax_head_supported(512, 33) == 0 and nv.lib.lidbox_softmax_head_supported(3000, 32) == 1
+    x = torch.zeros(64, device="cuda")
+    with pytest.raises(ValueError):
+        nv.check(nv.lib.lidbox_softmax_head_fwd_bwd(nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 1, 8, 33, 1.0, 0, nv.ptr(x), nv.ptr(x),
+                                                    nv.ptr(x), nv.ptr(x), None, nv.ptr(x), 256, nv.current_stream()))
+    with pytest.raises(ValueError):                              # workspace too small
+        nv.check(nv.lib.lidbox_softmax_head_fwd_bwd(nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 4, 8, 2, 1.0, 0, nv.ptr(x), nv.ptr(x),
+                                                    nv.ptr(x), nv.ptr(x), None, nv.ptr(x), 16, nv.current_stream()))
