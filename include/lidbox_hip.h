@@ -170,6 +170,12 @@ int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t workspace_byte
  * gemm_rows8_kernel (the same tile worked by twice the waves; nn / nt only). */
 int lidbox_gemm_plan_waves(int kind, long M, int N, int K, size_t workspace_bytes);
 
+/* 1 when lidbox_gemm_nn / _nt (kind 0 / 1) or lidbox_gemm_tn (kind 2; K = K1) would run this shape on the persistent
+ * stream-K kernels (csrc/gemm_sk.h: 128 x 128 tiles, LDS-DMA ring, in-launch fixed-order reduce) given 16-byte aligned
+ * operands and a workspace of workspace_bytes.  The workspace needs no initialisation (the arrival counters kept in its
+ * first 16 KiB carry a launch epoch); as before, two calls that may run concurrently must not share a workspace. */
+int lidbox_gemm_plan_is_stream_k(int kind, long M, int N, int K, size_t workspace_bytes);
+
 /* What the calling thread's most recent lidbox_gemm_nn / _nt / _tn call put on the stream (for profiling tools: it lets a
  * HIP-event bracket around the call be compared with rocprofv3's per-kernel averages).  out3 = {kernels of the
  * instantiation lidbox_gemm_plan_query names, GEMM kernels of another instantiation (the remainder of a tail split is

@@ -34,7 +34,10 @@
 // Roofline: MFMA fp32, 157.3 TFLOP/s.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gemm_shared.h"
+#include "gemm_sk.h"
 #include "gemm_tuned.h"
 
 namespace {
@@ -614,6 +617,134 @@ __global__ void colsum_stage2(const float* __restrict__ partial, int slices, int
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// persistent stream-K kernels (gemm_sk.h): eligibility, plans, launches
+// ------------------------------------------------------------------------------------------------
+// LIDBOX_GEMM_SK=0 keeps every launch on the kernels of this file (A/B aid).  LIDBOX_GEMM_SK_GRID / _MIN_FLOP are test
+// aids: a small persistent grid and no size floor let small problems exercise every branch of the stream-K schedule.
+inline bool sk_enabled() {
+    const char* e = getenv("LIDBOX_GEMM_SK");
+    return !(e && atoi(e) == 0);
+}
+inline unsigned sk_grid() {
+    if (const char* e = getenv("LIDBOX_GEMM_SK_GRID")) {
+        const int g = atoi(e);
+        if (g >= 1 && g <= NUM_CU * SK_WGCU) return (unsigned)g;
+    }
+    return NUM_CU * SK_WGCU;
+}
+inline double sk_min_flop() {
+    if (const char* e = getenv("LIDBOX_GEMM_SK_MIN_FLOP")) return atof(e);
+    return 3.0e9;                              // below this the slab traffic of 768 workgroups outweighs the balance
+}
+constexpr int SK_MIN_SPAN = 8;                 // K steps per workgroup
+constexpr int SK_PART_STEPS = 16;              // K steps of one part of a remainder tile
+
+// launch epoch of the arrival counters (gemm_sk.h): 1 .. 2^24 - 1
+inline unsigned sk_next_epoch() {
+    static std::atomic<unsigned> e{0};
+    unsigned v;
+    do v = e.fetch_add(1u) + 1u; while ((v & 0xffffffu) == 0u);
+    return v & 0xffffffu;
+}
+
+struct SkRows {
+    bool ok = false;
+    SkPlan pl{};
+    unsigned P = 0;
+    size_t ws_need = 0;
+};
+
+// Where the stream-K rows kernel is the default (measured per x-vector / CNN layer at bs 256, profiles/r03_gemm_sk_ab.txt):
+// forward GEMMs with a long contraction.  With K = 512 a tile's epilogue is a fifth of its life and the whole-tile rounds
+// of a persistent grid run their epilogues in phase, and the dgrad epilogues (ReLU mask / accumulate: dependent loads of
+// the old values at the end of a tile) sit on the critical path of the LAST contributor of a streamed tile -- the classic
+// kernels, eight small tiles per CU at different phases, hide both better.  LIDBOX_GEMM_SK_ALL=1 lifts the policy (tests,
+// A/B runs).
+inline bool sk_rows_policy(int kind, int K) {
+    if (const char* e = getenv("LIDBOX_GEMM_SK_ALL")) {
+        if (atoi(e) != 0) return true;
+    }
+    return kind == 0 && K >= 1024;
+}
+
+SkRows sk_rows_plan(int kind, long M, int N, int K) {
+    SkRows c;
+    if (!sk_enabled() || !sk_rows_policy(kind, K) || M < SK_BM || K % 4 != 0 || 2.0 * (double)M * N * K < sk_min_flop()) return c;
+    const unsigned P = sk_grid();
+    if (P % 8 != 0) return c;
+    SkPlan& pl = c.pl;
+    pl.tiles_n = (int)lbx_cdiv(N, SK_BN);
+    const long T = lbx_cdiv(M, SK_BM) * pl.tiles_n;
+    if (T > 0x3fffffffL) return c;
+    pl.ntiles = (int)T;
+    pl.nk = (int)lbx_cdiv(K, SK_BK);
+    pl.ktail = K - (pl.nk - 1) * SK_BK;
+    // Whole rounds of tiles go to the workgroups one tile each.  What remains:
+    //   * after >= 1 whole round: each remaining tile is cut into g parts of >= SK_PART_STEPS K steps for g workgroups of one
+    //     XCD (workgroups of a CU share its matrix pipes, so a few longer workgroups cost only the efficiency of the tail,
+    //     while every slab costs 64 KB each way);
+    //   * fewer tiles than workgroups: every workgroup takes the same number of K steps (stream-K proper).
+    pl.dp_rounds = (int)(T / P);
+    pl.sk_first = pl.dp_rounds * (int)P;
+    pl.sk_tiles = (int)T - pl.sk_first;
+    pl.parts = 0;
+    if (pl.dp_rounds > 0 && pl.sk_tiles > 0) {
+        long g = pl.nk / SK_PART_STEPS;
+        if (g > (long)(P / 8) / lbx_cdiv(pl.sk_tiles, 8)) g = (long)(P / 8) / lbx_cdiv(pl.sk_tiles, 8);
+        if (g < 1) g = 1;
+        if (g > 200) g = 200;
+        pl.parts = (int)g;
+    }
+    if (pl.parts == 0 && pl.sk_tiles > 0 && (long)pl.sk_tiles * pl.nk < (long)P * SK_MIN_SPAN) return c;
+    if (pl.parts == 0 && pl.sk_tiles > 0 && (long)pl.nk * P / ((long)pl.sk_tiles * pl.nk) + 2 > 250) return c;      // arrivals of a tile fit 8 bits
+    if ((size_t)pl.sk_tiles * sizeof(unsigned) > SK_COUNTER_BYTES) return c;
+    c.P = P;
+    c.ws_need = SK_COUNTER_BYTES + (size_t)P * 2 * SK_SLAB * sizeof(float);
+    c.ok = true;
+    return c;
+}
+
+// every lane offset of the saddr loads must fit 32 bits
+inline bool sk_extent_ok(const lidbox_rows_t& r, long cols) {
+    const double last = (double)(r.batch > 0 ? r.batch - 1 : 0) * r.batch_stride + (double)(r.rows_per_batch > 0 ? r.rows_per_batch - 1 : 0) * r.row_stride + cols + 64;
+    return last * 4.0 < 4.0e9;
+}
+
+void sk_set_lds_attr() {
+    static const bool done = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_sk_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_sk_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_sk_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
+        return true;
+    }();
+    (void)done;
+}
+
+struct SkTn {
+    bool ok = false;
+    int splits = 0, tiles_n = 0, ntiles = 0;
+    long rows_per_split = 0;
+    size_t ws_need = 0;
+};
+
+SkTn sk_tn_plan(long M, int K1, int N) {
+    SkTn c;
+    // (frame4's wgrad, 4.4 GFLOP at bs 256, measured 55 vs 52 us on the classic kernel: the floor is twice the rows kernels')
+    if (!sk_enabled() || K1 % 4 != 0 || N % 4 != 0 || 2.0 * (double)M * N * K1 < 2.0 * sk_min_flop()) return c;
+    c.tiles_n = (int)lbx_cdiv(N, SK_BN);
+    c.ntiles = (int)lbx_cdiv(K1, SK_BM) * c.tiles_n;
+    long g = (long)sk_grid() / c.ntiles;
+    if (g < 1) g = 1;
+    long rps = lbx_cdiv(lbx_cdiv(M, g), SK_BK) * SK_BK;
+    if (rps < 8 * SK_BK) return c;
+    c.rows_per_split = rps;
+    c.splits = (int)lbx_cdiv(M, rps);
+    c.ws_need = ((size_t)c.splits * K1 * N + (size_t)c.splits * N) * sizeof(float);
+    c.ok = true;
+    return c;
+}
+
 struct RowsChoice {
     int bm, bn, splits, k_per_split;
     bool no_tail_split = false;
@@ -769,6 +900,22 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     RowsOutD Co{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
     float* P = (float*)ws;
 
+    // persistent stream-K kernel (gemm_sk.h): aligned problems that fill the chip, workspace permitting
+    if (al && !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && aligned16(ws)) {
+        const SkRows sk = sk_rows_plan(B_KINNER ? 1 : 0, M, N, K);
+        if (sk.ok && wsb >= sk.ws_need && sk_extent_ok(A, K)) {
+            sk_set_lds_attr();
+            g_last_launches[0] = 1;
+            g_first_tile[0] = SK_BM; g_first_tile[1] = SK_BN;
+            unsigned* counters = (unsigned*)ws;
+            float* slabs = (float*)((char*)ws + SK_COUNTER_BYTES);
+            hipLaunchKernelGGL((gemm_sk_rows_kernel<B_KINNER>), dim3(sk.P), dim3(256), SK_LDS_BYTES, st, Ad, Bm, ldb, Co, M, K, N, epi,
+                               aux, sk.pl, sk_next_epoch(), counters, slabs);
+            LBX_LAUNCH_OK();
+            return LIDBOX_OK;
+        }
+    }
+
     // Tail quantisation: with W workgroups on 256 CUs the last partial round runs at the pace of a
     // full one (measured: the last 3 % of frame2's rows cost 21 % of its time).  When the main
     // decomposition is unsplit and leaves such a tail, launch it over the largest row prefix whose
@@ -871,6 +1018,19 @@ extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t wor
     return LIDBOX_OK;
 }
 
+extern "C" int lidbox_gemm_plan_is_stream_k(int kind, long M, int N, int K, size_t workspace_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 2) return 0;
+    if (kind == 2) {
+        const SkTn t = sk_tn_plan(M, K, N);
+        return t.ok && workspace_bytes >= t.ws_need;
+    }
+    {
+        const SkRows r = sk_rows_plan(kind, M, N, K);
+        return r.ok && workspace_bytes >= r.ws_need && (kind == 1 || N % 4 == 0);
+    }
+    return LIDBOX_OK;
+}
+
 extern "C" int lidbox_gemm_plan_waves(int kind, long M, int N, int K, size_t workspace_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 1) return 4;
     return choose_rows(kind, M, N, K, workspace_bytes).waves;
@@ -889,6 +1049,10 @@ extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
     for (int kind = 0; kind < 2; ++kind) {
         const RowsChoice ch = choose_rows(kind, M, N, K, (size_t)64 << 20);
         if (ch.splits > 1 && (size_t)ch.splits * M * N * sizeof(float) > need) need = (size_t)ch.splits * M * N * sizeof(float);
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+        const SkRows sk = sk_rows_plan(kind, M, N, K);
+        if (sk.ok && sk.ws_need > need) need = sk.ws_need;
     }
     return need;
 }
@@ -917,7 +1081,10 @@ extern "C" int lidbox_gemm_nt(lidbox_rows_t A, const float* Bm, long ldb, lidbox
 extern "C" size_t lidbox_gemm_tn_workspace(int M, int K1, int N) {
     if (M <= 0 || K1 <= 0 || N <= 0) return 0;
     const TnPlan pl = tn_plan(M, K1, N);
-    return ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+    size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+    const SkTn sk = sk_tn_plan(M, K1, N);
+    if (sk.ok && sk.ws_need > need) need = sk.ws_need;
+    return need;
 }
 
 extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N,
@@ -929,11 +1096,28 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     const long M = (long)A.batch * A.rows_per_batch;
     LBX_ARG(M == (long)Bd.batch * Bd.rows_per_batch, "A and B row counts differ");
     LBX_ARG(M >= 1, "M >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        // persistent-body kernel (gemm_sk.h) over a regular split of the contraction rows
+        const SkTn sk = sk_tn_plan(M, K1, N);
+        if (sk.ok && !getenv("LIDBOX_GEMM_TN_PLAN") && workspace && aligned16(workspace) && workspace_bytes >= sk.ws_need &&
+            rows_aligned(A) && rows_aligned(Bd) && sk_extent_ok(A, K1) && sk_extent_ok(Bd, N)) {
+            sk_set_lds_attr();
+            g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1;
+            float* P = (float*)workspace;
+            float* Pc = bias_grad ? P + (size_t)sk.splits * K1 * N : nullptr;
+            hipLaunchKernelGGL(gemm_sk_tn_kernel, dim3((unsigned)(sk.ntiles * sk.splits)), dim3(256), SK_LDS_BYTES, st, to_dev(A),
+                               to_dev(Bd), P, Pc, M, K1, N, sk.tiles_n, sk.ntiles, sk.rows_per_split);
+            LBX_LAUNCH_OK();
+            launch_splitk_reduce((const float*)P, (const float*)Pc, sk.splits, (long)K1 * N, N, Cm, ldc, accumulate, bias_grad, st);
+            LBX_LAUNCH_OK();
+            return LIDBOX_OK;
+        }
+    }
     const TnPlan pl = tn_plan(M, K1, N);
     const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
     LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_tn_workspace)");
     g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1;
-    hipStream_t st = (hipStream_t)stream;
     const int tiles_n = (int)lbx_cdiv(N, pl.bn);
     const int ntiles = (int)(lbx_cdiv(K1, pl.bm) * tiles_n);
     const bool al = rows_aligned(A) && rows_aligned(Bd) && K1 % 4 == 0 && N % 4 == 0;

@@ -1,0 +1,599 @@
+// gemm_sk.h -- persistent stream-K fp32 MFMA GEMM kernels (round 3), included by gemm.hip.
+//
+// Same contracts as gemm_rows_kernel / gemm_tn_kernel (gemm.hip): Conv1D(padding="causal") / Dense forward, dgrad and
+// wgrad of lidbox/models/xvector.py:38-43,53-64 and cnn.py:32-41 as implicit-row GEMMs.  Used for 16-byte aligned
+// problems large enough to fill the chip; everything else stays on the kernels of gemm.hip.
+//
+// What is different (measurements: profiles/r03_skgemm_*.txt, prototype tools/micro/skgemm.hip)
+//   * Operand tiles reach LDS by LDS-DMA (global_load_lds_dwordx4, saddr form: wave-uniform 64-bit base in SGPRs + one
+//     32-bit byte offset per lane) into a ring of SK_STAGES stages of BK = 16: no VGPR staging, no ds_write, and the loads
+//     of step t+2 are in flight while step t multiplies.  One s_barrier per K step.
+//   * K-inner operands ([row][k] in HBM: A of nn / nt, B of nt) land as [row][16 floats]; the four 16-byte chunks of a
+//     row are XOR-swizzled by (row >> 2) & 3 on the SOURCE side (the LDS image of a DMA is lane-linear) and read with
+//     conflict-free ds_read_b128: lanes 0-31 take chunk 2s, lanes 32-63 chunk 2s+1, so MFMA j of sub-step s contracts
+//     k = {8s + j, 8s + 4 + j} -- a permutation of the contraction index applied to both operands alike.
+//     K-outer operands ([k][col]: B of nn, both operands of tn) land as [k][128] and are read with ds_read_b32.
+//   * The four DMA pieces of a wave go out one per MFMA group and the operand reads of the next sub-step behind the
+//     first group of the current one: an LDS-DMA issue holds its wave ~56 cycles, four in a row left the matrix pipe
+//     idle (ablation: profiles/r03_skgemm_ablation_*.txt).
+//   * nn / nt: persistent grid of 256 x SK_WGCU workgroups.  Tiles beyond the whole rounds are streamed (stream-K):
+//     every workgroup gets the same number of K steps of them, partial tiles go to slabs in accumulator order, and the
+//     LAST contributor of a tile (write-through slab stores -> arrival ticket -> write-through loads; nobody ever waits,
+//     no cache-wide fence) sums the slabs in k order
+//     -- deterministic -- and runs the fused epilogue.  The streamed spans start at different k offsets, so epilogues and
+//     prologues of co-resident workgroups fall into each other's K loops instead of hitting HBM all at once.
+//   * Co-resident workgroups of a CU rotate one s_setprio step (slot = blockIdx.x / 256): between equal priorities the
+//     matrix pipe goes to the OLDEST wave, which let the first resident run ahead and left the last one alone at the end
+//     (profiles/r03_skgemm_timeline_per_cu.txt).
+//   * tn (wgrad): the same body over a regular split of the contraction rows; slabs in P[split][K1][N] order feed the
+//     fixed-order reduce of gemm_shared.h.
+#pragma once
+
+#include "gemm_shared.h"
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 16;
+constexpr int SK_A_STAGE = SK_BM * SK_BK, SK_B_STAGE = SK_BK * SK_BN, SK_STAGE = SK_A_STAGE + SK_B_STAGE;   // floats
+#ifndef LBX_SK_STAGES
+#define LBX_SK_STAGES 3
+#endif
+#ifndef LBX_SK_WGCU
+#define LBX_SK_WGCU 3
+#endif
+#ifndef LBX_SK_PRIO_ROTATE
+#define LBX_SK_PRIO_ROTATE 1               // 0: leave the arbitration to age (A/B aid)
+#endif
+constexpr int SK_STAGES = LBX_SK_STAGES;          // LDS ring depth: 48 KB per workgroup, three workgroups per CU
+constexpr int SK_WGCU = LBX_SK_WGCU;              // resident workgroups per CU the persistent grid is sized for
+constexpr int SK_SLAB = SK_BM * SK_BN;            // floats of one partial tile
+constexpr size_t SK_COUNTER_BYTES = 16384;        // head of the workspace: one arrival counter per streamed tile (<= 4096)
+constexpr size_t SK_LDS_BYTES = (size_t)SK_STAGES * SK_STAGE * sizeof(float);
+
+__device__ __attribute__((aligned(16))) float g_sk_zero[4];        // source of the chunks past K of a tail step
+
+struct SkPlan {
+    int tiles_n, ntiles;
+    int nk;                 // K steps per tile (the last one may be partial)
+    int ktail;              // valid k of the last step: 4 .. 16, a multiple of 4
+    int dp_rounds;          // whole tiles per workgroup
+    int sk_tiles, sk_first; // tiles [sk_first, sk_first + sk_tiles) are streamed
+    int parts;              // 0: every workgroup takes an equal span of the streamed K steps (fewer tiles than workgroups);
+                            // g >= 1: each streamed tile is cut into g equal parts, one workgroup each (the remainder of
+                            //         whole rounds: few slabs, the other workgroups go straight to their whole tiles)
+};
+
+// LDS-DMA of 16 bytes per lane: lane i of the wave lands at lds_dst + 16 i (M0 = wave-uniform destination).
+__device__ __forceinline__ void sk_dma_s(const float* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void sk_dma_f(const float* p, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(p), "s"(lds_dst)
+                 : "memory");
+}
+// a pointer every lane holds the same value of, provably so for the compiler (SGPR pair): the "s" operands of the DMA
+// statements otherwise cost a waterfall loop each
+__device__ __forceinline__ const float* sk_uniform(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+template <int N>
+__device__ __forceinline__ void sk_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- K-inner operand: 128 rows x 16 k per step.  Piece i of wave w = rows 16 (2w + i) .. + 15, four lanes per row.
+struct SkInner {
+    const float* sb;        // wave-uniform: base + k of the next step to issue
+    unsigned vo[2];         // this lane's byte offsets of its two pieces (row offset + swizzled chunk)
+    int rd;                 // LDS read base of this lane (floats inside the operand's stage)
+
+    // roff[i]: element offset of this lane's row of piece i relative to base (rows outside the matrix already clamped)
+    __device__ __forceinline__ void init(const float* base, const long (&roff)[2], int k0, int lane, int wsub) {
+        sb = sk_uniform(base + k0);
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);             // row within the piece = lane >> 2
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vo[i] = (unsigned)((roff[i] + chunk * 4) * 4);
+        rd = (wsub * 64 + (lane & 31)) * 16;
+    }
+    __device__ __forceinline__ void issue(int i, unsigned dst) const { sk_dma_s(sb, vo[i], dst); }
+    // the step holds only kvalid < 16 contraction values: later chunks come from the zero chunk
+    __device__ __forceinline__ void issue_tail(int i, unsigned dst, int kvalid, int lane) const {
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
+        sk_dma_f(chunk * 4 < kvalid ? p : g_sk_zero, dst);
+    }
+    __device__ __forceinline__ void advance() { sb += SK_BK; }
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[2][4]) const {
+        const int slot = (2 * s2 + (lane >> 5)) ^ ((lane >> 2) & 3);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f32x4_t x = *reinterpret_cast<const f32x4_t*>(st + rd + b * 32 * 16 + slot * 4);
+            v[b][0] = x[0]; v[b][1] = x[1]; v[b][2] = x[2]; v[b][3] = x[3];
+        }
+    }
+};
+
+// ---- K-outer operand of a plain matrix X[k][ld]: 16 k x 128 columns per step.  Piece i of wave w = k rows 2 (2w + i), + 1.
+struct SkOuter {
+    const float* sb;
+    unsigned vo[2];
+    long step;
+    int rd;
+
+    __device__ __forceinline__ void init(const float* base, long ld, int col0, int ncols, int k0, int lane, int wv, int wsub) {
+        sb = sk_uniform(base + (long)k0 * ld + col0);
+        int c = (lane & 31) * 4;
+        if (col0 + c >= ncols) c = 0;                                // columns outside the matrix: never stored
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vo[i] = (unsigned)(((long)(2 * (wv * 2 + i) + (lane >> 5)) * ld + c) * 4);
+        step = (long)SK_BK * ld;
+        rd = (4 * (lane >> 5)) * 128 + wsub * 64 + (lane & 31);
+    }
+    __device__ __forceinline__ void issue(int i, unsigned dst) const { sk_dma_s(sb, vo[i], dst); }
+    __device__ __forceinline__ void issue_tail(int i, unsigned dst, int kvalid, int lane, int wv) const {
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
+        sk_dma_f(2 * (wv * 2 + i) + (lane >> 5) < kvalid ? p : g_sk_zero, dst);
+    }
+    __device__ __forceinline__ void advance() { sb += step; }
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[2][4]) const {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b][j] = st[rd + (8 * s2 + j) * 128 + b * 32];
+    }
+};
+
+// ---- K-outer operand whose k index is an implicit row (tn: the contraction runs over the rows of the activations).
+//      Offsets are 32-bit element offsets (the host checks the extent), advanced with adds only.
+struct SkOuterRows {
+    const float* sb;        // base + first column of the tile
+    int off[2];             // element offset of this lane's row of piece i for the next step to issue (+ its column)
+    unsigned tt[2];         // its position inside the utterance
+    int a_step, a_wrap;
+    unsigned rpb;
+    int mleft[2];           // rows of the slice at or after this lane's row (<= 0: the row is past the slice)
+    int rd;
+
+    __device__ __forceinline__ void init(const RowsD& X, int col0, int ncols, long mbeg, long mend, int lane, int wv, int wsub) {
+        sb = sk_uniform(X.base + col0);
+        int c = (lane & 31) * 4;
+        if (col0 + c >= ncols) c = 0;
+        a_step = (int)(SK_BK * X.rs);
+        a_wrap = X.batch == 1 ? 0 : (int)(X.bs - (long)X.rpb * X.rs);
+        rpb = X.batch == 1 ? 0xffffffffu : (unsigned)X.rpb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long m = mbeg + 2 * (wv * 2 + i) + (lane >> 5);
+            const unsigned bq = X.batch == 1 ? 0u : (unsigned)m / rpb;
+            tt[i] = (unsigned)m - (X.batch == 1 ? 0u : bq * rpb);
+            off[i] = (int)((long)bq * X.bs + (long)tt[i] * X.rs) + c;
+            mleft[i] = (int)(mend - m);
+        }
+        rd = (4 * (lane >> 5)) * 128 + wsub * 64 + (lane & 31);
+    }
+    // tail (wave-uniform): the step may hold rows past the slice, which contribute zeros
+    __device__ __forceinline__ void issue(int i, unsigned dst, bool tail) {
+        if (!tail) {
+            sk_dma_s(sb, (unsigned)off[i] * 4u, dst);
+        } else {
+            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + (size_t)((unsigned)off[i] * 4u));
+            sk_dma_f(mleft[i] > 0 ? p : g_sk_zero, dst);
+        }
+        mleft[i] -= SK_BK;
+        tt[i] += SK_BK;
+        off[i] += a_step;
+        while (tt[i] >= rpb) { tt[i] -= rpb; off[i] += a_wrap; }
+    }
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[2][4]) const {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b][j] = st[rd + (8 * s2 + j) * 128 + b * 32];
+    }
+};
+
+template <int J0, int J1>
+__device__ __forceinline__ void sk_mma(const float (&a)[2][4], const float (&b)[2][4], f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int j = J0; j < J1; ++j)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj)
+                acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bi][j], b[bj][j], acc[bi][bj], 0, 0, 0);
+}
+
+// The K loop over n steps of one work item.  issue(piece, step, lds_dst) puts piece 0..3 (A0, A1, B0, B1) of step `step`
+// (0-based inside the item) on its way, next() is called once all four pieces of a step are out; reads come through
+// ra / rb (stage base, sub-step) -> registers.
+template <class IssueF, class NextF, class ReadA, class ReadB>
+__device__ __forceinline__ void sk_kloop(float* smem, unsigned lds0, int wv, int n, int prio_slot, IssueF issue, NextF next,
+                                         ReadA ra, ReadB rb, f32x16 (&acc)[2][2]) {
+    auto dst = [&](int stage, int piece) -> unsigned {
+        return lds0 + (unsigned)((stage * SK_STAGE + (piece >> 1) * SK_A_STAGE + (wv * 2 + (piece & 1)) * 256) * 4);
+    };
+    // every wave is past the previous item's LDS reads once it arrives here (its MFMAs consumed them)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int s = 0; s < SK_STAGES - 1; ++s)
+        if (s < n) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) issue(pc, s, dst(s, pc));
+            next();
+        }
+    if (n >= SK_STAGES - 1) sk_wait_vm<(SK_STAGES - 2) * 4>();
+    else sk_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+    ra(smem, 0, a0);
+    rb(smem + SK_A_STAGE, 0, b0);
+    int cur = 0;
+    for (int t = 0; t < n; ++t) {
+        // publish step t+1: its pieces were issued SK_STAGES-2 steps ago
+        if (t + 1 < n) {
+            if (SK_STAGES >= 4 && t + SK_STAGES - 2 < n) sk_wait_vm<(SK_STAGES >= 4 ? (SK_STAGES - 3) * 4 : 0)>();
+            else sk_wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        int nxt = cur + 1;
+        if (nxt == SK_STAGES) nxt = 0;
+        const bool more = t + SK_STAGES - 1 < n;
+        int tgt = cur + SK_STAGES - 1;
+        if (tgt >= SK_STAGES) tgt -= SK_STAGES;
+        const float* st = smem + cur * SK_STAGE;
+        if (SK_WGCU > 1 && LBX_SK_PRIO_ROTATE) {
+            if ((unsigned)(t + prio_slot) % (unsigned)SK_WGCU == 0) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        sk_mma<0, 1>(a0, b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        ra(st, 1, a1);
+        rb(st + SK_A_STAGE, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<1, 2>(a0, b0, acc);
+        if (more) issue(0, t + SK_STAGES - 1, dst(tgt, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<2, 3>(a0, b0, acc);
+        if (more) issue(1, t + SK_STAGES - 1, dst(tgt, 1));
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<3, 4>(a0, b0, acc);
+        if (more) issue(2, t + SK_STAGES - 1, dst(tgt, 2));
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<0, 1>(a1, b1, acc);
+        if (more) {
+            issue(3, t + SK_STAGES - 1, dst(tgt, 3));
+            next();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < n) {
+            const float* sn = smem + nxt * SK_STAGE;
+            ra(sn, 0, a0);
+            rb(sn + SK_A_STAGE, 0, b0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<1, 4>(a1, b1, acc);
+        cur = nxt;
+    }
+    if (SK_WGCU > 1 && LBX_SK_PRIO_ROTATE) __builtin_amdgcn_s_setprio(0);
+}
+
+// partial tile <-> slab, accumulator order: [(wave * 4 + block) * 4 + r4][lane][4] -- 1 KB per wave access.
+// Slabs travel WRITE-THROUGH (sc1 stores, sc1 loads): a hand-off needs no agent-scope release / acquire fence then -- a
+// release (buffer_wbl2) writes back EVERY dirty line of the XCD's L2, the output tiles of 95 other workgroups included,
+// and cost more than the K loop of a short tile (frame4, bs 256: 103 us with fences vs 51 us on the classic kernels).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_slab_rsrc(const float* slab) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sk_uniform(slab)), 0, SK_SLAB * 4, 0x00020000);
+}
+__device__ __forceinline__ void sk_slab_store(float* slab, const f32x16 (&acc)[2][2], int wv, int lane) {
+    const __amdgpu_buffer_rsrc_t r = sk_slab_rsrc(slab);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4_t x = {acc[bi][bj][4 * r4], acc[bi][bj][4 * r4 + 1], acc[bi][bj][4 * r4 + 2], acc[bi][bj][4 * r4 + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), r,
+                                                       ((((wv * 4 + bi * 2 + bj) * 4 + r4) * 64 + lane) * 4) * 4, 0, /*sc1*/ 16);
+            }
+}
+__device__ __forceinline__ void sk_slab_add(const float* slab, f32x16 (&acc)[2][2], int wv, int lane) {
+    const __amdgpu_buffer_rsrc_t r = sk_slab_rsrc(slab);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4_t x = __builtin_bit_cast(
+                    f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, ((((wv * 4 + bi * 2 + bj) * 4 + r4) * 64 + lane) * 4) * 4, 0, /*sc1*/ 16));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[bi][bj][4 * r4 + j] += x[j];
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K] . B)    B_KINNER = false: B[K][N] (nn)   true: B[N][K] (nt)
+// grid = 256 x SK_WGCU persistent workgroups.  ws: [SK_COUNTER_BYTES of arrival counters][2 slabs per workgroup];
+// epoch: 1 .. 2^24 - 1, different for launches that may find each other's counters.
+// ------------------------------------------------------------------------------------------------
+template <bool B_KINNER>
+__global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
+                                                                    long M, int K, int N, int epi, const float* __restrict__ aux,
+                                                                    SkPlan pl, unsigned epoch, unsigned* __restrict__ counters,
+                                                                    float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const unsigned P = gridDim.x;
+    const unsigned pid = xcd_chunk_id(blockIdx.x, P);
+    const int prio_slot = (int)(blockIdx.x >> 8);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)sk_smem);
+    const int nk = pl.nk;
+    const long total = (long)pl.sk_tiles * nk;
+
+    // one work item: K steps [kb, ke) of a tile; returns with the partial sums in acc
+    auto run_item = [&](int tile, int kb, int ke, f32x16 (&acc)[2][2], long& m0, int& n0) {
+        const int tn = tile % pl.tiles_n, tm = tile / pl.tiles_n;
+        m0 = (long)tm * SK_BM;
+        n0 = tn * SK_BN;
+        SkInner oa;
+        {
+            long roff[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                long r = m0 + 16 * (wv * 2 + i) + (lane >> 2);
+                if (r >= M) r = m0;
+                roff[i] = row_offset(A, (unsigned)r);
+            }
+            oa.init(A.base, roff, kb * SK_BK, lane, wm);
+        }
+        SkInner obi;
+        SkOuter obo;
+        if (B_KINNER) {
+            long roff[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                long r = n0 + 16 * (wv * 2 + i) + (lane >> 2);
+                if (r >= N) r = n0;
+                roff[i] = r * ldb;
+            }
+            obi.init(Bm, roff, kb * SK_BK, lane, wn);
+        } else {
+            obo.init(Bm, ldb, n0, N, kb * SK_BK, lane, wv, wn);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int n = ke - kb;
+        const int tail_step = (ke == nk && pl.ktail < SK_BK) ? n - 1 : -1;       // step of this item that is partial in k
+        auto issue = [&](int pc, int step, unsigned d) {
+            if (step == tail_step) {
+                if (pc < 2) oa.issue_tail(pc, d, pl.ktail, lane);
+                else if (B_KINNER) obi.issue_tail(pc - 2, d, pl.ktail, lane);
+                else obo.issue_tail(pc - 2, d, pl.ktail, lane, wv);
+            } else {
+                if (pc < 2) oa.issue(pc, d);
+                else if (B_KINNER) obi.issue(pc - 2, d);
+                else obo.issue(pc - 2, d);
+            }
+        };
+        auto next = [&]() {
+            oa.advance();
+            if (B_KINNER) obi.advance();
+            else obo.advance();
+        };
+        auto ra = [&](const float* st, int s2, float (&v)[2][4]) { oa.read(st, lane, s2, v); };
+        auto rb = [&](const float* st, int s2, float (&v)[2][4]) {
+            if (B_KINNER) obi.read(st, lane, s2, v);
+            else obo.read(st, lane, s2, v);
+        };
+        sk_kloop(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc);
+    };
+
+    f32x16 acc[2][2];
+    long m0;
+    int n0;
+
+    // Work items of this workgroup: its share of the streamed tiles first (their fix-ups then overlap the whole tiles of
+    // the other workgroups), then its whole tiles.  ONE call site each for the K loop and the epilogue.
+    long it = 0, end = 0;
+    // parts mode: block b = (xcd, idx): tile (idx / g) * 8 + xcd, part idx % g -- the parts of a tile sit on one XCD (their
+    // slabs and the A panel in one L2), the streamed tiles are dealt round-robin over the XCDs and CUs
+    const int g = pl.parts;
+    int pt_tile = -1, pt_part = 0;
+    if (pl.sk_tiles > 0) {
+        if (g == 0) {
+            it = (long)pid * total / P;
+            end = (long)(pid + 1) * total / P;
+        } else {
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            const int t = (idx / g) * 8 + xcd;
+            if (t < pl.sk_tiles) { pt_tile = t; pt_part = idx % g; }
+        }
+    }
+    int which = 0, d = 0;
+    for (;;) {
+        int tile, kb, ke, t = 0;
+        if (pt_tile >= 0) {
+            t = pt_tile;
+            pt_tile = -1;
+            kb = (int)((long)pt_part * nk / g);
+            ke = (int)((long)(pt_part + 1) * nk / g);
+            tile = pl.sk_first + t;
+        } else if (it < end) {
+            t = (int)(it / nk);
+            kb = (int)(it - (long)t * nk);
+            ke = kb + (int)(end - it);
+            if (ke > nk) ke = nk;
+            it += ke - kb;
+            tile = pl.sk_first + t;
+        } else if (d < pl.dp_rounds) {
+            tile = d * (int)P + (int)pid;
+            kb = 0;
+            ke = nk;
+            ++d;
+        } else {
+            break;
+        }
+        run_item(tile, kb, ke, acc, m0, n0);
+        // Opaque per-item copies of what the epilogue code addresses with: its per-lane / per-row address terms otherwise
+        // count as invariants of the item loop, get hoisted above the K loop and spilled (60 VGPRs + 110 SGPRs of scratch;
+        // a scratch-using launch cost ~70 us each).
+        int lane_e = lane, wm_e = wm, wn_e = wn, wv_e = wv;
+        RowsOutD Cd_e = Cd;
+        asm volatile("" : "+v"(lane_e), "+s"(wm_e), "+s"(wn_e), "+s"(wv_e), "+s"(Cd_e.rs), "+s"(Cd_e.bs));
+        bool finish = kb == 0 && ke == nk;
+        bool reducer = false;
+        if (!finish) {
+            // ---- partial tile: slab, ticket, and the last arriver finishes the tile
+            const long my_slab = g == 0 ? (long)pid * 2 + which : (long)blockIdx.x * 2;
+            sk_slab_store(slabs + my_slab * SK_SLAB, acc, wv_e, lane_e);
+            ++which;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(sk_smem);
+            if (tid == 0) {
+                // arrival counter = (launch epoch << 8) | arrivals.  A word that carries another epoch -- zero after a finished
+                // tile, anything at all in a workspace that was never used -- counts as zero arrivals, so the workspace
+                // needs no initialisation; the last arriver leaves the word zero (a graph replay, whose epoch is frozen,
+                // starts from there).
+                unsigned old = __hip_atomic_load(counters + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned cnt;
+                for (;;) {
+                    cnt = (old >> 8) == epoch ? (old & 255u) : 0u;
+                    if (__hip_atomic_compare_exchange_strong(counters + t, &old, (epoch << 8) | (cnt + 1u), __ATOMIC_RELAXED,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        break;
+                }
+                *flag = cnt;
+            }
+            __syncthreads();
+            const unsigned ticket = *flag;
+            // contributors of tile t, in k order: parts mode: the g blocks of the tile; span mode: workgroups pa .. pb
+            long pa = 0, pb = g - 1;
+            if (g == 0) {
+                const long ib = (long)t * nk, ie = ib + nk;
+                pa = ib * P / total;
+                while (pa > 0 && pa * total / P > ib) --pa;
+                while ((pa + 1) * total / P <= ib) ++pa;
+                pb = (ie - 1) * P / total;
+                while (pb + 1 < (long)P && (pb + 1) * total / P < ie) ++pb;
+                while (pb * total / P >= ie) --pb;
+            }
+            __syncthreads();                                    // everybody has read the flag word
+            if (ticket == (unsigned)(pb - pa)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (long p = pa; p <= pb; ++p) {               // k order: a fixed summation order whoever arrives last
+                    long sl;
+                    if (g == 0) {
+                        const long b = p * total / P, e = (p + 1) * total / P;
+                        const long t0 = b / nk;
+                        const bool first_partial = !(b == t0 * nk && e >= (t0 + 1) * nk);
+                        sl = p * 2 + ((t0 == t) ? 0 : (first_partial ? 1 : 0));
+                    } else {
+                        const long idx0 = (long)(t >> 3) * g;       // first idx of the tile's blocks on XCD t & 7
+                        sl = (((idx0 + p) << 3) | (t & 7)) * 2;
+                    }
+                    sk_slab_add(slabs + sl * SK_SLAB, acc, wv_e, lane_e);
+                }
+                finish = true;
+                reducer = true;
+            }
+        }
+        if (finish) store_rows_tile<2, 2>(acc, m0, n0, wm_e, wn_e, lane_e, 0, M, N, epi, aux, Cd_e, nullptr, 0);
+        if (reducer && tid == 0) __hip_atomic_store(counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = column sums of B[Mslice]
+// grid = ntiles x splits (consecutive blocks = the tiles of one slice), rows_per_split a multiple of 16.
+// (Slabs in accumulator order with a matching reduce kernel were tried: 16-byte slab stores, but the reduce then scatters
+// four rows per thread -- 135 vs 124 us on frame1's wgrad, 59 vs 55 on frame4's; not kept.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_tn_kernel(RowsD A, RowsD Bd, float* __restrict__ P, float* __restrict__ Pc,
+                                                                  long M, int K1, int N, int tiles_n, int ntiles, long rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)sk_smem);
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int i0 = tk * SK_BM, n0 = tn * SK_BN;
+    const long mbeg = (long)split * rows_per_split;
+    long mend = mbeg + rows_per_split;
+    if (mend > M) mend = M;
+    const int n = (int)((mend - mbeg + SK_BK - 1) / SK_BK);
+    const int prio_slot = (int)(blockIdx.x >> 8);
+
+    SkOuterRows oa, ob;
+    oa.init(A, i0, K1, mbeg, mend, lane, wv, wm);
+    ob.init(Bd, n0, N, mbeg, mend, lane, wv, wn);
+    const int tail_step = ((mend - mbeg) % SK_BK != 0) ? n - 1 : -1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
+    const bool do_csum = (Pc != nullptr) && tk == 0 && tid < SK_BN;
+    auto issue = [&](int pc, int step, unsigned d) {
+        if (pc < 2) oa.issue(pc, d, step == tail_step);
+        else ob.issue(pc - 2, d, step == tail_step);
+    };
+    auto next = [&]() {};
+    auto ra = [&](const float* st, int s2, float (&v)[2][4]) { oa.read(st, lane, s2, v); };
+    // the bias gradient (column sums of dY) comes from the B stage in LDS: the sub-step 0 read of a stage adds its 16 rows
+    auto rb = [&](const float* st, int s2, float (&v)[2][4]) {
+        ob.read(st, lane, s2, v);
+        if (do_csum && s2 == 0) {
+#pragma unroll
+            for (int kk = 0; kk < SK_BK; ++kk) csum += st[kk * 128 + tid];
+        }
+    };
+    sk_kloop(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc);
+
+    float* Pd = P + (long)split * K1 * N;
+    const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+        const int col = n0 + wn * 64 + bj * 32 + l;
+        if (col >= N) continue;
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
+            }
+    }
+    if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
+}
+
+}  // namespace

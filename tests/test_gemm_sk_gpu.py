@@ -1,0 +1,221 @@
+"""
+GPU parity of the persistent stream-K fp32 GEMM kernels (csrc/gemm_sk.h) through the C ABI against float64 numpy.
+
+The kernels are the default for large aligned problems (>= 3 GFLOP); the two test aids LIDBOX_GEMM_SK_GRID /
+LIDBOX_GEMM_SK_MIN_FLOP shrink the persistent grid and drop the size floor so that SMALL problems walk every branch of the
+schedule: whole tiles, streamed tiles with 2 .. many contributors, the in-launch fixed-order reduce, K tails (K % 16 != 0),
+ragged M / N edges, implicit-row (conv layout) operands and outputs, every epilogue.  Full-size shapes (BASELINE
+configs[1], bs 256) run on the real 768-workgroup grid at the end.
+Tolerance: rel 2e-5 of the result scale vs float64 (fp32 round-off of a K-long fmaf chain), as in test_ops_gpu.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float32))).cuda()
+
+
+def _rows(t, bs, rs, batch, rpb, off_floats=0):
+    from lidbox_amd import _native as nv
+    return nv.Rows(t.data_ptr() + 4 * off_floats, bs, rs, batch, rpb)
+
+
+def _close(got, ref, rel=2e-5):
+    scale = max(1e-30, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= rel * scale, (err, scale)
+
+
+def _garbage_ws(nbytes):
+    """a workspace that was never initialised: the arrival counters must cope (launch epochs)"""
+    ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device="cuda")
+    ws.fill_(0xAB)
+    return ws
+
+
+@pytest.fixture
+def small_grid(monkeypatch):
+    def set_grid(g):
+        monkeypatch.setenv("LIDBOX_GEMM_SK_GRID", str(g))
+        monkeypatch.setenv("LIDBOX_GEMM_SK_MIN_FLOP", "0")
+        monkeypatch.setenv("LIDBOX_GEMM_SK_ALL", "1")
+    return set_grid
+
+
+# grid 16 / 40: whole rounds + a remainder cut into 1 .. 5 parts per tile; 64 / 104: equal spans, every tile split (T < P)
+@pytest.mark.parametrize("grid", [16, 40, 64, 104])
+@pytest.mark.parametrize("M,K,N", [(1300, 600, 500), (777, 200, 1500), (1408, 1500, 512)])
+def test_stream_k_nn_nt_match_float64(grid, M, K, N, small_grid):
+    from lidbox_amd import _native as nv
+    small_grid(grid)
+    rng = np.random.default_rng(M + 3 * K + grid)
+    A, Bm, Bt = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((N, K))
+    bias, mask = rng.standard_normal(N), rng.standard_normal((M, N))
+    a, b, bt, bi, mk = _dev(A), _dev(Bm), _dev(Bt), _dev(bias), _dev(mask)
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_rows_workspace(M, N, K)
+    if not nv.lib.lidbox_gemm_plan_is_stream_k(0, M, N, K, wsb):
+        pytest.skip("spans shorter than 8 K steps at this grid: the planner keeps the classic kernels")
+    ws = _garbage_ws(wsb)
+    c = torch.full((M, N), 7.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), wsb, st))
+    first = c.clone()
+    _close(c.cpu().numpy(), np.maximum(A @ Bm + bias, 0))
+    # same launch again: bit-identical (fixed summation order whoever arrives last)
+    c.fill_(-1.0)
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), wsb, st))
+    assert torch.equal(c, first)
+    c.fill_(-2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_ACCUM_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0) - 2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0))
+    # the classic kernels on the same inputs: same values to fp32 round-off (different summation order)
+    ref = torch.zeros_like(c)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(ref, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
+                                   nv.ptr(mk), None, 0, st))
+    _close(c.cpu().numpy(), ref.cpu().numpy().astype(np.float64))
+
+
+@pytest.mark.parametrize("grid", [16, 40])
+def test_stream_k_conv_layout_rows(grid, small_grid):
+    """the conv layout: A rows are overlapping causal windows of a padded [B, Tp, C] activation (k = 3, stride 2), the dgrad
+    output rows are strided windows with an utterance gap, masks read through the same descriptor"""
+    from lidbox_amd import _native as nv
+    small_grid(grid)
+    rng = np.random.default_rng(grid)
+    Bn, T, C, k, s, Co = 24, 99, 128, 3, 2, 256
+    To, Tp = (T - 1) // s + 1, T + k - 1
+    X = np.zeros((Bn, Tp, C))
+    X[:, k - 1:, :] = rng.standard_normal((Bn, T, C))
+    W, bias = rng.standard_normal((k * C, Co)) * 0.1, rng.standard_normal(Co)
+    M, K = Bn * To, k * C
+    win = np.stack([X[:, t * s:t * s + k, :].reshape(Bn, K) for t in range(To)], axis=1).reshape(M, K)
+    x, w, bi = _dev(X), _dev(W), _dev(bias)
+    y = torch.full((Bn, To, Co), 5.0, device="cuda")
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_rows_workspace(M, Co, K)
+    assert nv.lib.lidbox_gemm_plan_is_stream_k(0, M, Co, K, wsb)
+    ws = _garbage_ws(wsb)
+    Ad = _rows(x, Tp * C, s * C, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_nn(Ad, nv.ptr(w), Co, _rows(y, To * Co, Co, Bn, To), K, Co, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), wsb, st))
+    ref_y = np.maximum(win @ W + bias, 0)
+    _close(y.cpu().numpy().reshape(M, Co), ref_y)
+    # dgrad of tap group 0 (taps 0..s-1): dX windows [t*s, t*s + s) += mask * (dY . W[:s*C]^T), rows strided by s*C
+    dY = rng.standard_normal((M, Co))
+    dy = _dev(dY)
+    dx = torch.zeros((Bn, Tp, C), device="cuda")
+    Kd, Nd = Co, s * C
+    wsb2 = nv.lib.lidbox_gemm_rows_workspace(M, Nd, Kd)
+    ws2 = _garbage_ws(wsb2)
+    Cd = _rows(dx, Tp * C, s * C, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, Cd, Kd, Nd, nv.EPI_RELU_MASK, nv.ptr(x), nv.ptr(ws2), wsb2, st))
+    got = dx.cpu().numpy()
+    full = dY @ W[:Nd].T                                          # [M, s*C]
+    ref = np.zeros((Bn, Tp, C))
+    for b_ in range(Bn):
+        for t in range(To):
+            blk = full[b_ * To + t].reshape(s, C)
+            rows = X[b_, t * s:t * s + s, :]
+            ref[b_, t * s:t * s + s, :] = blk * (rows > 0)
+    _close(got, ref)
+
+
+@pytest.mark.parametrize("grid", [8, 40, 256])
+@pytest.mark.parametrize("M,K1,N", [(5000, 200, 500), (3333, 512, 1500)])
+def test_stream_k_body_wgrad_matches_float64(grid, M, K1, N, small_grid):
+    from lidbox_amd import _native as nv
+    small_grid(grid)
+    rng = np.random.default_rng(M + grid)
+    A, Bm = rng.standard_normal((M, K1)), rng.standard_normal((M, N))
+    a, b = _dev(A), _dev(Bm)
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_tn_workspace(M, K1, N)
+    if not nv.lib.lidbox_gemm_plan_is_stream_k(2, M, N, K1, wsb):
+        pytest.skip("slices shorter than 128 rows at this grid")
+    ws = _garbage_ws(wsb)
+    c = torch.full((K1, N), 3.0, device="cuda")
+    g = torch.full((N,), -1.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K1, N, 0, nv.ptr(g), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), A.T @ Bm)
+    _close(g.cpu().numpy(), Bm.sum(0), rel=1e-5)
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K1, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K1, N, 1, nv.ptr(g), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), 2 * (A.T @ Bm))
+    _close(g.cpu().numpy(), 2 * Bm.sum(0), rel=1e-5)
+
+
+def test_stream_k_body_wgrad_conv_layout(small_grid):
+    """wgrad whose A rows are the causal windows of a padded activation (utterance wrap inside the contraction)"""
+    from lidbox_amd import _native as nv
+    small_grid(16)
+    rng = np.random.default_rng(5)
+    Bn, T, C, k, s, Co = 40, 50, 64, 3, 1, 128
+    To, Tp = T, T + k - 1
+    X = np.zeros((Bn, Tp, C))
+    X[:, k - 1:, :] = rng.standard_normal((Bn, T, C))
+    M, K = Bn * To, k * C
+    win = np.stack([X[:, t:t + k, :].reshape(Bn, K) for t in range(To)], axis=1).reshape(M, K)
+    dY = rng.standard_normal((M, Co))
+    x, dy = _dev(X), _dev(dY)
+    dw = torch.zeros((K, Co), device="cuda")
+    g = torch.zeros((Co,), device="cuda")
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_tn_workspace(M, K, Co)
+    assert nv.lib.lidbox_gemm_plan_is_stream_k(2, M, Co, K, wsb)
+    ws = _garbage_ws(wsb)
+    nv.check(nv.lib.lidbox_gemm_tn(_rows(x, Tp * C, s * C, Bn, To), _rows(dy, 0, Co, 1, M), nv.ptr(dw), Co, K, Co, 0, nv.ptr(g),
+                                   nv.ptr(ws), wsb, st))
+    _close(dw.cpu().numpy(), win.T @ dY)
+    _close(g.cpu().numpy(), dY.sum(0), rel=1e-5)
+
+
+@pytest.mark.parametrize("kind,M,K,N", [("nn", 50688, 200, 512), ("nn", 8448, 512, 1500), ("nt", 8448, 1500, 512),
+                                         ("nt", 25344, 512, 1024), ("nn", 25344, 1536, 512), ("tn", 8448, 512, 1500), ("tn", 50688, 200, 512)])
+def test_stream_k_full_size_layers_on_the_real_grid(kind, M, K, N, monkeypatch):
+    """x-vector layer shapes at bs 256 (BASELINE configs[1]) on the production 768-workgroup grid vs torch float64 on the GPU
+    (LIDBOX_GEMM_SK_ALL: also the shapes the default policy leaves to the classic kernels)"""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM_SK_ALL", "1")
+    gen = torch.Generator(device="cuda").manual_seed(M + K)
+    st = nv.current_stream()
+    if kind == "tn":
+        a = torch.randn(M, K, device="cuda", generator=gen)
+        b = torch.randn(M, N, device="cuda", generator=gen)
+        wsb = nv.lib.lidbox_gemm_tn_workspace(M, K, N)
+        assert nv.lib.lidbox_gemm_plan_is_stream_k(2, M, N, K, wsb)
+        ws = _garbage_ws(wsb)
+        c = torch.zeros(K, N, device="cuda")
+        g = torch.zeros(N, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_tn(_rows(a, 0, K, 1, M), _rows(b, 0, N, 1, M), nv.ptr(c), N, K, N, 0, nv.ptr(g), nv.ptr(ws), wsb, st))
+        ref = a.double().t() @ b.double()
+        assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        refg = b.double().sum(0)
+        assert float((g.double() - refg).abs().max()) <= 1e-5 * float(refg.abs().max())
+        return
+    a = torch.randn(M, K, device="cuda", generator=gen)
+    wsb = nv.lib.lidbox_gemm_rows_workspace(M, N, K)
+    assert nv.lib.lidbox_gemm_plan_is_stream_k(0 if kind == "nn" else 1, M, N, K, wsb)
+    ws = _garbage_ws(wsb)
+    c = torch.zeros(M, N, device="cuda")
+    if kind == "nn":
+        b = torch.randn(K, N, device="cuda", generator=gen)
+        bias = torch.randn(N, device="cuda", generator=gen)
+        nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bias),
+                                       nv.ptr(ws), wsb, st))
+        ref = torch.relu(a.double() @ b.double() + bias.double())
+    else:
+        b = torch.randn(N, K, device="cuda", generator=gen)
+        mask = torch.randn(M, N, device="cuda", generator=gen)
+        nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(b), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_RELU_MASK, nv.ptr(mask),
+                                       nv.ptr(ws), wsb, st))
+        ref = (a.double() @ b.double().t()) * (mask > 0)
+    assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())

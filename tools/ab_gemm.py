@@ -1,6 +1,8 @@
 """Same-process A/B timing of GEMM library variants built by tools/ab_build.py: every x-vector GEMM launch
 (B = 256) is timed alternately on each library, several rounds, medians reported.
-usage: python tools/ab_gemm.py tools/ab/libA.so tools/ab/libB.so [...]"""
+usage: python tools/ab_gemm.py tools/ab/libA.so tools/ab/libB.so [...]
+A variant is a library path, optionally followed by environment settings that apply to its launches only:
+    python tools/ab_gemm.py lidbox_amd/csrc/liblidbox_hip.so:LIDBOX_GEMM_SK=0 lidbox_amd/csrc/liblidbox_hip.so:LIDBOX_GEMM_SK=1"""
 import ctypes as C
 import os
 import statistics
@@ -35,9 +37,20 @@ def timeit(fn):
 
 
 def main():
-    libs = [(os.path.basename(p), load(p)) for p in sys.argv[1:]]
+    libs, envs = [], {}
+    for arg in sys.argv[1:]:
+        path, _, env = arg.partition(":")
+        name = os.path.basename(path) + (":" + env if env else "")
+        libs.append((name, load(path)))
+        envs[name] = dict(kv.split("=", 1) for kv in env.split(",")) if env else {}
+    all_keys = sorted({k for e in envs.values() for k in e})
+
+    def use(name):
+        for k in all_keys:
+            os.environ.pop(k, None)
+        os.environ.update(envs[name])
     st = nv.current_stream()
-    rws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    rws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     RW, RN = nv.ptr(rws), rws.numel()
     cases = []
     layers = [("frame1", 198, 40, 5, 1, 512), ("frame2", 198, 512, 3, 2, 512), ("frame3", 99, 512, 3, 3, 512),
@@ -54,7 +67,7 @@ def main():
         A, Y, DY = rows(x, Tp * Cc, s * Cc, B, To), rows(y, To * Co, Co, B, To), rows(dy, To * Co, Co, B, To)
         cases.append((name + " fwd", 2.0 * M * K * Co,
                       lambda lib, A=A, W=W, Co=Co, Y=Y, K=K, bias=bias: lib.lidbox_gemm_nn(A, nv.ptr(W), Co, Y, K, Co, nv.EPI_BIAS_RELU, nv.ptr(bias), RW, RN, st)))
-        wsb = nv.lib.lidbox_gemm_tn_workspace(M, K, Co)
+        wsb = max(lib.lidbox_gemm_tn_workspace(M, K, Co) for _, lib in libs)
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda"); keep.append(ws)
         cases.append((name + " wgrad", 2.0 * M * K * Co,
                       lambda lib, A=A, DY=DY, dW=dW, Co=Co, K=K, bias=bias, ws=ws, wsb=wsb: lib.lidbox_gemm_tn(A, DY, nv.ptr(dW), Co, K, Co, 0, nv.ptr(bias), nv.ptr(ws), wsb, st)))
@@ -80,14 +93,16 @@ def main():
         cases.append((name + " wgrad", fl, lambda lib, A=A, DY=DY, dW=dW, N=N, K=K, bias=bias, ws=ws, wsb=wsb: lib.lidbox_gemm_tn(A, DY, nv.ptr(dW), N, K, N, 0, nv.ptr(bias), nv.ptr(ws), wsb, st)))
         cases.append((name + " dgrad", fl, lambda lib, DY=DY, W=W, N=N, DX=DX, K=K, x=x: lib.lidbox_gemm_nt(DY, nv.ptr(W), N, DX, N, K, nv.EPI_RELU_MASK, nv.ptr(x), RW, RN, st)))
     totals = {n: 0.0 for n, _ in libs}
-    print("%-16s" % "launch" + "".join("%22s" % n for n, _ in libs))
+    print("%-16s" % "launch" + "".join("%22s" % n[-22:] for n, _ in libs))
     for cname, fl, fn in cases:
         t = {n: [] for n, _ in libs}
         for n, lib in libs:
+            use(n)
             nv.check(fn(lib))
         torch.cuda.synchronize()
         for _ in range(ROUNDS):
             for n, lib in libs:
+                use(n)
                 t[n].append(timeit(lambda: fn(lib)))
         line = "%-16s" % cname
         for n, _ in libs:
