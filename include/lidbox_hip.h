@@ -409,8 +409,10 @@ int lidbox_cavg_result(const float* tp, const float* fn, const float* fp_pairs, 
 
 /* tf.keras.optimizers.Adam dense update (keras_utils.py:137-140; epsilon 1e-7):
  *   t = ++state[0];  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps)
- * `state` is a 16-byte device block {int64 step; float lr_t; float pad} owned by the caller and
- * advanced ON THE DEVICE, so a captured hipGraph replays with the right bias correction.
+ * `state` is a 16-byte device block {int64 step; float lr_t; float lr_now} owned by the caller and
+ * advanced ON THE DEVICE, so a captured hipGraph replays with the right bias correction.  lr_now > 0 replaces `lr` for
+ * the step (tf.keras.optimizers.schedules.*, keras_utils.py:137-139: the host writes the schedule's value there before
+ * the step, also ahead of a graph replay); zero-initialised state = constant `lr`.
  * grad_scale multiplies g first (1/world_size after an all-reduce(sum)). */
 int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, void* state,

@@ -5,8 +5,10 @@
 //   lidbox/models/xvector_2d.py:36,43      FrameLayer2D: Conv2D(activation="relu") -> BatchNormalization -> (Dropout)
 // Keras defaults restated: momentum 0.99, epsilon 1e-3, gamma 1 / beta 0, moving_mean 0 / moving_variance 1;
 // training normalises with the batch mean and the POPULATION variance of the batch and moves the running statistics by
-// (1 - momentum) towards them (the fused kernel's Bessel-corrected variance is rescaled by (n-1)/n before the update, so the
-// running variance tracks the population variance too); inference uses the running statistics.
+// (1 - momentum) towards them -- the running VARIANCE towards the Bessel-corrected batch variance var * n / (n - 1): the
+// layer's 4-D input with axis = -1 takes tf.keras' fused path, which keeps the fused kernel's unbiased estimate for the
+// running average (`_bessels_correction_test_only` is True by default) while normalising with the population variance;
+// inference uses the running statistics.
 //
 // All four kernels are HBM-bound streams over x (and dy): column sums are accumulated in FLOAT64 per thread (one pass gives
 // mean and E[x^2] without cancellation trouble), partials [slices][C] are combined in a fixed order (deterministic, no
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const double* __restrict_
     shift[c] = beta[c] - muf * sc;
     if (moving_mean) {
         moving_mean[c] = moving_mean[c] * momentum + muf * (1.f - momentum);
-        moving_var[c] = moving_var[c] * momentum + varf * (1.f - momentum);
+        const float unbiased = R > 1 ? (float)(var * ((double)R / (double)(R - 1))) : varf;
+        moving_var[c] = moving_var[c] * momentum + unbiased * (1.f - momentum);
     }
 }
 

@@ -44,12 +44,17 @@ def read_weights_file(path):
 
 
 def _set_weights_checked(model, weights, path):
-    """every parameter of the model must be in the file with the model's shape (Keras `load_weights` raises likewise)"""
+    """every parameter of the model must be in the file with the model's shape (Keras `load_weights` raises likewise);
+    entries the model has no use for (variables of layers outside the hot path saved next to it) are ignored with a warning"""
     want = dict(list(model.layout.items()) + list(getattr(model, "state_layout", {}).items()))
     missing = sorted(set(want) - set(weights))
     extra = sorted(set(weights) - set(want))
-    if missing or extra:
-        raise ValueError("%s does not match the model: missing %s, unexpected %s" % (path, missing[:6], extra[:6]))
+    if missing:
+        raise ValueError("%s does not match the model: missing %s (unexpected %s)" % (path, missing[:6], extra[:6]))
+    if extra:
+        import warnings
+        warnings.warn("%s: ignoring %d entries the model does not have (%s ...)" % (path, len(extra), extra[:3]))
+        weights = {k: v for k, v in weights.items() if k in want}
     for name, (_, shape) in want.items():
         if tuple(np.shape(weights[name])) != tuple(shape):
             raise ValueError("%s: %s has shape %s, the model expects %s" % (path, name, np.shape(weights[name]), tuple(shape)))
@@ -205,14 +210,43 @@ def _loss_from_config(loss_conf):
     raise ValueError("unsupported loss %r" % (cls,))
 
 
+def lr_schedule_from_config(conf):
+    """reference keras_utils.py:137-139: `getattr(tf.keras.optimizers.schedules, cls)(**kwargs)` as a plain function of the
+    optimizer step (Keras' `iterations`: 0 at the first update).  ExponentialDecay and PiecewiseConstantDecay with their
+    Keras argument names and semantics; float32 arithmetic as the Keras ops."""
+    cls, kw = conf["cls"], dict(conf.get("kwargs", {}))
+    if cls == "ExponentialDecay":
+        lr0, steps, rate = np.float32(kw["initial_learning_rate"]), np.float32(kw["decay_steps"]), np.float32(kw["decay_rate"])
+        staircase = bool(kw.get("staircase", False))
+
+        def sched(step):
+            p = np.float32(step) / steps
+            if staircase:
+                p = np.floor(p)
+            return float(lr0 * np.power(rate, p, dtype=np.float32))
+        return sched
+    if cls == "PiecewiseConstantDecay":
+        boundaries, values = list(kw["boundaries"]), [float(v) for v in kw["values"]]
+        if len(values) != len(boundaries) + 1:
+            raise ValueError("PiecewiseConstantDecay: len(values) must be len(boundaries) + 1")
+
+        def sched(step):
+            for b, v in zip(boundaries, values):
+                if step <= b:
+                    return v
+            return values[-1]
+        return sched
+    raise ValueError("unsupported learning-rate schedule %r (ExponentialDecay, PiecewiseConstantDecay)" % (cls,))
+
+
 def _optimizer_from_config(opt_conf):
-    """reference keras_utils.py:135-140: Adam with Keras argument names"""
+    """reference keras_utils.py:135-140: Adam with Keras argument names; `lr_scheduler` as there"""
     if opt_conf["cls"] != "Adam":
         raise ValueError("only the Adam optimizer is implemented (got %r)" % (opt_conf["cls"],))
     kw = dict(opt_conf.get("kwargs", {}))
-    if "lr_scheduler" in kw:
-        raise ValueError("learning-rate schedules are not implemented")
     out = {}
+    if "lr_scheduler" in kw:
+        out["lr_schedule"] = lr_schedule_from_config(kw.pop("lr_scheduler"))
     for src, dst in (("learning_rate", "lr"), ("lr", "lr"), ("beta_1", "beta_1"), ("beta_2", "beta_2"), ("epsilon", "epsilon")):
         if src in kw:
             out[dst] = float(kw[src])
@@ -369,6 +403,7 @@ class KerasWrapper:
                 losses.append((self.trainer.train_step(xs, ys).clone(), xs.shape[0]))
                 n += xs.shape[0]
             logs = {"loss": float(sum(float(l) * b for l, b in losses) / max(1, n))}
+            self.trainer.sync_state()        # data parallelism: the replicas' BatchNormalization running statistics, averaged before they are used
             if validation_dataset is not None and (epoch + 1) % int(kwargs["validation_freq"]) == 0:
                 logs.update({"val_" + k: v for k, v in self.evaluate(validation_dataset).items()})
             if kwargs["verbose"]:

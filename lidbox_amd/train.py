@@ -75,6 +75,15 @@ class GradSync:
         self.world = dist.get_world_size(group) if self.active else 1
         self.cuda = flat.is_cuda
         self._pending = []
+        # RCCL collectives can be captured into a hipGraph (torch.distributed's nccl backend records them on its own
+        # communication stream, forked from / joined to the capturing stream); gloo stages through the host and cannot
+        self.capturable = bool(self.active and self.cuda and dist.get_backend(group) == "nccl")
+
+    def warm(self):
+        """one eager collective on the gradient buffer's device: the communicator must exist before a capture starts"""
+        if self.active:
+            t = torch.zeros(1, dtype=self.flat.dtype, device=self.flat.device)
+            self.dist.all_reduce(t, group=self.group)
 
     @property
     def num_buckets(self):
@@ -143,7 +152,8 @@ class Trainer:
     """
 
     def __init__(self, model, loss="sparse_categorical_crossentropy", optimizer=None, feature=None,
-                 use_graph=True, num_buckets=2, group=None, metric=None, overlap_wgrad=False, overlap_head_wgrad=False):
+                 use_graph=True, num_buckets=2, group=None, metric=None, overlap_wgrad=False, overlap_head_wgrad=False,
+                 sync_state_every_step=False):
         self.model = model
         self.device = model.device
         opt = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
@@ -182,11 +192,13 @@ class Trainer:
         # bs 256): the three fork / join edges cost the graph more than the ~35 us of small kernels they could hide.  Off.
         if overlap_head_wgrad and model.head_wgrad_stream is None:
             model.head_wgrad_stream = torch.cuda.Stream(device=self.device)
+        self.sync_state_every_step = bool(sync_state_every_step)
         self.use_graph = bool(use_graph)
         self._warming = False            # True during the pre-capture warm-up pass: streaming metrics must not count it
         self._graphs = {}
         self._static = {}
-        self._global_batch = None        # sum of the ranks' shard sizes (set at the first step under data parallelism)
+        self._global_batch = {}          # local shard size -> sum of the ranks' shard sizes (data parallelism)
+        self._step_global_batch = None   # what the caller of the running step passed (train_step(..., global_batch=))
 
     # ---------------------------------------------------------------- pieces of a step
     def _forward_loss(self, ws, inputs, labels):
@@ -212,7 +224,7 @@ class Trainer:
             # SpatialDropout1D of the training pass (xvector.py:50-51, cnn.py:29-30); the Adam step counter on the device
             # keys the mask, so every replay of the captured step draws a new one
             nv.check(lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, in_bs, model.channel_dropout_rate,
-                                                model.dropout_seed, nv.ptr(self.adam_state), None, st))
+                                                self._dropout_seed(), nv.ptr(self.adam_state), None, st))
         # BatchNormalization layers: batch statistics; the running statistics move once per real step (not in warm-up passes)
         B = ws.B
         scale = self._loss_scale(B)
@@ -249,17 +261,30 @@ class Trainer:
         if self.loss_kind == "nll" and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)
 
+    def _dropout_seed(self):
+        """the model's dropout seed, offset per data-parallel rank: the mask of local row b must not repeat on every rank"""
+        seed = self.model.dropout_seed
+        if self.sync.active:
+            seed = (seed + 0x9E3779B97F4A7C15 * (self.sync.dist.get_rank(self.sync.group) + 1)) & (2 ** 63 - 1)
+        return seed
+
     def _loss_scale(self, B):
-        """d(mean loss)/d(per-example loss).  Under data parallelism the mean is over the GLOBAL batch (the ranks' shard
-        sizes summed once, at the first step), so that uneven shards (`shard_bounds` gives the remainder to the first
-        ranks) still yield the gradient of the global-batch mean after the all-reduce(sum)."""
+        """d(mean loss)/d(per-example loss).  Under data parallelism the mean is over the GLOBAL batch, so that uneven
+        shards (`shard_bounds` gives the remainder to the first ranks) still yield the gradient of the global-batch mean
+        after the all-reduce(sum).  The global batch is what the caller passed to `train_step(..., global_batch=)`;
+        without it the ranks' shard sizes are summed (one small all-reduce) the first time a LOCAL shard size is seen
+        and remembered per local size -- enough when every rank's shard size changes together (a smaller last batch
+        split by `shard_bounds` changes it on every rank or is passed explicitly).  The scale is a kernel argument, so
+        it is part of the key of a captured step."""
         if not self.sync.active:
             return 1.0 / B
-        if self._global_batch is None:
+        if self._step_global_batch is not None:
+            return 1.0 / self._step_global_batch
+        if B not in self._global_batch:
             t = torch.tensor([B], dtype=torch.int64, device=self.device)
             self.sync.dist.all_reduce(t, group=self.sync.group)
-            self._global_batch = int(t.item())
-        return 1.0 / self._global_batch
+            self._global_batch[B] = int(t.item())
+        return 1.0 / self._global_batch[B]
 
     def _ap_buffers(self, ws, D):
         if not hasattr(ws, "ap_zn"):
@@ -293,6 +318,18 @@ class Trainer:
     def _backward_lo(self, ws):
         for k in range(1, self.num_stages):
             self._backward_stage(ws, k)
+
+    def _set_lr(self):
+        """learning-rate schedule (opt["lr_schedule"]: optimizer step, 0-based as Keras' `iterations` -> lr): the value of
+        the coming step goes into the device-side Adam state, where the captured optimizer kernels read it"""
+        sched = self.opt.get("lr_schedule")
+        if sched is None:
+            return
+        if not hasattr(self, "_lr_view"):
+            self._lr_view = self.adam_state[12:16].view(torch.float32)
+            self._host_step = self.step_count
+        self._lr_view.fill_(float(sched(self._host_step)))
+        self._host_step += 1
 
     def _adam(self):
         o = self.opt
@@ -347,7 +384,23 @@ class Trainer:
                     self._warming = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(self.device)
-            if self.sync.active:
+            if self.sync.active and self.sync.capturable and not os.environ.get("LIDBOX_SEGMENTED_SYNC"):
+                # RCCL: the bucket all-reduces are captured INSIDE the step's graph (fork to the backend's communication
+                # stream behind the stage that completes the bucket, join ahead of Adam): an N-GPU step is one graph
+                # launch like the single-GPU step.  LIDBOX_SEGMENTED_SYNC=1 keeps the host-launched collectives between
+                # graph segments (the only form gloo supports).
+                def whole():
+                    nb = self.sync.num_buckets
+                    for k in range(self.num_stages):
+                        segs[k]()
+                        if k < nb:
+                            self.sync.launch(nb - 1 - k)
+                    self.sync.wait()
+                    segs[-1]()
+                self.sync.warm()
+                torch.cuda.synchronize(self.device)
+                entry["graphs"] = (self._capture(whole).replay,)
+            elif self.sync.active:
                 # the optimizer segment is two small kernels behind the last collective: launched directly unless
                 # LIDBOX_ADAM_GRAPH is set (a graph launch costs more than it saves there)
                 adam_seg = self._capture(segs[-1]).replay if os.environ.get("LIDBOX_ADAM_GRAPH") else segs[-1]
@@ -357,16 +410,20 @@ class Trainer:
         return entry
 
     # ---------------------------------------------------------------- public API
-    def train_step(self, inputs, labels):
+    def train_step(self, inputs, labels, global_batch=None):
         """One optimisation step on this rank's shard.  inputs: waveforms [B,N] (feature != None) or
         features [B,T,C]; labels int32 [B].  Both must stay alive and at the same address between
         calls that reuse the captured graph (pass the same tensors, refilled in place).
+        global_batch (data parallelism): the number of utterances of this step over ALL ranks; pass it whenever the ranks'
+        shard sizes do not all change together (see `_loss_scale`).
         Returns the device scalar holding this rank's mean loss."""
         inputs = nv.require_gpu_tensor(inputs, "inputs", torch.float32)
         labels = nv.require_gpu_tensor(labels, "labels", torch.int32)
         if labels.dim() != 1 or labels.shape[0] != inputs.shape[0]:
             raise ValueError("labels must be [batch_size]")
-        key = (inputs.data_ptr(), labels.data_ptr(), tuple(inputs.shape), tuple(inputs.stride()))
+        key = (inputs.data_ptr(), labels.data_ptr(), tuple(inputs.shape), tuple(inputs.stride()),
+               None if global_batch is None else int(global_batch))
+        self._step_global_batch = None if global_batch is None else int(global_batch)
         with torch.cuda.device(self.device):
             entry = self._graphs.get(key)
             if entry is None:
@@ -375,6 +432,7 @@ class Trainer:
                 entry = self._build(inputs, labels)
                 self._graphs[key] = entry
             ws = entry["ws"]
+            self._set_lr()
             if entry["graphs"] is not None and len(entry["graphs"]) == 1:
                 entry["graphs"][0]()
             else:
@@ -386,15 +444,17 @@ class Trainer:
                         self.sync.launch(nb - 1 - k)              # bucket (nb-1-k) is complete after stage k
                 self.sync.wait()
                 run[-1]()                                         # Adam
-            self._sync_state()
+            if self.sync_state_every_step:
+                self.sync_state()
             return ws.loss[0]
 
-    def _sync_state(self):
+    def sync_state(self):
         """BatchNormalization running statistics under data parallelism: every replica normalises with ITS shard's batch
         statistics (tf.keras BatchNormalization under MirroredStrategy; the reference never asks for
-        SyncBatchNormalization) and moves its running statistics with them; the replicas' running statistics are then
-        averaged (the MEAN aggregation Keras declares for these variables), one small all-reduce per step, so every rank
-        checkpoints the same values."""
+        SyncBatchNormalization) and moves its running statistics with them; the replicas' running statistics are
+        averaged (the MEAN aggregation Keras declares for these variables) WHEN THEY ARE CONSUMED -- call this before
+        evaluating or checkpointing (`KerasWrapper.fit` does at the end of every epoch) -- so every rank then holds the
+        same values.  `Trainer(sync_state_every_step=True)` restores the per-step all-reduce."""
         state = getattr(self.model, "state", None)
         if not self.sync.active or not getattr(self.model, "state_layout", None):
             return
@@ -409,7 +469,12 @@ class Trainer:
             B = inputs.shape[0]
             T = self.feature["plan"].num_frames(inputs.shape[1]) if self.feature is not None else inputs.shape[1]
             ws = self.model.workspace(B, T)
-            self._forward_loss(ws, inputs, labels)
+            was = self._warming
+            self._warming = True                 # a probe, not a step: BatchNormalization running statistics and streaming metrics stay put
+            try:
+                self._forward_loss(ws, inputs, labels)
+            finally:
+                self._warming = was
             self.model.backward_ws(ws)
             return ws.loss[0], self.model.flat_grad
 

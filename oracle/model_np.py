@@ -397,14 +397,18 @@ def conv_freq_fwd(x, W, b, s, relu=True):
 
 
 def batchnorm_fwd(x, gamma, beta, moving_mean, moving_var, training, momentum=BN_MOMENTUM, eps=BN_EPSILON):
-    """BatchNormalization(axis=-1).  training: batch mean / population variance over every axis but the last, moving
-    statistics moved by (1 - momentum) towards them; inference: the moving statistics.  Returns (y, moving_mean, moving_var)."""
+    """BatchNormalization(axis=-1) on the 4-D conv output of xvector_2d.py:36 (tf.keras' fused path).  training: batch mean /
+    population variance over every axis but the last for the normalisation; the moving mean moves by (1 - momentum) towards
+    the batch mean, the moving variance towards the BESSEL-CORRECTED batch variance var * n / (n - 1) (the fused kernel's
+    estimate, which Keras keeps: `_bessels_correction_test_only` defaults to True); inference: the moving statistics.
+    Returns (y, moving_mean, moving_var)."""
     axes = tuple(range(x.ndim - 1))
     if training:
         mean = x.mean(axis=axes)
         var = ((x - mean) ** 2).mean(axis=axes)
+        n = x.size // x.shape[-1]
         moving_mean = moving_mean * momentum + mean * (1 - momentum)
-        moving_var = moving_var * momentum + var * (1 - momentum)
+        moving_var = moving_var * momentum + var * (n / (n - 1) if n > 1 else 1.0) * (1 - momentum)
     else:
         mean, var = moving_mean, moving_var
     return gamma * (x - mean) / np.sqrt(var + eps) + beta, moving_mean, moving_var

@@ -276,7 +276,7 @@ def test_gemm_plans_tuned_table_and_model(nv):
         assert waves in (4, 8) and (kind == 2 or nv.lib.lidbox_gemm_plan_waves(kind, M, N, K, 1 << 30) == waves)
         if kind == 2:
             assert out[2] >= 1 and out[2] * out[3] >= M and (out[2] - 1) * out[3] < M       # slices cover the M rows
-            assert nv.lib.lidbox_gemm_tn_workspace(M, K, N) == (out[2] * K * N + out[2] * N) * 4
+            assert nv.lib.lidbox_gemm_tn_workspace(M, K, N) >= (out[2] * K * N + out[2] * N) * 4
         else:
             assert out[2] == splits == 1 or out[2] * out[3] >= K
             if out[2] > 1:
@@ -287,6 +287,50 @@ def test_gemm_plans_tuned_table_and_model(nv):
         nv.check(nv.lib.lidbox_gemm_plan_query(kind, M, N, K, 1 << 26, out))
         assert out[0] in (64, 128) and out[1] in (64, 128) and out[2] >= 1
         assert out[2] * out[3] >= (M if kind == 2 else K)
+
+
+def test_stream_k_dispatch_policy_is_host_logic(nv, monkeypatch):
+    """which launches go to the persistent stream-K kernels (csrc/gemm_sk.h): forward GEMMs with K >= 1024 and wgrads, above
+    a size floor, workspace permitting; LIDBOX_GEMM_SK=0 / LIDBOX_GEMM_SK_ALL=1 move the policy (A/B and test aids)"""
+    q = nv.lib.lidbox_gemm_plan_is_stream_k
+    big = 1 << 30
+    for var in ("LIDBOX_GEMM_SK", "LIDBOX_GEMM_SK_ALL", "LIDBOX_GEMM_SK_GRID", "LIDBOX_GEMM_SK_MIN_FLOP"):
+        monkeypatch.delenv(var, raising=False)
+    # x-vector layers at bs 256 (SURVEY 8a): frame2 / frame3 forward (K = 1536) yes, K = 512 / 200 forward no, dgrad no
+    assert q(0, 25344, 512, 1536, big) == 1 and q(0, 8448, 512, 1536, big) == 1
+    assert q(0, 8448, 1500, 512, big) == 0 and q(0, 50688, 512, 200, big) == 0
+    assert q(1, 8448, 512, 1500, big) == 0 and q(1, 25344, 1024, 512, big) == 0
+    # wgrads (kind 2: K = K1) above 6 GFLOP yes, frame4's 4.4 GFLOP and the dense head no
+    assert q(2, 25344, 512, 1536, big) == 1 and q(2, 50688, 512, 200, big) == 1 and q(2, 8448, 1500, 512, big) == 1
+    assert q(2, 8448, 512, 512, big) == 0 and q(2, 256, 512, 3000, big) == 0
+    # the workspace decides too, and the queries cover what the kernels need (counters + two slabs per workgroup)
+    need = nv.lib.lidbox_gemm_rows_workspace(25344, 512, 1536)
+    assert need >= 16384 + 768 * 2 * 128 * 128 * 4
+    assert q(0, 25344, 512, 1536, need) == 1 and q(0, 25344, 512, 1536, need - 1) == 0
+    assert q(2, 25344, 512, 1536, nv.lib.lidbox_gemm_tn_workspace(25344, 1536, 512)) == 1
+    monkeypatch.setenv("LIDBOX_GEMM_SK", "0")
+    assert q(0, 25344, 512, 1536, big) == 0 and q(2, 25344, 512, 1536, big) == 0
+    monkeypatch.delenv("LIDBOX_GEMM_SK")
+    monkeypatch.setenv("LIDBOX_GEMM_SK_ALL", "1")
+    assert q(1, 25344, 1024, 512, big) == 1 and q(0, 8448, 1500, 512, big) == 1
+
+
+def test_lr_schedules_follow_keras(nv):
+    """tf.keras.optimizers.schedules.ExponentialDecay / PiecewiseConstantDecay (reference keras_utils.py:137-139) as host
+    functions of the optimizer step (Keras' 0-based `iterations`)"""
+    from lidbox_amd.models.keras_utils import _optimizer_from_config, lr_schedule_from_config
+    s = lr_schedule_from_config({"cls": "ExponentialDecay", "kwargs": {"initial_learning_rate": 0.01, "decay_steps": 100, "decay_rate": 0.5}})
+    assert s(0) == pytest.approx(0.01) and s(100) == pytest.approx(0.005) and s(50) == pytest.approx(0.01 * 0.5 ** 0.5, rel=1e-6)
+    st = lr_schedule_from_config({"cls": "ExponentialDecay",
+                                  "kwargs": {"initial_learning_rate": 0.01, "decay_steps": 100, "decay_rate": 0.5, "staircase": True}})
+    assert st(99) == pytest.approx(0.01) and st(100) == pytest.approx(0.005) and st(250) == pytest.approx(0.0025)
+    pw = lr_schedule_from_config({"cls": "PiecewiseConstantDecay", "kwargs": {"boundaries": [10, 20], "values": [1.0, 0.5, 0.1]}})
+    assert [pw(i) for i in (0, 10, 11, 20, 21, 1000)] == [1.0, 1.0, 0.5, 0.5, 0.1, 0.1]      # boundaries are inclusive on the left value
+    opt = _optimizer_from_config({"cls": "Adam", "kwargs": {"beta_1": 0.8, "lr_scheduler": {"cls": "PiecewiseConstantDecay",
+                                                                                          "kwargs": {"boundaries": [1], "values": [0.1, 0.01]}}}})
+    assert opt["beta_1"] == 0.8 and opt["lr_schedule"](0) == 0.1 and opt["lr_schedule"](2) == 0.01
+    with pytest.raises(ValueError):
+        lr_schedule_from_config({"cls": "CosineDecay", "kwargs": {}})
 
 
 def test_early_stopping_follows_keras_patience_semantics():

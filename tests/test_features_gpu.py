@@ -286,3 +286,48 @@ def test_fused_path_other_mel_configurations(sr, mel):
             assert (np.abs(got - ref) / np.abs(ref).max()).max() <= 2e-5
         else:
             assert np.abs(got - ref).max() <= tol
+
+
+def test_concurrent_callers_on_one_plan_are_bit_identical():
+    """The reference calls the feature op from tf.data AUTOTUNE threads under one device (steps.py:734-736; SURVEY 8b
+    "concurrent callers on one device").  Two host threads, each on its own HIP stream, run log-mel and MFCC through the
+    SAME immutable plan over different batches, many times, while a third keeps asking for the plan: every result equals
+    the single-threaded one bit for bit and no call reports an error."""
+    import threading
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.testutil import synthetic_batch
+    plan = audio.get_plan(16000, 400, 160)
+    batches = [torch.from_numpy(synthetic_batch(b, num_labels=4, duration_s=1.0, seed=b)[0]).cuda() for b in (3, 17, 64, 5)]
+    kinds = (nv.FEAT_LOGMEL, nv.FEAT_MFCC)
+    expect = {(i, k): plan.run(k, x).clone() for i, x in enumerate(batches) for k in kinds}
+    torch.cuda.synchronize()
+    errors, results = [], {}
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for rep in range(25):
+                    for i, x in enumerate(batches):
+                        if (i + tid) % 2:
+                            continue
+                        p = audio.get_plan(16000, 400, 160)              # the shared, cached plan
+                        assert p is plan
+                        for k in kinds:
+                            out = p.run(k, x)
+                            if rep == 24:
+                                results[(i, k)] = out
+            stream.synchronize()
+        except Exception as e:                                          # noqa: BLE001 - surfaced below
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert set(results) == set(expect)
+    for key, ref in expect.items():
+        assert torch.equal(results[key], ref), key

@@ -155,3 +155,63 @@ def test_config5_shard_counter_identities_100_languages():
         assert torch.equal(pairs, expect)
         c = float(metric.result())
         assert 0.0 <= c <= 1.0
+
+
+def test_config4_mfcc_cmvn_cnn_full_size_runs_and_learns():
+    """BASELINE configs[3] at its stated size: MFCC(1:13) + CMVN -> lidbox.models.cnn (cnn.py:25-45), bs 256, graph-captured
+    step from waveforms.  Properties the domain gives at full size: the CMVN'd conv input has zero mean / unit variance
+    per utterance and channel over time (features/__init__.py:22-32), log-probabilities are normalised, the step learns."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import cnn
+    from lidbox_amd.train import Trainer
+    sig, y = _batch(256)
+    m = cnn.create((T, 12), 4, seed=0)
+    w0 = m.flat.clone()
+    tr = Trainer(m, feature=dict(plan=audio.get_plan(SR, 400, 160), kind=nv.FEAT_MFCC, cmvn=True), use_graph=True)
+    l0 = float(tr.train_step(sig, y))
+    assert abs(l0 - np.log(4.0)) < 0.7
+    x_in = m.workspace(256, T).input_view()                  # [256, 198, 12]: what conv_1 read in the last step
+    assert float(x_in.mean(dim=1).abs().max()) < 1e-4
+    assert float((x_in.var(dim=1, unbiased=False) - 1).abs().max()) < 1e-3
+    logp = m.workspace(256, T).logp
+    assert float((torch.exp(logp.double()).sum(-1) - 1).abs().max()) < 1e-5
+    for _ in range(40):
+        l1 = float(tr.train_step(sig, y))
+    # (mean/variance-normalised MFCCs of noisy tones separate slowly: 1.39 -> 1.29 after 20 steps, measured)
+    assert np.isfinite(l1) and l1 < 0.95 * l0
+    assert tr.step_count == 41
+    moved = (m.flat - w0).abs()
+    assert 1e-3 < float(moved.max()) <= 41 * 1e-3 * 1.01
+
+
+def test_config5_bf16_step_time_smoke():
+    """BASELINE configs[4], one GPU's shard at its stated size (512 utterances, 100 languages, bfloat16 compute with fp32
+    master weights, AP loss): the captured step runs, stays finite, and takes a plausible time (a regression that falls
+    back to a slow path -- fp32 GEMMs, eager launches -- shows up as several times the 1.6 ms this shard measured)"""
+    import time
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.losses import SparseAngularProximity
+    from lidbox_amd.models import xvector
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    from lidbox_amd.train import Trainer
+    N, D, B = 100, 512, 512
+    sig, y = _batch(B, langs=N, seed=99)
+    convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
+             xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
+             xvector.frame_layer(1500, 1, 1, name="frame5")]
+    m = SequentialTDNN((T, MEL), convs, "stats", [DenseSpec("segment1", D, relu=False)], output_activation=None, seed=0,
+                       compute_dtype="bfloat16")
+    tr = Trainer(m, loss=SparseAngularProximity(N, D), feature=dict(plan=audio.get_plan(SR, 400, 160), kind=nv.FEAT_LOGMEL),
+                 use_graph=True)
+    for _ in range(5):
+        loss = float(tr.train_step(sig, y))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        tr.train_step(sig, y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    assert np.isfinite(loss) and np.isfinite(float(tr.train_step(sig, y)))
+    assert ms < 6.0, "bf16 config-5 shard step took %.2f ms" % ms

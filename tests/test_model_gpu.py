@@ -435,3 +435,45 @@ def test_config0_32_utterances_logmel_xvector_forward():
     assert np.abs(got - ref).max() < 1e-3
     emb = xvector.as_embedding_extractor(m)(feats).cpu().numpy()
     assert _cos(emb, mo.xvector_fwd(_oracle_params(m), ref_feats, embedding=True)).min() >= 0.9999
+
+
+def test_learning_rate_schedule_reaches_the_captured_optimizer():
+    """reference keras_utils.py:137-139 (`lr_scheduler`): the schedule's value of every step is written into the device-side
+    Adam state ahead of the step, so eager and graph-replayed steps follow it -- against the oracle's Adam run with the
+    same per-step learning rates, and a piecewise schedule that drops to (almost) zero freezes the weights"""
+    from lidbox_amd.models import xvector
+    from lidbox_amd.models.keras_utils import lr_schedule_from_config
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((6, 50, 24)).astype(np.float32)
+    y = rng.integers(0, 5, size=6).astype(np.int32)
+    xd, yd = _dev(x), _dev(y, np.int32)
+    sched = lr_schedule_from_config({"cls": "ExponentialDecay",
+                                     "kwargs": {"initial_learning_rate": 2e-3, "decay_steps": 2, "decay_rate": 0.5}})
+    m_e, m_g = xvector.create((50, 24), 5, seed=7), xvector.create((50, 24), 5, seed=7)
+    p = _oracle_params(m_e)
+    am = {k: np.zeros_like(v) for k, v in p.items()}
+    av = {k: np.zeros_like(v) for k, v in p.items()}
+    t_e = Trainer(m_e, use_graph=False, optimizer=dict(lr_schedule=sched))
+    t_g = Trainer(m_g, use_graph=True, optimizer=dict(lr_schedule=sched))
+    for step in range(1, 5):
+        le, lg = float(t_e.train_step(xd, yd)), float(t_g.train_step(xd, yd))
+        lo, go, _ = mo.xvector_loss_and_grads(p, x.astype(np.float64), y)
+        mo.adam_step(p, go, am, av, step, lr=sched(step - 1))
+        assert le == lg and abs(le - lo) <= 2e-4 * abs(lo), (step, le, lg, lo)
+    assert torch.equal(m_e.flat, m_g.flat)
+    for k, v in m_e.get_weights().items():
+        # Adam normalises the update: a weight whose gradient is ~0 may take its +-lr step the other way on fp32 noise;
+        # four steps at <= 2e-3 moved the weights by ~6e-3
+        assert np.abs(v - p[k]).max() <= 1e-3, k
+        assert np.median(np.abs(v - p[k])) <= 2e-5, k
+    # piecewise: one real step, then a vanishing rate
+    pw = lr_schedule_from_config({"cls": "PiecewiseConstantDecay", "kwargs": {"boundaries": [0], "values": [1e-3, 1e-12]}})
+    m = xvector.create((50, 24), 5, seed=7)
+    t = Trainer(m, use_graph=True, optimizer=dict(lr_schedule=pw))
+    w0 = m.flat.clone()
+    t.train_step(xd, yd)
+    w1 = m.flat.clone()
+    for _ in range(3):
+        t.train_step(xd, yd)
+    assert float((w1 - w0).abs().max()) > 5e-4 and float((m.flat - w1).abs().max()) < 1e-9
