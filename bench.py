@@ -19,7 +19,16 @@ synchronize, K graph-replayed steps, synchronize + barrier; max over ranks.  One
 by rank 0.  `python bench.py --gpus N` without a launcher re-executes itself under
 torch.distributed.run (N ranks on 127.0.0.1) and still prints exactly one line.
 
+--config selects the BASELINE.json configuration (default 1; the driver's line):
+  1  configs[1] / [2]: log-mel + x-vector, 4 languages, bs 256 per GPU, fp32 (--compute-dtype bfloat16: config 5's precision)
+  3  configs[3]: MFCC(1:13) + CMVN -> lidbox.models.cnn classifier, 4 languages, bs 256, fp32
+  4  configs[4], one GPU's shard: log-mel -> x-vector trunk -> segment1 -> L2 norm -> SparseAngularProximity + C_avg,
+     100 languages, bs 512 per GPU, bf16 compute / fp32 master weights
+Every configuration prints the same one-line JSON (metric / value / roofline / cpu_baseline).
+
 Extra measurements in the same process (rank 0):
+  step_events       median / min / p90 of per-step HIP-event times over K more graph-replayed steps (the headline value is
+                    the wall-clock mean of the timed region).
   roofline          fp32-MFMA roofline of the dominant GEMM kernel family: algorithmic flops of
                     its launches / HIP-event time of those launches, from an instrumented eager
                     pass over the same steps (events cannot be placed inside a graph replay).
@@ -44,6 +53,9 @@ NUM_LANGS = 4
 SAMPLE_RATE, DURATION_S = 16000, 2.0
 BYTES_PER_UTT_FEATURE = 32000 * 4 + 198 * 40 * 4           # 159 680 B
 FLOPS_PER_UTT_TRAIN = 918.7e6
+FLOPS_PER_UTT_TRAIN_CNN = 2135e6                           # SURVEY 8d (config 4 in its numbering): 3 x 715.7 - 11.9 MFLOP
+FLOPS_PER_UTT_TRAIN_AP = 915.6e6                           # x-vector trunk + 512-d segment1 head instead of the classifier head
+BYTES_PER_UTT_FEATURE_MFCC = 32000 * 4 + 198 * 12 * 4      # 137 504 B
 PEAK_FP32_MFMA_TFLOPS = 157.3                              # MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0                             # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -63,10 +75,16 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--resident-batches", type=int, default=4,
                     help="different batches kept in HBM per rank; the timed loop rotates over them")
-    ap.add_argument("--compute-dtype", choices=["float32", "bfloat16"], default="float32",
+    ap.add_argument("--config", type=int, choices=[1, 3, 4], default=1, help="BASELINE.json configs[] index (see the module docstring)")
+    ap.add_argument("--compute-dtype", choices=["float32", "bfloat16"], default=None,
                     help="GEMM arithmetic; float32 is the BASELINE metric's configuration, bfloat16 = config 5's "
-                         "bf16-compute / fp32-master variant of the same workload")
-    return ap.parse_args()
+                         "bf16-compute / fp32-master variant of the same workload (default: what the configuration names)")
+    a = ap.parse_args()
+    if a.compute_dtype is None:
+        a.compute_dtype = "bfloat16" if a.config == 4 else "float32"
+    if a.config == 4 and a.batch == PER_GPU_BATCH:
+        a.batch = 512
+    return a
 
 
 class KernelTimer:
@@ -79,16 +97,25 @@ class KernelTimer:
              "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13,
              "lidbox_gemm_bf16s_tn": 14}
 
-    def __init__(self, nv):
+    def __init__(self, nv, feature_bytes=BYTES_PER_UTT_FEATURE):
         self.nv = nv
         self.records = {}
         self._orig = {}
+        self.feature_bytes = feature_bytes
+        # what an empty bracket measures: subtracted from every bracket (event record + the gap the host leaves)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(40)]
+        torch.cuda.synchronize()
+        for i in range(0, 40, 2):
+            e[i].record()
+            e[i + 1].record()
+        torch.cuda.synchronize()
+        self.bracket_overhead_ms = float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(0, 40, 2)]))
 
     def _classify(self, name, args):
         import ctypes
         kind = self.ENTRY[name]
         if kind < 0:
-            return "fused_feat512_kernel", float(args[3]) * BYTES_PER_UTT_FEATURE
+            return "fused_feat512_kernel", float(args[3]) * self.feature_bytes
         if kind == 13:                                        # bf16-storage kernel: (A16, B16, ldb, C, C16, K, N, ...)
             A, K, N = args[0], args[5], args[6]
             return "gemm16s_rows_kernel", 2.0 * A.batch * A.rows_per_batch * K * N
@@ -98,7 +125,11 @@ class KernelTimer:
             return "gemm16s_tn_kernel", 2.0 * M * K * N
         if kind >= 10:                                        # bf16 family: one tile shape per entry point
             return ("gemm16_tn_kernel", "gemm16_rows_kernel<NN>", "gemm16_rows_kernel<NT>")[(kind - 9) % 3], 2.0 * M * K * N
-        ws_bytes = args[9] if kind < 2 else 0
+        ws_bytes = args[9]
+        if self.nv.lib.lidbox_gemm_plan_is_stream_k(kind, M, N, K, int(ws_bytes or 0)):
+            return ("gemm_sk_rows_kernel<NN>", "gemm_sk_rows_kernel<NT>", "gemm_sk_tn_kernel")[kind], 2.0 * M * K * N
+        if kind == 2:
+            ws_bytes = 0
         out = (ctypes.c_int * 4)()
         self.nv.check(self.nv.lib.lidbox_gemm_plan_query(kind, M, N, K, int(ws_bytes or 0), out))
         if kind == 2:
@@ -138,7 +169,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for key, recs in self.records.items():
-            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            ms = sum(max(1e-4, r[0].elapsed_time(r[1]) - self.bracket_overhead_ms) for r in recs)
             work = sum(r[2] for r in recs)
             nk = sum(r[3] for r in recs)                  # kernel launches (a tail split launches the instantiation twice)
             out[key] = dict(launches=nk, calls=len(recs), total_ms=ms, avg_us=1e3 * ms / nk,
@@ -179,7 +210,11 @@ def pmc_traffic(kernel_key, bf16=False):
     if doc.get("source_hash") != source_hash():
         return None
     m = re.match(r"gemm_rows(8?)_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
-    if m:
+    if kernel_key.startswith("gemm_sk_rows_kernel<"):
+        name = "gemm_sk_rows_kernel<%s>" % ("true" if kernel_key.endswith("NT>") else "false")
+    elif kernel_key == "gemm_sk_tn_kernel":
+        name = "gemm_sk_tn_kernel"
+    elif m:
         name = "gemm_rows%s_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), m.group(3), "true" if m.group(4) == "NT" else "false")
     elif kernel_key.startswith("gemm_tn_kernel<"):
         name = kernel_key[:-1] + ", true>"
@@ -192,16 +227,16 @@ def pmc_traffic(kernel_key, bf16=False):
     return int(v["hbm_bytes_per_launch"]) if v else None
 
 
-def cpu_baseline(seconds, batch=PER_GPU_BATCH):
+def cpu_baseline(seconds, batch=PER_GPU_BATCH, config="xvector", num_langs=NUM_LANGS, what="log-mel + x-vector fwd/bwd + Adam"):
     """oracle/torch_ref.py train step on the host cores, bounded sample.  torch-CPU does not scale past a
     few dozen threads on this workload (256 threads is 10x SLOWER than 16 on the 2 x 64-core host), so the
     thread count is chosen by a short sweep and reported as `cores`."""
     from oracle.torch_ref import TrainStepCPU
     from lidbox_amd.testutil import synthetic_batch
     ncpu = os.cpu_count() or 1
-    sig, y = synthetic_batch(batch, NUM_LANGS, SAMPLE_RATE, DURATION_S)
+    sig, y = synthetic_batch(batch, num_langs, SAMPLE_RATE, DURATION_S)
     sig_t, y_t = torch.from_numpy(sig), torch.from_numpy(y.astype(np.int64))
-    step = TrainStepCPU(num_outputs=NUM_LANGS, seed=0, threads=min(ncpu, 8))
+    step = TrainStepCPU(num_outputs=num_langs, seed=0, threads=min(ncpu, 8), config=config)
     best_threads, best_rate = min(ncpu, 8), 0.0
     for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
         torch.set_num_threads(th)
@@ -223,9 +258,9 @@ def cpu_baseline(seconds, batch=PER_GPU_BATCH):
         if dt >= seconds or n >= 400:
             break
     return dict(value=round(n * batch / dt, 2), unit="utterances/s", cores=best_threads, kind="port",
-                sample="%d train steps of %d utterances (log-mel + x-vector fwd/bwd + Adam, fp32, torch-CPU "
+                sample="%d train steps of %d utterances (%s, fp32, torch-CPU "
                        "restatement oracle/torch_ref.py; TensorFlow unavailable) in %.1f s on %d of %d logical "
-                       "cores (best of a 8/16/32/64-thread sweep)" % (n, batch, dt, best_threads, ncpu))
+                       "cores (best of a 8/16/32/64-thread sweep)" % (n, batch, what, dt, best_threads, ncpu))
 
 
 def respawn_under_launcher(args):
@@ -249,7 +284,10 @@ def main():
         raise SystemExit(respawn_under_launcher(args))
     from lidbox_amd import _native as nv
     from lidbox_amd.features import audio
-    from lidbox_amd.models import xvector
+    from lidbox_amd.losses import SparseAngularProximity
+    from lidbox_amd.metrics import SparseAverageDetectionCost
+    from lidbox_amd.models import cnn, xvector
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
     from lidbox_amd.testutil import synthetic_batch
     from lidbox_amd.train import Trainer, init_distributed, shard_bounds
     import torch.distributed as dist
@@ -271,20 +309,55 @@ def main():
     #      resident in HBM
     B = args.batch
     global_B = B * world
+    num_langs = 100 if args.config == 4 else NUM_LANGS
     lo, hi = shard_bounds(global_B, rank, world)
     batches = []
     for i in range(max(1, args.resident_batches)):
-        sig, labels = synthetic_batch(global_B, NUM_LANGS, SAMPLE_RATE, DURATION_S, seed=1234 + i)
+        sig, labels = synthetic_batch(global_B, num_langs, SAMPLE_RATE, DURATION_S, seed=1234 + i)
         batches.append((torch.from_numpy(sig[lo:hi]).to(dev), torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)))
         del sig
     sig_d, lab_d = batches[0]
 
-    model = xvector.create((198, 40), NUM_LANGS, seed=0, device=dev, compute_dtype=args.compute_dtype)
     bf16 = args.compute_dtype == "bfloat16"
     peak_mfma = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     plan = audio.get_plan(SAMPLE_RATE, 400, 160, device=dev)
-    trainer = Trainer(model, loss="sparse_categorical_crossentropy", feature=dict(plan=plan, kind=nv.FEAT_LOGMEL),
-                      use_graph=not args.no_graph, num_buckets=args.buckets)
+    metric = None
+    if args.config == 3:
+        # BASELINE configs[3]: MFCC(1:13) + CMVN -> cnn (reference cnn.py:25-45, tf_utils.py:180-185, features/__init__.py:22-32)
+        model = cnn.create((198, 12), num_langs, seed=0, device=dev, compute_dtype=args.compute_dtype)
+        feature, loss_spec = dict(plan=plan, kind=nv.FEAT_MFCC, cmvn=True), "sparse_categorical_crossentropy"
+        flops_per_utt, feature_bytes = FLOPS_PER_UTT_TRAIN_CNN, BYTES_PER_UTT_FEATURE_MFCC
+        cpu_cfg = dict(config="cnn", what="MFCC + CMVN + CNN classifier fwd/bwd + Adam")
+        workload = "MFCC(1:13)+CMVN + cnn 4-lang train step, bs=%d per GPU, %s (BASELINE configs[3])" % (B, "bf16 compute" if bf16 else "fp32")
+        metric_name = "utterances/sec (16kHz x 2s) MFCC+CMVN + CNN classifier train step"
+        model_name = "lidbox.models.cnn"
+    elif args.config == 4:
+        # BASELINE configs[4], one GPU's shard: x-vector trunk -> segment1 (no activation) -> L2 norm -> AP loss + C_avg
+        # (reference losses.py:25-52, metrics.py:51-103; SURVEY 8d: the head is this build's documented choice)
+        convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
+                 xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
+                 xvector.frame_layer(1500, 1, 1, name="frame5")]
+        model = SequentialTDNN((198, 40), convs, "stats", [DenseSpec("segment1", 512, relu=False)], output_activation=None, seed=0,
+                               device=dev, compute_dtype=args.compute_dtype)
+        metric = SparseAverageDetectionCost(num_langs, np.linspace(-np.pi, 0, 100))
+        feature, loss_spec = dict(plan=plan, kind=nv.FEAT_LOGMEL), SparseAngularProximity(num_langs, 512)
+        flops_per_utt, feature_bytes = FLOPS_PER_UTT_TRAIN_AP, BYTES_PER_UTT_FEATURE
+        cpu_cfg = dict(config="ap", what="log-mel + x-vector trunk + angular-proximity loss fwd/bwd + Adam")
+        workload = ("log-mel + x-vector trunk + angular-proximity loss + C_avg, 100 languages, bs=%d per GPU, %s (BASELINE configs[4], "
+                    "one GPU's shard of 8 x 512)" % (B, "bf16 compute / fp32 master weights" if bf16 else "fp32"))
+        metric_name = "utterances/sec (16kHz x 2s) log-mel + x-vector + angular-proximity train step"
+        model_name = "lidbox.models.xvector trunk + SparseAngularProximity"
+    else:
+        model = xvector.create((198, 40), num_langs, seed=0, device=dev, compute_dtype=args.compute_dtype)
+        feature, loss_spec = dict(plan=plan, kind=nv.FEAT_LOGMEL), "sparse_categorical_crossentropy"
+        flops_per_utt, feature_bytes = FLOPS_PER_UTT_TRAIN, BYTES_PER_UTT_FEATURE
+        cpu_cfg = dict(config="xvector", what="log-mel + x-vector fwd/bwd + Adam")
+        workload = ("log-mel + x-vector 4-lang train step, bs=%d per GPU, %s (BASELINE configs[%d]%s)"
+                    % (B, "bf16 MFMA operands and bf16 activations / gradients in the Conv1D layers, fp32 accumulate, fp32 dense head and master weights" if bf16 else "fp32",
+                       1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""))
+        metric_name = "utterances/sec (16kHz x 2s) log-mel + x-vector train step"
+        model_name = "lidbox.models.xvector"
+    trainer = Trainer(model, loss=loss_spec, feature=feature, use_graph=not args.no_graph, num_buckets=args.buckets, metric=metric)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -318,16 +391,28 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = global_B * args.steps / elapsed
 
+    # per-step HIP events over K more steps (outside the timed region): the distribution behind the wall-clock mean
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for i, (e0, e1) in enumerate(evs):
+        e0.record()
+        trainer.train_step(*batches[i % len(batches)])
+        e1.record()
+    torch.cuda.synchronize(dev)
+    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+
     result = {
-        "metric": "utterances/sec (16kHz x 2s) log-mel + x-vector train step",
+        "metric": metric_name,
         "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-        "config": {"workload": "log-mel + x-vector 4-lang train step, bs=%d per GPU, %s (BASELINE configs[%d]%s)"
-                               % (B, "bf16 MFMA operands and bf16 activations / gradients in the Conv1D layers, fp32 accumulate, fp32 dense head and master weights" if bf16 else "fp32",
-                                  1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""),
+        "step_events": {"median_ms": round(step_ms[len(step_ms) // 2], 4), "min_ms": round(step_ms[0], 4),
+                        "p90_ms": round(step_ms[min(len(step_ms) - 1, (9 * len(step_ms)) // 10)], 4), "steps": len(step_ms),
+                        "note": "HIP events around each of K further graph-replayed steps (host launch gaps included); "
+                                "`value` / `ms_per_step` are the wall-clock mean of the timed region"},
+        "config": {"workload": workload, "baseline_config": args.config if world == 1 or args.config != 1 else 2,
+                   "reference_model": model_name,
                    "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
-                   "languages": NUM_LANGS, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world, "grad_buckets": trainer.sync.num_buckets if world > 1 else 1,
+                   "languages": num_langs, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world, "grad_buckets": trainer.sync.num_buckets if world > 1 else 1,
                    "hip_graph": not args.no_graph, "resident_batches": len(batches),
                    "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6),
                    "loss_note": "SURVEY 8d's synthetic languages (one sine frequency each) are separable: the loss reaches ~0 within a "
@@ -344,13 +429,12 @@ def main():
     if rank == 0:
         # ---- per-kernel HIP-event timing: instrumented eager pass over the same steps
         if not args.no_kernel_timing and world == 1:
-            eager = Trainer(model, loss="sparse_categorical_crossentropy",
-                            feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=False)
+            eager = Trainer(model, loss=loss_spec, feature=feature, use_graph=False)
             eager.m, eager.v, eager.adam_state = trainer.m, trainer.v, trainer.adam_state
             eager.train_step(sig_d, lab_d)
             torch.cuda.synchronize()
             nsteps = min(args.steps, 10)
-            with KernelTimer(nv) as kt:
+            with KernelTimer(nv, feature_bytes) as kt:
                 for _ in range(nsteps):
                     eager.train_step(sig_d, lab_d)
                 ks = kt.summary()
@@ -363,10 +447,14 @@ def main():
                                   "frac": round(ach / peak_mfma, 4), "traffic": pmc_traffic(dom, bf16),
                                   "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
                                   "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
-                                  "note": "HIP-event brackets around the C-ABI calls that launch this instantiation, divided by "
-                                          "the kernel launches they made (lidbox_gemm_last_launches; a bracket also covers the "
-                                          "split-K reduce kernel where one follows); rocprofv3 --stats lists the same "
-                                          "instantiation by this name"}
+                                  "hbm_floor_us": round(1e6 * (pmc_traffic(dom, bf16) or 0) / (PEAK_HBM_GBS * 1e9), 2) or None,
+                                  "mfma_floor_us": round(1e6 * d["work_per_launch"] / (peak_mfma * 1e12), 2),
+                                  "bracket_overhead_us": round(1e3 * kt.bracket_overhead_ms, 2),
+                                  "note": "HIP-event brackets around the C-ABI calls that launch this instantiation (minus what an "
+                                          "empty bracket measures), divided by the kernel launches they made "
+                                          "(lidbox_gemm_last_launches; a bracket also covers the split-K reduce kernel where one "
+                                          "follows); rocprofv3 --stats lists the same instantiation by this name; the two floors "
+                                          "are PMC HBM bytes / 8 TB/s and flops / the MFMA peak per launch"}
             gemm_ms = sum(v["total_ms"] for v in gemms.values()) / nsteps
             gemm_flops = sum(v["rate"] * v["total_ms"] * 1e-3 for v in gemms.values()) / nsteps
             result["kernels"] = {k: {"launches_per_step": v["launches"] // nsteps, "ms_per_step": round(v["total_ms"] / nsteps, 4),
@@ -383,9 +471,11 @@ def main():
                                               "traffic": pmc_traffic("fused_feat512_kernel", bf16), "avg_launch_us": round(f["avg_us"], 2),
                                               "bytes_per_launch": int(f["work_per_launch"])}
         # whole-step view of the same roofline: algorithmic train flops / step time
-        result["step_tflops"] = round(value / world * FLOPS_PER_UTT_TRAIN / 1e12, 2)
+        result["step_tflops"] = round(value / world * flops_per_utt / 1e12, 2)
+        if metric is not None:
+            result["config"]["c_avg"] = round(float(metric.result()), 4)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, batch=B, num_langs=num_langs, **cpu_cfg)
         print(json.dumps(result), flush=True)
     if dist.is_available() and dist.is_initialized():
         if world > 1:

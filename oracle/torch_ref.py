@@ -119,19 +119,43 @@ class KerasAdam:
 
 
 class TrainStepCPU:
-    """log-mel + x-vector train step on the host (the timed cpu_baseline)."""
+    """train step on the host (the timed cpu_baseline of bench.py).
+    config "xvector": log-mel -> x-vector -> sparse CE (BASELINE configs[1]);
+           "cnn":     MFCC(1:13) + CMVN -> cnn -> sparse CE (configs[3]; tf_utils.py:180-185, features/__init__.py:22-32);
+           "ap":      log-mel -> x-vector trunk -> segment1 (no activation) -> L2 normalise -> angular proximity loss
+                      (configs[4]'s per-GPU shard; losses.py:25-49), fp32 on the CPU."""
 
-    def __init__(self, num_outputs=4, seed=0, threads=None):
+    def __init__(self, num_outputs=4, seed=0, threads=None, config="xvector"):
         if threads:
             torch.set_num_threads(threads)
+        self.config = config
         self.feat = LogMelCPU()
-        self.params = to_torch_params(model_np.xvector_init(40, num_outputs, seed))
+        self.num_outputs = num_outputs
+        if config == "cnn":
+            self.dct = torch.from_numpy(features_np.dct_matrix(40, np.float32)[:, 1:13].copy())
+            self.params = to_torch_params(model_np.cnn_init(12, num_outputs, seed))
+        elif config == "ap":
+            p = model_np.xvector_init(40, num_outputs, seed)
+            self.params = to_torch_params({k: v for k, v in p.items() if not k.startswith(("segment2", "outputs"))})
+        else:
+            self.params = to_torch_params(model_np.xvector_init(40, num_outputs, seed))
         self.opt = KerasAdam(self.params)
 
     def step(self, signals, labels):
         with torch.no_grad():
             x = self.feat(signals)
-        loss = sparse_ce_from_logits(xvector_fwd(self.params, x), labels)
+            if self.config == "cnn":
+                x = x @ self.dct
+                mean = x.mean(dim=1, keepdim=True)
+                std = x.std(dim=1, unbiased=False, keepdim=True)
+                x = torch.where(std > 0, (x - mean) / std, torch.zeros_like(x))
+        if self.config == "cnn":
+            loss = sparse_ce_from_logits(cnn_fwd(self.params, x), labels)
+        elif self.config == "ap":
+            z = F.normalize(xvector_fwd(self.params, x, embedding=True), dim=1)
+            loss = ap_loss(labels, z, self.num_outputs)
+        else:
+            loss = sparse_ce_from_logits(xvector_fwd(self.params, x), labels)
         loss.backward()
         self.opt.step()
         return float(loss.detach())
