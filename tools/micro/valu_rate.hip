@@ -48,10 +48,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, long long* cyc) 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
+static int g_short = 0;
 template <int OP> void run(const char* name, int mult) {
     float* out; long long* cyc;
     const int iters = 2000;
-    for (int wg_per_cu = 2; wg_per_cu <= 4; wg_per_cu += 2) {
+    // "short" mode (the PMC reconciliation run, profiles/r03_valu_issue_counters.txt): 1, 2 and 4 workgroups per CU
+    for (int wg_per_cu = g_short ? 1 : 2; wg_per_cu <= 4; wg_per_cu *= 2) {
         int nwg = 256 * wg_per_cu;
         hipMalloc(&out, nwg * 256 * 4); hipMalloc(&cyc, nwg * 4 * 8);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -67,7 +69,12 @@ template <int OP> void run(const char* name, int mult) {
         hipFree(out); hipFree(cyc);
     }
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {          // short: the three ops the feature kernel's ceiling rests on
+        g_short = 1;
+        run<0>("v_fma_f32", 1); run<5>("v_add_f32", 1); run<1>("v_pk_fma_f32", 1);
+        return 0;
+    }
     run<0>("v_fma_f32", 1); run<5>("v_add_f32", 1); run<8>("v_mul_f32", 1); run<9>("v_cndmask_b32", 1);
     run<1>("v_pk_fma_f32", 1); run<2>("v_pk_add_f32", 1); run<3>("v_pk_add_f32 op_sel neg", 1); run<4>("v_pk_mul_f32", 1);
     run<6>("v_pk_fma_f32 op_sel neg", 1); run<7>("2 x v_add_f32 (pair)", 2); run<10>("v_pk_add_f32 sgpr src", 1);
