@@ -449,6 +449,12 @@ int lidbox_mean(const float* x, long n, float* out, lidbox_stream_t stream);
  * scores the C_avg metric sees. */
 int lidbox_neg_acos(const float* z, long B, int D, int N, float* out, lidbox_stream_t stream);
 
+/* Keras Dropout (element-wise; FrameLayer2D(dropout_rate=...), xvector_2d.py:37-46) in place on the rows x[r][0..C) of an
+ * implicit-row descriptor: zero with probability `rate`, kept values scaled by 1/(1-rate).  The mask is a counter-based hash
+ * of (seed, *step_counter, r, c) -- the same call on the gradient rows regenerates the forward mask. */
+int lidbox_dropout_rows(lidbox_rows_out_t x, int C, float rate, unsigned long long seed, const void* step_counter,
+                        lidbox_stream_t stream);
+
 /* Keras SpatialDropout1D (xvector.py:50-51, cnn.py:29-30) in place on x [B, T, C] (batch stride in floats): whole
  * channels of an utterance are zeroed with probability `rate`, kept ones scaled by 1/(1-rate).  The mask is a
  * counter-based hash of (seed, *step_counter, b, c); step_counter is a DEVICE int64 (NULL = 0), e.g. the Adam step,

@@ -119,6 +119,7 @@ _SIGS = {
     "lidbox_cavg_result": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
+    "lidbox_dropout_rows": (_i, [Rows, _i, _f, C.c_ulonglong, _vp, _vp]),
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),
     "lidbox_gemm_bf16s_nt": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_bf16s_tn_workspace": (_sz, [_i, _i, _i]),

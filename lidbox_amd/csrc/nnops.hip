@@ -787,6 +787,34 @@ __global__ __launch_bounds__(256) void spatial_dropout_kernel(float* __restrict_
     }
 }
 
+struct RowsOutD {
+    float* base;
+    long bs, rs;
+    int batch, rpb;
+};
+__device__ __forceinline__ long row_offset(const RowsOutD& r, unsigned m) {
+    if (r.batch == 1) return (long)m * r.rs;
+    const unsigned b = m / (unsigned)r.rpb;
+    return (long)b * r.bs + (long)(m - b * (unsigned)r.rpb) * r.rs;
+}
+
+// Keras Dropout (element-wise) in place on rows x[r][0..C) addressed through an implicit-row descriptor: an element is zeroed
+// with probability `rate`, the kept ones scaled by 1 / (1 - rate).  The draw is a function of (seed, *step, r, c) only, so the
+// SAME call on the gradient regenerates the forward mask (FrameLayer2D's dropout, xvector_2d.py:37-46: y = dropout(bn(x))
+// forward, d(bn out) = mask * d(y) backward).
+__global__ __launch_bounds__(256) void dropout_rows_kernel(RowsOutD X, long R, int C, float rate, unsigned long long seed,
+                                                           const long long* __restrict__ step) {
+    const unsigned long long stp = step ? (unsigned long long)*step : 0ull;
+    const float keep_scale = 1.f / (1.f - rate);
+    const long total = R * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        float* p = X.base + row_offset(X, (unsigned)r) + c;
+        *p *= hash_uniform(seed, stp, (unsigned)r, (unsigned)c) >= rate ? keep_scale : 0.f;
+    }
+}
+
 __global__ void scale_kernel(float* __restrict__ x, long n, float alpha) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= alpha;
 }
@@ -1011,6 +1039,21 @@ extern "C" int lidbox_spatial_dropout(float* x, int B, int T, int C, long batch_
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(spatial_dropout_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                        x, T, C, batch_stride, rate, seed, (const long long*)step_counter, mask_out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_dropout_rows(lidbox_rows_out_t x, int C, float rate, unsigned long long seed, const void* step_counter,
+                                   lidbox_stream_t stream) {
+    LBX_ARG(x.base && C >= 1 && rate >= 0.f && rate < 1.f, "x != NULL, C >= 1, 0 <= rate < 1");
+    const long R = (long)x.batch * x.rows_per_batch;
+    LBX_ARG(R >= 0 && R <= 0x7fffffffL, "row count");
+    if (R == 0 || rate == 0.f) return LIDBOX_OK;
+    RowsOutD X{x.base, x.batch_stride, x.row_stride, x.batch, x.rows_per_batch};
+    long g = lbx_cdiv(R * C, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, X, R, C, rate, seed,
+                       (const long long*)step_counter);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

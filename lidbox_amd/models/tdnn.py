@@ -66,8 +66,10 @@ class FreqConvSpec:
     def __init__(self, name, filters, kernel_width, stride, momentum=0.99, epsilon=1e-3, dropout_rate=None):
         self.name, self.filters, self.k, self.s = name, int(filters), int(kernel_width), int(stride)
         self.momentum, self.epsilon = float(momentum), float(epsilon)
-        if dropout_rate:
-            raise ValueError("FrameLayer2D dropout is not supported (the reference never enables it: xvector_2d.py:70-73)")
+        # Keras Dropout behind the BatchNormalization (xvector_2d.py:37-39,45-46); the reference's create() never sets it
+        self.dropout_rate = float(dropout_rate or 0.0)
+        if not 0.0 <= self.dropout_rate < 1.0:
+            raise ValueError("dropout_rate must be in [0, 1)")
         if self.k < 1 or self.s < 1 or self.filters < 1:
             raise ValueError("filters, kernel width and stride must be >= 1")
 
@@ -580,7 +582,18 @@ class SequentialTDNN:
             last = i == len(self.frontend) - 1
             y = self._fe_last_rows(ws.act[0], ws) if last else _rows(ws.fe_y[i].data_ptr(), 0, Co, 1, R)
             nv.check(lib.lidbox_bn_apply(nv.ptr(ws.fe_a[i]), R, Co, cp[2], cp[3], y, st))
+            if training and l.dropout_rate > 0:
+                nv.check(lib.lidbox_dropout_rows(y, Co, l.dropout_rate, self._fe_dropout_seed(i), self._dropout_step_ptr(), st))
             cin = Co
+
+    def _fe_dropout_seed(self, i):
+        return (self.dropout_seed + 0xD1B54A32D192ED03 * (i + 1)) & (2 ** 64 - 1)
+
+    def _dropout_step_ptr(self):
+        """device int64 that keys the FrameLayer2D dropout masks: the Trainer points it at its Adam step (a fresh mask per
+        step, also under graph replay); standalone training-mode calls use a constant zero"""
+        t = getattr(self, "dropout_step", None)
+        return None if t is None else nv.ptr(t)
 
     def _backward_frontend(self, ws):
         """dact[0] holds d loss / d (front-end output).  BatchNorm + ReLU backward, wgrad / bias gradient, dgrad per layer."""
@@ -596,6 +609,8 @@ class SequentialTDNN:
             g = self.fe_gemm(i)
             c = ws.fe_consts[i]
             dy = self._fe_last_rows(ws.dact[0], ws) if i == n - 1 else _rows(ws.fe_dy[i].data_ptr(), 0, Co, 1, R)
+            if l.dropout_rate > 0:               # the forward mask, regenerated on the gradient (same seed, same device step)
+                nv.check(lib.lidbox_dropout_rows(dy, Co, l.dropout_rate, self._fe_dropout_seed(i), self._dropout_step_ptr(), st))
             nv.check(lib.lidbox_bn_bwd(nv.ptr(ws.fe_a[i]), dy, R, Co, ctypes.c_void_p(c.data_ptr()), ctypes.c_void_p(c.data_ptr() + 4 * Co),
                                        self._p(l.name + "_bn.gamma"), 1, self._p(l.name + "_bn.gamma", True),
                                        self._p(l.name + "_bn.beta", True), nv.ptr(ws.fe_dz[i]), nv.ptr(ws.bn_ws), ws.bn_ws.numel(), st))

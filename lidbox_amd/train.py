@@ -175,6 +175,7 @@ class Trainer:
         self.m = torch.zeros(model.num_flat, **f32)
         self.v = torch.zeros(model.num_flat, **f32)
         self.adam_state = torch.zeros(16, dtype=torch.uint8, device=self.device)     # {int64 step, float lr_t}
+        model.dropout_step = self.adam_state      # FrameLayer2D dropout masks follow the optimizer step (tdnn._dropout_step_ptr)
         bounds, splits = plan_buckets(model, num_buckets)
         self.splits = [] if splits is None else ([splits] if isinstance(splits, int) else list(splits))   # ascending conv indices
         self.split_conv = self.splits[-1] if self.splits else None

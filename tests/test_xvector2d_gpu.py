@@ -182,3 +182,65 @@ def test_xvector_2d_train_step_from_waveforms_and_bf16_compute():
     assert not mb.bf16_storage                       # the shadow path is the plain TDNN's; the front-end model keeps fp32-source kernels
     lb, _ = Trainer(mb, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=False).loss_and_grads(sd, yd)
     assert abs(float(lb) - ref_loss) <= 3e-2 * abs(ref_loss)
+
+
+def test_frame_layer_2d_dropout_forward_mask_and_backward():
+    """FrameLayer2D(dropout_rate=...) (reference xvector_2d.py:37-39,45-46: Keras Dropout behind the BatchNormalization;
+    the reference's create() never sets it).  Inference ignores it; in training an element is zeroed with probability
+    `rate` and the kept ones are the BatchNormalization output / (1 - rate); the mask depends on (seed, optimizer step,
+    position) only -- the same within a step, new after an optimizer step -- and the backward pass applies the same mask:
+    the analytic gradient equals a central finite difference of the (deterministic at a fixed step) loss."""
+    from lidbox_amd.models import xvector_2d
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    from lidbox_amd.models.xvector import frame_layer, segment_layer
+    from lidbox_amd.train import Trainer
+    rate = 0.3
+
+    def build(rate_):
+        frontend = [xvector_2d.FrameLayer2D(16, (1, 5), (1, 2), name="frame2d_1", dropout_rate=rate_),
+                    xvector_2d.FrameLayer2D(8, (1, 3), (1, 3), name="frame2d_2")]
+        convs = [frame_layer(32, 3, 1, name="frame1"), frame_layer(48, 1, 1, name="frame2")]
+        denses = [segment_layer(24, name="segment1"), DenseSpec("output", 3, relu=False)]
+        return SequentialTDNN((12, 40), convs, "stats", denses, name="tiny-2d", output_activation="log_softmax", seed=4,
+                              frontend=frontend)
+    rng = np.random.default_rng(8)
+    x = _dev(rng.standard_normal((5, 12, 40)))
+    y = _dev(rng.integers(0, 3, size=5), np.int32)
+    m, m0 = build(rate), build(0.0)
+    assert torch.equal(m.flat, m0.flat)
+    # inference: no dropout
+    assert torch.equal(m(x, training=False), m0(x, training=False))
+    # training forward: layer 1's output (input rows of layer 2) is the no-dropout output times {0, 1/(1-rate)}
+    m0(x, training=True)
+    clean = m0.workspace(5, 12).fe_y[0].clone()
+    m(x, training=True)
+    dropped = m.workspace(5, 12).fe_y[0].clone()
+    zero = dropped == 0
+    frac = float((zero & (clean != 0)).float().sum() / (clean != 0).float().sum())
+    assert abs(frac - rate) < 0.03, frac
+    assert torch.equal(dropped[~zero], (clean * (1.0 / (1.0 - rate)))[~zero])
+    m(x, training=True)
+    assert torch.equal(m.workspace(5, 12).fe_y[0], dropped)              # same step -> same mask
+    # backward: analytic gradient vs central differences along a random direction of the first conv's weights
+    tr = Trainer(m, use_graph=False)
+    loss, g = tr.loss_and_grads(x, y)
+    g = g.clone()
+    off, shape = m.layout["frame2d_1_conv.W"]
+    n = int(np.prod(shape))
+    d = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    d /= d.norm()
+    eps = 2e-3
+    base = m.flat.clone()
+    vals = []
+    for sgn in (1.0, -1.0):
+        m.flat.copy_(base)
+        m.flat[off:off + n] += sgn * eps * d
+        vals.append(float(tr.loss_and_grads(x, y)[0]))
+    m.flat.copy_(base)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = float((g[off:off + n] * d).sum())
+    assert abs(fd - an) <= 0.03 * max(abs(an), 1e-3) + 2e-4, (fd, an)
+    # a new optimizer step draws a new mask
+    tr.train_step(x, y)
+    m(x, training=True)
+    assert not torch.equal(m.workspace(5, 12).fe_y[0] == 0, zero)
