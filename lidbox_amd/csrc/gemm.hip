@@ -668,10 +668,29 @@ inline bool sk_rows_policy(int kind, int K) {
     return kind == 0 && K >= 1024;
 }
 
-SkRows sk_rows_plan(int kind, long M, int N, int K) {
+// pipelined-epilogue variant (gemm_skp_rows_kernel): 0 off, 1 where the policy says, 2 every eligible launch (A/B aid).
+// MEASURED AND NOT ADOPTED (profiles/r03_gemm_skp_ab.txt, bs 256): correct through every schedule branch
+// (LIDBOX_GEMM_SKP=2 pytest tests/test_gemm_sk_gpu.py) but slower than the classic kernels on every x-vector layer --
+// frame2 dgrad0 289 vs 241 us, frame5 fwd 145 vs 122, frame2 fwd 346 vs 321 (306 on the plain stream-K kernel): the second
+// accumulator set costs the third resident workgroup, and eight stores + the staging traffic per K step between the
+// MFMA groups cost the wave more issue time than the epilogue they hide.  The policy below therefore selects nothing.
+inline int skp_mode() {
+    if (const char* e = getenv("LIDBOX_GEMM_SKP")) return atoi(e);
+    return 1;
+}
+
+// where the pipelined variant is the default (measured, profiles/r03_gemm_skp_ab.txt); LIDBOX_GEMM_SKP=2: everywhere
+inline bool skp_policy(int kind, long M, int N, int K) {
+    (void)kind; (void)M; (void)N; (void)K;
+    return skp_mode() == 2;
+}
+
+SkRows sk_rows_plan(int kind, long M, int N, int K, bool pipelined = false) {
     SkRows c;
-    if (!sk_enabled() || !sk_rows_policy(kind, K) || M < SK_BM || K % 4 != 0 || 2.0 * (double)M * N * K < sk_min_flop()) return c;
-    const unsigned P = sk_grid();
+    if (!sk_enabled() || M < SK_BM || K % 4 != 0 || 2.0 * (double)M * N * K < sk_min_flop()) return c;
+    if (!pipelined && !sk_rows_policy(kind, K)) return c;
+    unsigned P = sk_grid();
+    if (pipelined && P == (unsigned)(NUM_CU * SK_WGCU)) P = NUM_CU * SKP_WGCU;
     if (P % 8 != 0) return c;
     SkPlan& pl = c.pl;
     pl.tiles_n = (int)lbx_cdiv(N, SK_BN);
@@ -694,13 +713,25 @@ SkRows sk_rows_plan(int kind, long M, int N, int K) {
         if (g > (long)(P / 8) / lbx_cdiv(pl.sk_tiles, 8)) g = (long)(P / 8) / lbx_cdiv(pl.sk_tiles, 8);
         if (g < 1) g = 1;
         if (g > 200) g = 200;
-        pl.parts = (int)g;
+        // K steps of the busiest CU (its resident workgroups share the matrix pipes): parts are dealt one per workgroup, so a
+        // big remainder with g = 1 is a half-empty extra round (792 tiles on 512 workgroups: +29 %); equal spans over the
+        // remainder plus one whole round balance exactly and cost two slabs per workgroup (charged 5 %)
+        const long wg_cu = P / NUM_CU > 0 ? P / NUM_CU : 1;
+        const double cu_parts = (double)pl.dp_rounds * pl.nk * wg_cu + (double)lbx_cdiv(pl.sk_tiles * g, NUM_CU) * ((double)pl.nk / g);
+        const double cu_spans = 1.05 * (double)T * pl.nk / NUM_CU;
+        if (cu_parts <= cu_spans) {
+            pl.parts = (int)g;
+        } else {
+            --pl.dp_rounds;
+            pl.sk_first = pl.dp_rounds * (int)P;
+            pl.sk_tiles = (int)T - pl.sk_first;
+        }
     }
     if (pl.parts == 0 && pl.sk_tiles > 0 && (long)pl.sk_tiles * pl.nk < (long)P * SK_MIN_SPAN) return c;
     if (pl.parts == 0 && pl.sk_tiles > 0 && (long)pl.nk * P / ((long)pl.sk_tiles * pl.nk) + 2 > 250) return c;      // arrivals of a tile fit 8 bits
     if ((size_t)pl.sk_tiles * sizeof(unsigned) > SK_COUNTER_BYTES) return c;
     c.P = P;
-    c.ws_need = SK_COUNTER_BYTES + (size_t)P * 2 * SK_SLAB * sizeof(float);
+    c.ws_need = SK_COUNTER_BYTES + (size_t)P * 2 * SK_SLAB * sizeof(float) + (pipelined ? SKP_DUMMY_BYTES : 0);
     c.ok = true;
     return c;
 }
@@ -716,6 +747,10 @@ void sk_set_lds_attr() {
         (void)hipFuncSetAttribute((const void*)gemm_sk_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_sk_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_sk_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
+#define LBX_SKP_ATTR(B_, M_, A_) (void)hipFuncSetAttribute((const void*)gemm_skp_rows_kernel<B_, M_, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SKP_LDS_BYTES)
+        LBX_SKP_ATTR(false, false, false); LBX_SKP_ATTR(false, true, false); LBX_SKP_ATTR(false, false, true); LBX_SKP_ATTR(false, true, true);
+        LBX_SKP_ATTR(true, false, false); LBX_SKP_ATTR(true, true, false); LBX_SKP_ATTR(true, false, true); LBX_SKP_ATTR(true, true, true);
+#undef LBX_SKP_ATTR
         return true;
     }();
     (void)done;
@@ -905,6 +940,36 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
 
     // persistent stream-K kernel (gemm_sk.h): aligned problems that fill the chip, workspace permitting
     if (al && !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && aligned16(ws)) {
+        // the pipelined variant: its in-loop epilogue addresses C rows with at most one utterance wrap per 32-row block
+        // (its drain stages the mask / old values of C through LDS-DMA: 16-byte aligned C rows, whole 16-byte column chunks)
+        const bool has_mask_ = epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK;
+        const bool skp_ok = skp_mode() != 0 && (Cd.batch == 1 || Cd.rows_per_batch >= 32) && N % 4 == 0 && aligned16(Cd.base) &&
+                            Cd.row_stride % 4 == 0 && (Cd.batch == 1 || Cd.batch_stride % 4 == 0) && (!has_mask_ || aligned16(aux)) &&
+                            skp_policy(B_KINNER ? 1 : 0, M, N, K);
+        if (skp_ok) {
+            const SkRows sk = sk_rows_plan(B_KINNER ? 1 : 0, M, N, K, true);
+            if (sk.ok && wsb >= sk.ws_need && sk_extent_ok(A, K)) {
+                sk_set_lds_attr();
+                g_last_launches[0] = 1;
+                g_first_tile[0] = SK_BM; g_first_tile[1] = SK_BN;
+                unsigned* counters = (unsigned*)ws;
+                float* slabs = (float*)((char*)ws + SK_COUNTER_BYTES);
+                float* dummy = slabs + (size_t)sk.P * 2 * SK_SLAB;
+                const bool has_mask = epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK;
+                const bool accum = epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU;
+                const unsigned ep = sk_next_epoch();
+#define LBX_SKP(MASK_, ACC_)                                                                                                \
+    hipLaunchKernelGGL((gemm_skp_rows_kernel<B_KINNER, MASK_, ACC_>), dim3(sk.P), dim3(256), (MASK_ || ACC_) ? SKP_LDS_BYTES : SK_LDS_BYTES, st, Ad, Bm, ldb, Co, M, K, \
+                       N, epi, aux, sk.pl, ep, counters, slabs, dummy)
+                if (has_mask && accum) LBX_SKP(true, true);
+                else if (has_mask) LBX_SKP(true, false);
+                else if (accum) LBX_SKP(false, true);
+                else LBX_SKP(false, false);
+#undef LBX_SKP
+                LBX_LAUNCH_OK();
+                return LIDBOX_OK;
+            }
+        }
         const SkRows sk = sk_rows_plan(B_KINNER ? 1 : 0, M, N, K);
         if (sk.ok && wsb >= sk.ws_need && sk_extent_ok(A, K)) {
             sk_set_lds_attr();
@@ -1056,6 +1121,10 @@ extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
     for (int kind = 0; kind < 2; ++kind) {
         const SkRows sk = sk_rows_plan(kind, M, N, K);
         if (sk.ok && sk.ws_need > need) need = sk.ws_need;
+        if (skp_mode() != 0 && skp_policy(kind, M, N, K)) {
+            const SkRows skp = sk_rows_plan(kind, M, N, K, true);
+            if (skp.ok && skp.ws_need > need) need = skp.ws_need;
+        }
     }
     return need;
 }

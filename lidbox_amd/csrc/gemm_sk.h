@@ -70,14 +70,14 @@ __device__ __forceinline__ void sk_dma_s(const float* sbase, unsigned voff, unsi
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
                  : "memory");
 }
 __device__ __forceinline__ void sk_dma_f(const float* p, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(p), "s"(lds_dst)
+                 : "v"(p), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
                  : "memory");
 }
 // a pointer every lane holds the same value of, provably so for the compiler (SGPR pair): the "s" operands of the DMA
@@ -217,64 +217,96 @@ __device__ __forceinline__ void sk_mma(const float (&a)[2][4], const float (&b)[
 // The K loop over n steps of one work item.  issue(piece, step, lds_dst) puts piece 0..3 (A0, A1, B0, B1) of step `step`
 // (0-based inside the item) on its way, next() is called once all four pieces of a step are out; reads come through
 // ra / rb (stage base, sub-step) -> registers.
-template <class IssueF, class NextF, class ReadA, class ReadB>
+// drain(i), i = 0 .. 7, is called behind each of the eight MFMA groups of a step and step_end() once per step: the pipelined
+// kernel issues one piece of the PREVIOUS tile's epilogue there (gemm_skp_rows_kernel); the others pass no-ops.
+// epi_ops(): vector-memory instructions the drains of the coming step will issue, EXACTLY (wave-uniform): they sit between
+// the ring's DMAs in the vmcnt queue (gfx9 returns vector memory operations in issue order), so the wait that publishes a
+// stage allows for the ones issued after that stage's DMAs -- a count that is too high would read the stage early.
+struct SkNoDrain {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+struct SkNoEpiOps {
+    __device__ __forceinline__ int operator()() const { return 0; }
+};
+__device__ __forceinline__ void sk_wait_vm_dyn(int nops) {
+    switch (nops) {
+        case 0: sk_wait_vm<0>(); break;
+        case 4: sk_wait_vm<4>(); break;
+        case 8: sk_wait_vm<8>(); break;
+        case 12: sk_wait_vm<12>(); break;
+        case 16: sk_wait_vm<16>(); break;
+        case 20: sk_wait_vm<20>(); break;
+        case 24: sk_wait_vm<24>(); break;
+        case 28: sk_wait_vm<28>(); break;
+        default: sk_wait_vm<0>(); break;
+    }
+}
+template <int STAGES, int WGCU, class IssueF, class NextF, class ReadA, class ReadB, class DrainF, class StepEndF, class EpiOpsF>
 __device__ __forceinline__ void sk_kloop(float* smem, unsigned lds0, int wv, int n, int prio_slot, IssueF issue, NextF next,
-                                         ReadA ra, ReadB rb, f32x16 (&acc)[2][2]) {
+                                         ReadA ra, ReadB rb, f32x16 (&acc)[2][2], DrainF drain, StepEndF step_end, EpiOpsF epi_ops) {
     auto dst = [&](int stage, int piece) -> unsigned {
         return lds0 + (unsigned)((stage * SK_STAGE + (piece >> 1) * SK_A_STAGE + (wv * 2 + (piece & 1)) * 256) * 4);
     };
     // every wave is past the previous item's LDS reads once it arrives here (its MFMAs consumed them)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int s = 0; s < SK_STAGES - 1; ++s)
+    for (int s = 0; s < STAGES - 1; ++s)
         if (s < n) {
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) issue(pc, s, dst(s, pc));
             next();
         }
-    if (n >= SK_STAGES - 1) sk_wait_vm<(SK_STAGES - 2) * 4>();
+    if (n >= STAGES - 1) sk_wait_vm<(STAGES - 2) * 4>();
     else sk_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
     ra(smem, 0, a0);
     rb(smem + SK_A_STAGE, 0, b0);
     int cur = 0;
+    int e_prev = 0;                     // epilogue operations issued during the previous step
     for (int t = 0; t < n; ++t) {
-        // publish step t+1: its pieces were issued SK_STAGES-2 steps ago
+        // publish step t+1: its pieces were issued STAGES-2 steps ago; what was issued since may stay in flight:
+        // the DMAs of the steps after it (STAGES >= 4) and the previous step's epilogue operations
         if (t + 1 < n) {
-            if (SK_STAGES >= 4 && t + SK_STAGES - 2 < n) sk_wait_vm<(SK_STAGES >= 4 ? (SK_STAGES - 3) * 4 : 0)>();
-            else sk_wait_vm<0>();
+            if (STAGES >= 4 && t + STAGES - 2 < n) sk_wait_vm_dyn((STAGES - 3) * 4 + (STAGES >= 4 ? e_prev : 0));
+            else sk_wait_vm_dyn(STAGES >= 4 ? e_prev : 0);
         }
+        e_prev = epi_ops();
         __builtin_amdgcn_s_barrier();
         int nxt = cur + 1;
-        if (nxt == SK_STAGES) nxt = 0;
-        const bool more = t + SK_STAGES - 1 < n;
-        int tgt = cur + SK_STAGES - 1;
-        if (tgt >= SK_STAGES) tgt -= SK_STAGES;
+        if (nxt == STAGES) nxt = 0;
+        const bool more = t + STAGES - 1 < n;
+        int tgt = cur + STAGES - 1;
+        if (tgt >= STAGES) tgt -= STAGES;
         const float* st = smem + cur * SK_STAGE;
-        if (SK_WGCU > 1 && LBX_SK_PRIO_ROTATE) {
-            if ((unsigned)(t + prio_slot) % (unsigned)SK_WGCU == 0) __builtin_amdgcn_s_setprio(2);
+        if (WGCU > 0 && LBX_SK_PRIO_ROTATE) {
+            if ((unsigned)(t + prio_slot) % (unsigned)(WGCU > 0 ? WGCU : 1) == 0) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
         }
         sk_mma<0, 1>(a0, b0, acc);
+        drain(0);
         __builtin_amdgcn_sched_barrier(0);
         ra(st, 1, a1);
         rb(st + SK_A_STAGE, 1, b1);
         __builtin_amdgcn_sched_barrier(0);
         sk_mma<1, 2>(a0, b0, acc);
-        if (more) issue(0, t + SK_STAGES - 1, dst(tgt, 0));
+        if (more) issue(0, t + STAGES - 1, dst(tgt, 0));
+        drain(1);
         __builtin_amdgcn_sched_barrier(0);
         sk_mma<2, 3>(a0, b0, acc);
-        if (more) issue(1, t + SK_STAGES - 1, dst(tgt, 1));
+        if (more) issue(1, t + STAGES - 1, dst(tgt, 1));
+        drain(2);
         __builtin_amdgcn_sched_barrier(0);
         sk_mma<3, 4>(a0, b0, acc);
-        if (more) issue(2, t + SK_STAGES - 1, dst(tgt, 2));
+        if (more) issue(2, t + STAGES - 1, dst(tgt, 2));
+        drain(3);
         __builtin_amdgcn_sched_barrier(0);
         sk_mma<0, 1>(a1, b1, acc);
         if (more) {
-            issue(3, t + SK_STAGES - 1, dst(tgt, 3));
+            issue(3, t + STAGES - 1, dst(tgt, 3));
             next();
         }
+        drain(4);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < n) {
             const float* sn = smem + nxt * SK_STAGE;
@@ -282,10 +314,18 @@ __device__ __forceinline__ void sk_kloop(float* smem, unsigned lds0, int wv, int
             rb(sn + SK_A_STAGE, 0, b0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        sk_mma<1, 4>(a1, b1, acc);
+        sk_mma<1, 2>(a1, b1, acc);
+        drain(5);
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<2, 3>(a1, b1, acc);
+        drain(6);
+        __builtin_amdgcn_sched_barrier(0);
+        sk_mma<3, 4>(a1, b1, acc);
+        drain(7);
+        step_end();
         cur = nxt;
     }
-    if (SK_WGCU > 1 && LBX_SK_PRIO_ROTATE) __builtin_amdgcn_s_setprio(0);
+    if (WGCU > 0 && LBX_SK_PRIO_ROTATE) __builtin_amdgcn_s_setprio(0);
 }
 
 // partial tile <-> slab, accumulator order: [(wave * 4 + block) * 4 + r4][lane][4] -- 1 KB per wave access.
@@ -314,7 +354,7 @@ __device__ __forceinline__ void sk_slab_add(const float* slab, f32x16 (&acc)[2][
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj)
+        for (int bj = 0; bj < 2; ++bj) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const f32x4_t x = __builtin_bit_cast(
@@ -322,6 +362,9 @@ __device__ __forceinline__ void sk_slab_add(const float* slab, f32x16 (&acc)[2][
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[bi][bj][4 * r4 + j] += x[j];
             }
+            // four 16-byte loads in flight at a time: left alone the scheduler hoists all sixteen (64 registers) above the adds
+            __builtin_amdgcn_sched_barrier(0);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,7 +447,7 @@ __global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_rows_kernel(RowsD A, con
             if (B_KINNER) obi.read(st, lane, s2, v);
             else obo.read(st, lane, s2, v);
         };
-        sk_kloop(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc);
+        sk_kloop<SK_STAGES, SK_WGCU>(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc, SkNoDrain{}, [] {}, SkNoEpiOps{});
     };
 
     f32x16 acc[2][2];
@@ -528,6 +571,406 @@ __global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_rows_kernel(RowsD A, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pipelined variant of the rows kernel: the epilogue of a finished tile is NOT run behind its K loop.  The tile's
+// accumulators are copied to a second register set and its epilogue is issued behind the MFMA groups of the NEXT item's K
+// loop, one (32 x 32 block, 8-row) group per K step:
+//     step s     : the mask / old values of group s start on their way into a per-wave LDS staging area BY LDS-DMA
+//     step s + 2 : they are read from LDS, group s is finished and its eight rows are stored
+// so the only vector-memory operations inside the K loop are LDS-DMAs and stores: nothing the compiler has to wait for (a
+// VGPR load carried around the loop makes hipcc drain the whole queue, ring DMAs included, at every use), and every drain
+// step issues an EXACT number of them -- lanes outside the matrix read a safe address and store to a scratch word -- which
+// the counted vmcnt wait of the ring accounts for (sk_kloop: epi_ops).  A tile with K = 512 otherwise spends a fifth of its
+// life in a mask epilogue (dependent load -> select -> store chains with idle matrix pipes, all resident workgroups of a
+// persistent grid at once).  Two workgroups per CU (256 registers per lane, 48 KB ring + 32 KB staging each = all 160 KB);
+// no priority rotation: between equal priorities the older workgroup runs ahead, which staggers the two residents' tile
+// boundaries.  Streamed (partial) tiles keep the synchronous slab / ticket path; the tile a last arriver sums takes the
+// pipelined road like a whole one.
+// ------------------------------------------------------------------------------------------------
+constexpr int SKP_WGCU = 2;
+constexpr int SKP_STAGE_FLOATS = 512;          // one group of one kind for one wave: 16 rows x 32 columns
+constexpr size_t SKP_LDS_BYTES = SK_LDS_BYTES + (size_t)4 * 4 * SKP_STAGE_FLOATS * sizeof(float);   // + [wave][buffer][kind]
+constexpr size_t SKP_DUMMY_BYTES = (size_t)NUM_CU * SK_WGCU * 256 * sizeof(float);   // where lanes outside the matrix "store"
+
+struct SkPend {
+    int s;                  // drain step of the pending tile: 0 .. 9; 10: nothing pending
+    long m0;
+    int n0;
+};
+
+struct SkEpiCtx {
+    RowsOutD Cd;
+    long M;
+    int N;
+    const float* aux;
+    bool has_bias, do_relu;
+    long wrap;
+    unsigned t_wrap;
+    float bias0, bias1;     // bias of this lane's two columns of the pending tile
+    float* dummy;           // this lane's scratch word: the store target of lanes outside the matrix (every drain store is issued)
+    float* stage;           // this wave's LDS staging area [buffer 2][kind 2][16 rows][32 columns]
+    unsigned stage_lds;     // its LDS byte address
+};
+
+// values of group g (block bi = g >> 2, bj = (g >> 1) & 1, rows r0 = 8 (g & 1) .. + 7) out of the accumulators: the only place
+// that indexes them with the group, as a switch over compile-time indices (a runtime index would put them in scratch)
+__device__ __forceinline__ void skp_extract(const f32x16 (&acc)[2][2], int g, float (&val)[8]) {
+#define SKP_CASE(G)                                                                        \
+    case G:                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) val[i] = acc[(G) >> 2][((G) >> 1) & 1][8 * ((G) & 1) + i]; \
+        break;
+    switch (g) {
+        SKP_CASE(0) SKP_CASE(1) SKP_CASE(2) SKP_CASE(3) SKP_CASE(4) SKP_CASE(5) SKP_CASE(6) SKP_CASE(7)
+        default: break;
+    }
+#undef SKP_CASE
+}
+
+// element offset of row (rb + dr) of C / the mask (negative: outside the matrix).  rb is the first row of a 32-row block and
+// WAVE-UNIFORM (the division runs on the scalar unit); dr in 0 .. 31 is the lane's part; an utterance holds >= 32 rows
+// (checked on the host), so a block crosses at most one utterance boundary.
+__device__ __forceinline__ long skp_row_off(long rb, int dr, const SkEpiCtx& c) {
+    long o;
+    const unsigned rbu = (unsigned)__builtin_amdgcn_readfirstlane((int)rb);
+    if (c.Cd.batch != 1) {
+        const unsigned b0 = rbu / (unsigned)c.Cd.rpb;
+        const unsigned t0 = rbu - b0 * (unsigned)c.Cd.rpb;
+        o = ((long)b0 * c.Cd.bs + (long)t0 * c.Cd.rs) + (long)dr * c.Cd.rs + (t0 + (unsigned)dr >= c.t_wrap ? c.wrap : 0);
+    } else {
+        o = (long)(rbu + (unsigned)dr) * c.Cd.rs;
+    }
+    return (long)rbu + dr < c.M ? o : -1;
+}
+
+// the mask / old values of group g of the pending tile start towards staging buffer g & 1: per kind two LDS-DMAs, one per
+// half wave h of the CONSUMER layout (lane -> row slot lane >> 3 = row i of the group, 16-byte chunk lane & 7 of its 32 columns)
+template <bool HAS_MASK, bool ACCUM>
+__device__ __forceinline__ void skp_issue_loads(const SkPend& pd, int g, const SkEpiCtx& c, int wm, int wn, int lane) {
+    const int bi = g >> 2, bj = (g >> 1) & 1;
+    const int i = lane >> 3, chunk = lane & 7;
+    const int dr = (i & 3) + 8 * (i >> 2) + 16 * (g & 1);
+    const int col = pd.n0 + wn * 64 + bj * 32 + chunk * 4;
+    const long rb = pd.m0 + wm * 64 + bi * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const long o = skp_row_off(rb, dr + 4 * h, c);
+        const long a = (o >= 0 && col < c.N) ? o + col : 0;                  // a safe address for what lies outside the matrix
+        const unsigned dst = c.stage_lds + (unsigned)((((g & 1) * 2) * SKP_STAGE_FLOATS + h * 256) * 4);
+        if (HAS_MASK) sk_dma_f(c.aux + a, dst);
+        if (ACCUM) sk_dma_f(c.Cd.base + a, dst + SKP_STAGE_FLOATS * 4);
+    }
+}
+
+// group g of the pending tile: staged values -> registers (before the buffer is handed to group g + 2's DMAs)
+template <bool HAS_MASK, bool ACCUM>
+__device__ __forceinline__ void skp_read_stage(int g, const SkEpiCtx& c, int lane, float (&mv)[8], float (&ov)[8]) {
+    const float* st = c.stage + ((g & 1) * 2) * SKP_STAGE_FLOATS + (lane >> 5) * 256 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (HAS_MASK) mv[i] = st[i * 32];
+        if (ACCUM) ov[i] = st[SKP_STAGE_FLOATS + i * 32];
+    }
+}
+
+// rows i0 .. i0 + 3 of group g: finish and store (every lane stores: outside the matrix to its scratch word)
+template <bool HAS_MASK, bool ACCUM>
+__device__ __forceinline__ void skp_store4(const SkPend& pd, int g, int i0, const SkEpiCtx& c, int wm, int wn, int lane,
+                                           const float (&val)[8], const float (&mv)[8], const float (&ov)[8]) {
+    const int bi = g >> 2, bj = (g >> 1) & 1;
+    const int col = pd.n0 + wn * 64 + bj * 32 + (lane & 31);
+    const float bias = bj ? c.bias1 : c.bias0;
+    const long rb = pd.m0 + wm * 64 + bi * 32;
+#pragma unroll
+    for (int i = i0; i < i0 + 4; ++i) {
+        const int dr = (i & 3) + 8 * (i >> 2) + 16 * (g & 1) + 4 * (lane >> 5);
+        const long o = skp_row_off(rb, dr, c);
+        float x = val[i] + bias;
+        if (HAS_MASK) x = mv[i] > 0.f ? x : 0.f;
+        if (ACCUM) x += ov[i];
+        if (c.do_relu) x = fmaxf(x, 0.f);
+        float* dst = (o >= 0 && col < c.N) ? c.Cd.base + o + col : c.dummy;
+        *dst = x;
+    }
+}
+
+template <bool B_KINNER, bool HAS_MASK, bool ACCUM>
+__global__ __launch_bounds__(256, SKP_WGCU) void gemm_skp_rows_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
+                                                                      long M, int K, int N, int epi, const float* __restrict__ aux,
+                                                                      SkPlan pl, unsigned epoch, unsigned* __restrict__ counters,
+                                                                      float* __restrict__ slabs, float* __restrict__ dummy) {
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const unsigned P = gridDim.x;
+    const unsigned pid = xcd_chunk_id(blockIdx.x, P);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)sk_smem);
+    const int nk = pl.nk;
+    const long total = (long)pl.sk_tiles * nk;
+
+    SkEpiCtx ec;
+    ec.Cd = Cd; ec.M = M; ec.N = N; ec.aux = aux;
+    ec.has_bias = epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU;
+    ec.do_relu = epi == LIDBOX_EPI_BIAS_RELU || epi == LIDBOX_EPI_ACCUM_RELU || epi == LIDBOX_EPI_RELU;
+    ec.wrap = Cd.batch != 1 ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
+    ec.t_wrap = Cd.batch != 1 ? (unsigned)Cd.rpb : 0xffffffffu;
+    ec.bias0 = ec.bias1 = 0.f;
+    ec.dummy = dummy + (long)blockIdx.x * 256 + tid;
+    ec.stage = sk_smem + SK_STAGES * SK_STAGE + wv * 4 * SKP_STAGE_FLOATS;
+    ec.stage_lds = lds0 + (unsigned)((SK_STAGES * SK_STAGE + wv * 4 * SKP_STAGE_FLOATS) * 4);
+
+    SkPend pd;
+    pd.s = 10;
+    pd.m0 = 0; pd.n0 = 0;
+    float val[8], mv[8], ov[8];      // the group being stored in the current drain step
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { val[i] = 0.f; mv[i] = 0.f; ov[i] = 0.f; }
+    // one drain step = three pieces, placed behind the ring's DMAs of the K step (MFMA groups 5, 6, 7)
+    auto drain_piece = [&](int which, const f32x16 (&prev)[2][2]) {
+        const int ds = __builtin_amdgcn_readfirstlane(pd.s);          // wave-uniform, and provably so: scalar branches
+        if (ds >= 10) return;
+        if (which == -1) {
+            if (ds >= 2) {                                    // group s - 2: staged two steps ago, landed (counted wait / flush wait)
+                skp_read_stage<HAS_MASK, ACCUM>(ds - 2, ec, lane, mv, ov);
+                skp_extract(prev, ds - 2, val);
+            }
+        } else if (which == 0) {
+            // the staging reads (issued one MFMA group ago) are back before their buffer is refilled
+            if ((HAS_MASK || ACCUM) && ds >= 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ds < 8) skp_issue_loads<HAS_MASK, ACCUM>(pd, ds, ec, wm, wn, lane);
+        } else if (ds >= 2) {
+            skp_store4<HAS_MASK, ACCUM>(pd, ds - 2, which == 1 ? 0 : 4, ec, wm, wn, lane, val, mv, ov);
+        }
+    };
+    auto drain_ops = [&]() -> int {
+        const int ds = __builtin_amdgcn_readfirstlane(pd.s);
+        if (ds >= 10) return 0;
+        return (ds < 8 ? 2 * ((HAS_MASK ? 1 : 0) + (ACCUM ? 1 : 0)) : 0) + (ds >= 2 ? 8 : 0);
+    };
+    // outside a K loop: the rest of the pending epilogue, step by step (each step waits for everything in flight)
+    auto flush = [&](const f32x16 (&prev)[2][2]) {
+        while (pd.s < 10) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drain_piece(-1, prev);
+            drain_piece(0, prev);
+            drain_piece(1, prev);
+            drain_piece(2, prev);
+            ++pd.s;
+        }
+    };
+
+    // work items as in gemm_sk_rows_kernel
+    long it = 0, end = 0;
+    const int g = pl.parts;
+    int pt_tile = -1, pt_part = 0;
+    if (pl.sk_tiles > 0) {
+        if (g == 0) {
+            it = (long)pid * total / P;
+            end = (long)(pid + 1) * total / P;
+        } else {
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            const int t = (idx / g) * 8 + xcd;
+            if (t < pl.sk_tiles) { pt_tile = t; pt_part = idx % g; }
+        }
+    }
+    int which = 0, d = 0;
+
+    // One K loop and one accumulator set `cur`; a finished whole tile is COPIED to `prev` (64 register moves per tile) and
+    // drains from there while the next item accumulates into `cur`.
+    f32x16 cur[2][2], prev[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) prev[i][j][r] = 0.f;
+    for (;;) {
+        int tile, kb, ke, t = 0;
+        if (pt_tile >= 0) {
+            t = pt_tile;
+            pt_tile = -1;
+            kb = (int)((long)pt_part * nk / g);
+            ke = (int)((long)(pt_part + 1) * nk / g);
+            tile = pl.sk_first + t;
+        } else if (it < end) {
+            t = (int)(it / nk);
+            kb = (int)(it - (long)t * nk);
+            ke = kb + (int)(end - it);
+            if (ke > nk) ke = nk;
+            it += ke - kb;
+            tile = pl.sk_first + t;
+        } else if (d < pl.dp_rounds) {
+            tile = d * (int)P + (int)pid;
+            kb = 0;
+            ke = nk;
+            ++d;
+        } else {
+            break;
+        }
+        const int tn = tile % pl.tiles_n, tm = tile / pl.tiles_n;
+        const long m0 = (long)tm * SK_BM;
+        const int n0 = tn * SK_BN;
+        SkInner oa;
+        {
+            long roff[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                long r = m0 + 16 * (wv * 2 + i) + (lane >> 2);
+                if (r >= M) r = m0;
+                roff[i] = row_offset(A, (unsigned)r);
+            }
+            oa.init(A.base, roff, kb * SK_BK, lane, wm);
+        }
+        SkInner obi;
+        SkOuter obo;
+        if (B_KINNER) {
+            long roff[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                long r = n0 + 16 * (wv * 2 + i) + (lane >> 2);
+                if (r >= N) r = n0;
+                roff[i] = r * ldb;
+            }
+            obi.init(Bm, roff, kb * SK_BK, lane, wn);
+        } else {
+            obo.init(Bm, ldb, n0, N, kb * SK_BK, lane, wv, wn);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cur[i][j][r] = 0.f;
+        const int n = ke - kb;
+        const int tail_step = (ke == nk && pl.ktail < SK_BK) ? n - 1 : -1;
+        auto issue = [&](int pc, int step, unsigned dd) {
+            if (step == tail_step) {
+                if (pc < 2) oa.issue_tail(pc, dd, pl.ktail, lane);
+                else if (B_KINNER) obi.issue_tail(pc - 2, dd, pl.ktail, lane);
+                else obo.issue_tail(pc - 2, dd, pl.ktail, lane, wv);
+            } else {
+                if (pc < 2) oa.issue(pc, dd);
+                else if (B_KINNER) obi.issue(pc - 2, dd);
+                else obo.issue(pc - 2, dd);
+            }
+        };
+        auto next = [&]() {
+            oa.advance();
+            if (B_KINNER) obi.advance();
+            else obo.advance();
+        };
+        auto ra = [&](const float* st, int s2, float (&v)[2][4]) { oa.read(st, lane, s2, v); };
+        auto rb = [&](const float* st, int s2, float (&v)[2][4]) {
+            if (B_KINNER) obi.read(st, lane, s2, v);
+            else obo.read(st, lane, s2, v);
+        };
+        auto drain = [&](int i) {
+            if (i >= 4) drain_piece(i - 5, prev);
+        };
+        auto step_end = [&]() {
+            if (pd.s < 10) ++pd.s;
+        };
+        sk_kloop<SK_STAGES, 0>(sk_smem, lds0, wv, n, 0, issue, next, ra, rb, cur, drain, step_end, drain_ops);
+        // what the K loop was too short to drain (prev is about to be overwritten / the drain registers reused)
+        flush(prev);
+        if (kb == 0 && ke == nk) {
+            // whole tile: its epilogue rides the next item's K loop
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) prev[i][j] = cur[i][j];
+            pd.s = 0;
+            pd.m0 = m0;
+            pd.n0 = n0;
+            if (ec.has_bias) {
+                const int c0 = n0 + wn * 64 + (lane & 31);
+                ec.bias0 = c0 < N ? aux[c0] : 0.f;
+                ec.bias1 = c0 + 32 < N ? aux[c0 + 32] : 0.f;
+            }
+            continue;
+        }
+        // ---- partial tile: slab, ticket, and the last arriver finishes the tile (synchronously, on `cur`)
+        // nothing is pending here (flushed above): say so to the register allocator -- `prev` and the drain state are dead
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) prev[i][j][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { val[i] = 0.f; mv[i] = 0.f; ov[i] = 0.f; }
+        int lane_e = lane, wv_e = wv;
+        asm volatile("" : "+v"(lane_e), "+s"(wv_e));
+        const long my_slab = g == 0 ? (long)pid * 2 + which : (long)blockIdx.x * 2;
+        sk_slab_store(slabs + my_slab * SK_SLAB, cur, wv_e, lane_e);
+        ++which;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(sk_smem);
+        if (tid == 0) {
+            unsigned old = __hip_atomic_load(counters + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned cnt;
+            for (;;) {
+                cnt = (old >> 8) == epoch ? (old & 255u) : 0u;
+                if (__hip_atomic_compare_exchange_strong(counters + t, &old, (epoch << 8) | (cnt + 1u), __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break;
+            }
+            *flag = cnt;
+        }
+        __syncthreads();
+        const unsigned ticket = *flag;
+        long pa = 0, pb = g - 1;
+        if (g == 0) {
+            const long ib = (long)t * nk, ie = ib + nk;
+            pa = ib * P / total;
+            while (pa > 0 && pa * total / P > ib) --pa;
+            while ((pa + 1) * total / P <= ib) ++pa;
+            pb = (ie - 1) * P / total;
+            while (pb + 1 < (long)P && (pb + 1) * total / P < ie) ++pb;
+            while (pb * total / P >= ie) --pb;
+        }
+        __syncthreads();
+        if (ticket == (unsigned)(pb - pa)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[i][j][r] = 0.f;
+            for (long p = pa; p <= pb; ++p) {
+                long sl;
+                if (g == 0) {
+                    const long b = p * total / P, e = (p + 1) * total / P;
+                    const long t0 = b / nk;
+                    const bool first_partial = !(b == t0 * nk && e >= (t0 + 1) * nk);
+                    sl = p * 2 + ((t0 == t) ? 0 : (first_partial ? 1 : 0));
+                } else {
+                    const long idx0 = (long)(t >> 3) * g;
+                    sl = (((idx0 + p) << 3) | (t & 7)) * 2;
+                }
+                sk_slab_add(slabs + sl * SK_SLAB, cur, wv_e, lane_e);
+            }
+            if (tid == 0) __hip_atomic_store(counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the summed tile takes the same road as a whole one: its epilogue rides the next item's K loop
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) prev[i][j] = cur[i][j];
+            pd.s = 0;
+            pd.m0 = m0;
+            pd.n0 = n0;
+            if (ec.has_bias) {
+                const int c0 = n0 + wn * 64 + (lane & 31);
+                ec.bias0 = c0 < N ? aux[c0] : 0.f;
+                ec.bias1 = c0 + 32 < N ? aux[c0 + 32] : 0.f;
+            }
+        }
+    }
+    // the last finished tile
+    flush(prev);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = column sums of B[Mslice]
 // grid = ntiles x splits (consecutive blocks = the tiles of one slice), rows_per_split a multiple of 16.
 // (Slabs in accumulator order with a matching reduce kernel were tried: 16-byte slab stores, but the reduce then scatters
@@ -577,7 +1020,7 @@ __global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_tn_kernel(RowsD A, RowsD
             for (int kk = 0; kk < SK_BK; ++kk) csum += st[kk * 128 + tid];
         }
     };
-    sk_kloop(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc);
+    sk_kloop<SK_STAGES, SK_WGCU>(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc, SkNoDrain{}, [] {}, SkNoEpiOps{});
 
     float* Pd = P + (long)split * K1 * N;
     const int h = lane >> 5, l = lane & 31;
