@@ -219,3 +219,51 @@ def test_stream_k_full_size_layers_on_the_real_grid(kind, M, K, N, monkeypatch):
                                        nv.ptr(ws), wsb, st))
         ref = (a.double() @ b.double().t()) * (mask > 0)
     assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("grid", [16, 40, 64])
+def test_pipelined_epilogue_variant_matches_float64(grid, small_grid, monkeypatch):
+    """gemm_skp_rows_kernel (LIDBOX_GEMM_SKP=2; measured, not adopted: profiles/r03_gemm_skp_ab.txt): a finished tile's epilogue
+    -- bias / ReLU, ReLU mask, accumulate -- is drained behind the next item's MFMA groups, the mask and old values staged by
+    LDS-DMA.  Same answers as float64 through whole rounds, remainder parts and equal spans, plain and conv-layout outputs
+    (utterance gap inside a 32-row block), bit-identical run to run."""
+    from lidbox_amd import _native as nv
+    small_grid(grid)
+    monkeypatch.setenv("LIDBOX_GEMM_SKP", "2")
+    rng = np.random.default_rng(100 + grid)
+    M, K, N = 1300, 600, 500
+    A, Bm, Bt = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((N, K))
+    bias, mask = rng.standard_normal(N), rng.standard_normal((M, N))
+    a, b, bt, bi, mk = _dev(A), _dev(Bm), _dev(Bt), _dev(bias), _dev(mask)
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_rows_workspace(M, N, K)
+    ws = _garbage_ws(wsb)
+    c = torch.full((M, N), 7.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), wsb, st))
+    first = c.clone()
+    _close(c.cpu().numpy(), np.maximum(A @ Bm + bias, 0))
+    c.fill_(-1.0)
+    nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), wsb, st))
+    assert torch.equal(c, first)
+    c.fill_(-2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_ACCUM_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0) - 2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0))
+    # conv layout: 26 utterances of 50 output rows inside [26, 53, N] buffers (3 leading rows per utterance untouched)
+    Bn, R, Rp = 26, 50, 53
+    cb = torch.full((Bn, Rp, N), 7.0, device="cuda")
+    mkb = torch.zeros((Bn, Rp, N), device="cuda")
+    mkb[:, 3:, :] = mk[:Bn * R].reshape(Bn, R, N)
+    cv, mv = cb[:, 3:, :], mkb[:, 3:, :]
+    Cd = nv.Rows(cv.data_ptr(), Rp * N, N, Bn, R)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, Bn * R), nv.ptr(bt), K, Cd, K, N, nv.EPI_ACCUM_RELU_MASK,
+                                   nv.C.c_void_p(mv.data_ptr()), nv.ptr(ws), wsb, st))
+    got = cb.cpu().numpy()
+    ref = (A[:Bn * R] @ Bt.T) * (mask[:Bn * R] > 0) + 7.0
+    _close(got[:, 3:, :].reshape(Bn * R, N), ref)
+    assert np.all(got[:, :3, :] == 7.0)
