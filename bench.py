@@ -64,8 +64,8 @@ PEAK_HBM_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="utterances per GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--buckets", type=int, default=3,

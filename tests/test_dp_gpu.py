@@ -205,3 +205,59 @@ def test_two_rccl_ranks_step_equals_single_process_step(tmp_path):
     assert np.allclose(single["losses"], dual["losses"], rtol=1e-5, atol=1e-6)
     diff = np.abs(single["flat"] - dual["flat"])
     assert np.median(diff) <= 1e-6 and diff.max() <= 3 * 2e-3 + 1e-6
+
+
+_WORKER_TWO_SHAPES = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer, init_distributed
+
+    use_graph = bool(int(sys.argv[1]))
+    out_path = sys.argv[2]
+    os.environ["LOCAL_RANK"] = "0"
+    rank, world, _ = init_distributed(backend="gloo")
+    torch.cuda.set_device(0)
+    sig, y = synthetic_batch(13, num_labels=4, duration_s=0.5)
+    # step A: 13 utterances as 7 + 6; step B: the first 11 as 7 + 4 -- rank 0's shard size does NOT change, the global batch does
+    cuts = {1: [(0, 13), (0, 11)], 2: [((0, 7), (7, 13)), ((0, 7), (7, 11))]}[world]
+    model = xvector.create((48, 40), 4, seed=0)
+    plan = audio.get_plan(16000, 400, 160)
+    tr = Trainer(model, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=use_graph, num_buckets=2)
+    losses = []
+    for step, total in ((0, 13), (1, 11), (0, 13), (1, 11)):
+        lo, hi = cuts[step] if world == 1 else cuts[step][rank]
+        sd = torch.from_numpy(sig[lo:hi]).cuda()
+        yd = torch.from_numpy(y[lo:hi].astype(np.int32)).cuda()
+        losses.append(float(tr.train_step(sd, yd, global_batch=total)) * (hi - lo) / total)     # this rank's share of the global mean
+    torch.cuda.synchronize()
+    l = torch.tensor(losses, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(l)
+    if rank == 0:
+        np.savez(out_path, flat=model.flat.cpu().numpy(), losses=l.numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_global_batch_changes_while_one_ranks_shard_does_not(tmp_path, use_graph):
+    """the loss scale must follow the GLOBAL batch of every step, also when this rank's own shard size stays the
+    same (a short last batch that only shortens the last rank's shard).  Two ranks run 7 + 6, then 7 + 4 utterances, twice,
+    passing `global_batch=`; a single process runs 13, then 11: same loss trajectory and weights (the scale is part of the
+    captured step's key, so the graph path keeps one graph per global batch)."""
+    script = tmp_path / "worker_two_shapes.py"
+    script.write_text(_WORKER_TWO_SHAPES % {"root": ROOT})
+    single = _run(script, 1, use_graph, tmp_path / "single.npz")
+    dual = _run(script, 2, use_graph, tmp_path / "dual.npz")
+    assert np.allclose(single["losses"], dual["losses"], rtol=2e-5, atol=1e-6), (single["losses"], dual["losses"])
+    diff = np.abs(single["flat"] - dual["flat"])
+    assert np.median(diff) <= 1e-6 and (diff > 2e-4).mean() <= 2e-3 and diff.max() <= 4 * 2e-3 + 1e-6
