@@ -156,6 +156,8 @@ class KernelTimer:
                     out3 = (ctypes.c_int * 3)()
                     self.nv.check(self.nv.lib.lidbox_gemm_last_launches(out3))
                     nk = max(1, out3[0])
+                    if self.nv.lib.lidbox_gemm_last_family() == 1:     # the LDS-DMA instantiation of the same tile shape
+                        key = key.replace("gemm_rows_kernel<", "gemm_rows_dma_kernel<")
                 self.records.setdefault(key, []).append((e0, e1, work, nk))
                 return rc
             setattr(self.nv.lib, name, wrapper)
@@ -210,10 +212,13 @@ def pmc_traffic(kernel_key, bf16=False):
     if doc.get("source_hash") != source_hash():
         return None
     m = re.match(r"gemm_rows(8?)_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
+    md = re.match(r"gemm_rows_dma_kernel<(\d+), (\d+), (NN|NT)>", kernel_key)
     if kernel_key.startswith("gemm_sk_rows_kernel<"):
         name = "gemm_sk_rows_kernel<%s>" % ("true" if kernel_key.endswith("NT>") else "false")
     elif kernel_key == "gemm_sk_tn_kernel":
         name = "gemm_sk_tn_kernel"
+    elif md:
+        name = "gemm_rows_dma_kernel<%s, %s, %s>" % (md.group(1), md.group(2), "true" if md.group(3) == "NT" else "false")
     elif m:
         name = "gemm_rows%s_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), m.group(3), "true" if m.group(4) == "NT" else "false")
     elif kernel_key.startswith("gemm_tn_kernel<"):

@@ -181,6 +181,9 @@ int lidbox_gemm_plan_is_stream_k(int kind, long M, int N, int K, size_t workspac
  * instantiation lidbox_gemm_plan_query names, GEMM kernels of another instantiation (the remainder of a tail split is
  * planned on its own), reduce kernels}. */
 int lidbox_gemm_last_launches(int* out3);
+/* Kernel family of that same call: 0 = register-staged kernels (gemm_rows_kernel / gemm_tn_kernel), 1 = the same
+ * decomposition on the LDS-DMA operand path (gemm_rows_dma_kernel: 16-byte aligned operands), 2 = stream-K. */
+int lidbox_gemm_last_family(void);
 
 /* Split-K workspace (bytes) that lets lidbox_gemm_nn / _nt fill the chip when M*N is small
  * (Dense layers at M = batch): partial sums are reduced in a fixed order with the epilogue

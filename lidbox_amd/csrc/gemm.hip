@@ -38,6 +38,7 @@
 
 #include "gemm_shared.h"
 #include "gemm_sk.h"
+#include "gemm_dma.h"
 #include "gemm_tuned.h"
 
 namespace {
@@ -661,12 +662,13 @@ struct SkRows {
 // the old values at the end of a tile) sit on the critical path of the LAST contributor of a streamed tile -- the classic
 // kernels, eight small tiles per CU at different phases, hide both better.  LIDBOX_GEMM_SK_ALL=1 lifts the policy (tests,
 // A/B runs).
-inline bool sk_rows_policy(int kind, int K) {
-    if (const char* e = getenv("LIDBOX_GEMM_SK_ALL")) {
-        if (atoi(e) != 0) return true;
-    }
-    return kind == 0 && K >= 1024;
+inline bool sk_all() {
+    const char* e = getenv("LIDBOX_GEMM_SK_ALL");
+    return e && atoi(e) != 0;
 }
+inline bool sk_rows_policy(int kind, int K) { return sk_all() || (kind == 0 && K >= 1024); }
+// a measured classic decomposition of the shape (gemm_tuned.h, swept with the stream-K kernels as "model") wins over stream-K
+inline bool sk_tuned_out(int kind, long M, int N, int K) { return !sk_all() && tuned_gemm(kind, M, N, K) != nullptr; }
 
 // pipelined-epilogue variant (gemm_skp_rows_kernel): 0 off, 1 where the policy says, 2 every eligible launch (A/B aid).
 // MEASURED AND NOT ADOPTED (profiles/r03_gemm_skp_ab.txt, bs 256): correct through every schedule branch
@@ -793,6 +795,7 @@ struct RowsChoice {
 // {kernels of the instantiation plan_query names, GEMM kernels of another instantiation (a tail-split remainder planned
 // on its own), reduce kernels}
 thread_local int g_last_launches[3] = {0, 0, 0};
+thread_local int g_last_family = 0;       // 0 register-staged kernels of this file, 1 LDS-DMA (gemm_dma.h), 2 stream-K (gemm_sk.h)
 thread_local int g_first_tile[2] = {0, 0};
 
 // Cost model in "K-steps of a 128x128 tile at the full fp32 MFMA rate" (~1 us each per CU).
@@ -869,10 +872,24 @@ void launch_rows_t(bool al, dim3 grid, hipStream_t st, RowsD Ad, const float* Bm
                            m_end, K, N, epi, aux, tiles_n, ntiles, kps);
 }
 
+// The classic decompositions run on the LDS-DMA operand path (gemm_dma.h) wherever the operands allow (16-byte aligned, 32-bit
+// extents); LIDBOX_GEMM_DMA=0 keeps the register-staged kernels of this file (A/B aid, and what unaligned problems use).
+inline int dma_mode() {
+    if (const char* e = getenv("LIDBOX_GEMM_DMA")) return atoi(e);
+    return 1;
+}
+
+template <int BM, int BN, bool B_KINNER>
+void launch_rows_dma_t(dim3 grid, hipStream_t st, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, float* P, long m_beg, long m_end,
+                       int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps) {
+    hipLaunchKernelGGL((gemm_rows_dma_kernel<BM, BN, B_KINNER>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi,
+                       aux, tiles_n, ntiles, kps);
+}
+
 // one launch (+ its split-K reduce) over the row range [m_beg, m_end) with a given decomposition
 template <bool B_KINNER>
 int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, long m_beg,
-                      long m_end, int K, int N, int epi, const float* aux, float* P, hipStream_t st) {
+                      long m_end, int K, int N, int epi, const float* aux, float* P, hipStream_t st, bool dma_ok = false) {
     const long Msub = m_end - m_beg;
     if (Msub <= 0) return LIDBOX_OK;
     const int tiles_n = (int)lbx_cdiv(N, ch.bn);
@@ -883,6 +900,14 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
     if (ch.splits > 1) ++g_last_launches[2];
 #define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
 #define LBX_ROWS8(BM_, BN_) launch_rows8_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+#define LBX_ROWS_DMA(BM_, BN_) launch_rows_dma_t<BM_, BN_, B_KINNER>(grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+    if (dma_ok && al && dma_mode() != 0) {
+        g_last_family = 1;
+        if (ch.bm == 128 && ch.bn == 128) LBX_ROWS_DMA(128, 128);
+        else if (ch.bm == 128) LBX_ROWS_DMA(128, 64);
+        else if (ch.bn == 128) LBX_ROWS_DMA(64, 128);
+        else LBX_ROWS_DMA(64, 64);
+    } else
 #if LBX_GEMM_BK == 16
     if (ch.waves == 8 && ch.bm == 128 && ch.bn == 128) LBX_ROWS8(128, 128);
     else if (ch.waves == 8 && ch.bm == 128 && ch.bn == 64) LBX_ROWS8(128, 64);
@@ -912,6 +937,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
                 const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
     const long M = (long)A.batch * A.rows_per_batch;
     g_last_launches[0] = g_last_launches[1] = g_last_launches[2] = 0;
+    g_last_family = 0;
     if (M == 0 || N == 0) return LIDBOX_OK;
     const size_t wsb = ws ? ws_bytes : 0;
     RowsChoice ch = choose_rows(B_KINNER ? 1 : 0, M, N, K, wsb);
@@ -939,7 +965,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     float* P = (float*)ws;
 
     // persistent stream-K kernel (gemm_sk.h): aligned problems that fill the chip, workspace permitting
-    if (al && !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && aligned16(ws)) {
+    if (al && !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && aligned16(ws) && !sk_tuned_out(B_KINNER ? 1 : 0, M, N, K)) {
         // the pipelined variant: its in-loop epilogue addresses C rows with at most one utterance wrap per 32-row block
         // (its drain stages the mask / old values of C through LDS-DMA: 16-byte aligned C rows, whole 16-byte column chunks)
         const bool has_mask_ = epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK;
@@ -951,6 +977,8 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
             if (sk.ok && wsb >= sk.ws_need && sk_extent_ok(A, K)) {
                 sk_set_lds_attr();
                 g_last_launches[0] = 1;
+            g_last_family = 2;
+                g_last_family = 2;
                 g_first_tile[0] = SK_BM; g_first_tile[1] = SK_BN;
                 unsigned* counters = (unsigned*)ws;
                 float* slabs = (float*)((char*)ws + SK_COUNTER_BYTES);
@@ -974,6 +1002,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
         if (sk.ok && wsb >= sk.ws_need && sk_extent_ok(A, K)) {
             sk_set_lds_attr();
             g_last_launches[0] = 1;
+            g_last_family = 2;
             g_first_tile[0] = SK_BM; g_first_tile[1] = SK_BN;
             unsigned* counters = (unsigned*)ws;
             float* slabs = (float*)((char*)ws + SK_COUNTER_BYTES);
@@ -984,6 +1013,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
         }
     }
 
+    const bool dma_ok = al && sk_extent_ok(A, K) && (double)N * ldb * 4.0 < 4.0e9;
     // Tail quantisation: with W workgroups on 256 CUs the last partial round runs at the pace of a
     // full one (measured: the last 3 % of frame2's rows cost 21 % of its time).  When the main
     // decomposition is unsplit and leaves such a tail, launch it over the largest row prefix whose
@@ -1009,14 +1039,14 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
                                            (double)rem.k_per_split / BK);
                 if (rem.splits > 1) split += 5.0 + (double)m_rem * N * 4.0 * (rem.splits + 1) / 3.0e6;
                 if (split < 0.97 * whole) {
-                    int rc = launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, m_main, K, N, epi, aux, P, st);
+                    int rc = launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, m_main, K, N, epi, aux, P, st, dma_ok);
                     if (rc) return rc;
-                    return launch_rows_range<B_KINNER>(rem, al, Ad, Bm, ldb, Co, m_main, M, K, N, epi, aux, P, st);
+                    return launch_rows_range<B_KINNER>(rem, al, Ad, Bm, ldb, Co, m_main, M, K, N, epi, aux, P, st, dma_ok);
                 }
             }
         }
     }
-    return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st);
+    return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st, dma_ok);
 }
 
 struct TnPlan {
@@ -1090,11 +1120,11 @@ extern "C" int lidbox_gemm_plan_is_stream_k(int kind, long M, int N, int K, size
     if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 2) return 0;
     if (kind == 2) {
         const SkTn t = sk_tn_plan(M, K, N);
-        return t.ok && workspace_bytes >= t.ws_need;
+        return t.ok && workspace_bytes >= t.ws_need && !sk_tuned_out(2, M, N, K);
     }
     {
         const SkRows r = sk_rows_plan(kind, M, N, K);
-        return r.ok && workspace_bytes >= r.ws_need && (kind == 1 || N % 4 == 0);
+        return r.ok && workspace_bytes >= r.ws_need && (kind == 1 || N % 4 == 0) && !sk_tuned_out(kind, M, N, K);
     }
     return LIDBOX_OK;
 }
@@ -1103,6 +1133,8 @@ extern "C" int lidbox_gemm_plan_waves(int kind, long M, int N, int K, size_t wor
     if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 1) return 4;
     return choose_rows(kind, M, N, K, workspace_bytes).waves;
 }
+
+extern "C" int lidbox_gemm_last_family(void) { return g_last_family; }
 
 extern "C" int lidbox_gemm_last_launches(int* out3) {
     LBX_ARG(out3, "out3 != NULL");
@@ -1172,10 +1204,12 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     {
         // persistent-body kernel (gemm_sk.h) over a regular split of the contraction rows
         const SkTn sk = sk_tn_plan(M, K1, N);
-        if (sk.ok && !getenv("LIDBOX_GEMM_TN_PLAN") && workspace && aligned16(workspace) && workspace_bytes >= sk.ws_need &&
+        if (sk.ok && !getenv("LIDBOX_GEMM_TN_PLAN") && !sk_tuned_out(2, M, N, K1) && workspace && aligned16(workspace) && workspace_bytes >= sk.ws_need &&
             rows_aligned(A) && rows_aligned(Bd) && sk_extent_ok(A, K1) && sk_extent_ok(Bd, N)) {
             sk_set_lds_attr();
             g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1;
+    g_last_family = 0;
+            g_last_family = 2;
             float* P = (float*)workspace;
             float* Pc = bias_grad ? P + (size_t)sk.splits * K1 * N : nullptr;
             hipLaunchKernelGGL(gemm_sk_tn_kernel, dim3((unsigned)(sk.ntiles * sk.splits)), dim3(256), SK_LDS_BYTES, st, to_dev(A),
@@ -1190,6 +1224,7 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
     LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_tn_workspace)");
     g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1;
+    g_last_family = 0;
     const int tiles_n = (int)lbx_cdiv(N, pl.bn);
     const int ntiles = (int)(lbx_cdiv(K1, pl.bm) * tiles_n);
     const bool al = rows_aligned(A) && rows_aligned(Bd) && K1 % 4 == 0 && N % 4 == 0;

@@ -1,0 +1,237 @@
+// gemm_dma.h -- the classic decomposition (one tile per workgroup, grid = tiles x K splits, many small workgroups per CU at
+// different phases: gemm.hip) on the operand path of gemm_sk.h: LDS-DMA ring in the saddr form, K-inner operands XOR-swizzled
+// on the source side and read with ds_read_b128, K-outer operands read with ds_read_b32.  Tiles 64 x 64, 128 x 64, 64 x 128,
+// 128 x 128 (four waves 2 x 2, MI x NJ blocks of 32 x 32 per wave).  Same contracts / epilogues as gemm_rows_kernel
+// (reference xvector.py:38-43,53-64, cnn.py:32-41); 16-byte aligned operands only.
+#pragma once
+
+#include "gemm_sk.h"
+
+namespace {
+
+#ifndef LBX_DMA_STAGES
+#define LBX_DMA_STAGES 3
+#endif
+constexpr int DMA_STAGES = LBX_DMA_STAGES;
+
+// K-inner operand, ROWS = 64 or 128 rows x 16 k per step; a wave issues ROWS / 64 pieces of 16 rows (four lanes per row)
+template <int ROWS>
+struct DmaInner {
+    static constexpr int PW = ROWS / 64;          // pieces per wave per step
+    const float* sb;
+    unsigned vo[PW];
+    int rd;
+    __device__ __forceinline__ void init(const float* base, const long (&roff)[PW], int k0, int lane, int wsub) {
+        sb = sk_uniform(base + k0);
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) vo[i] = (unsigned)((roff[i] + chunk * 4) * 4);
+        rd = (wsub * (ROWS / 2) + (lane & 31)) * 16;
+    }
+    __device__ __forceinline__ void issue(int i, unsigned dst) const { sk_dma_s(sb, vo[i], dst); }
+    __device__ __forceinline__ void issue_tail(int i, unsigned dst, int kvalid, int lane) const {
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
+        sk_dma_f(chunk * 4 < kvalid ? p : g_sk_zero, dst);
+    }
+    __device__ __forceinline__ void advance() { sb += SK_BK; }
+    template <int NB>
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[NB][4]) const {
+        const int slot = (2 * s2 + (lane >> 5)) ^ ((lane >> 2) & 3);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f32x4_t x = *reinterpret_cast<const f32x4_t*>(st + rd + b * 32 * 16 + slot * 4);
+            v[b][0] = x[0]; v[b][1] = x[1]; v[b][2] = x[2]; v[b][3] = x[3];
+        }
+    }
+};
+
+// K-outer operand of a plain matrix X[k][ld], 16 k x COLS columns per step; LDS image [k][COLS]; a piece = 1 KB =
+// 1024 / (4 COLS) k rows
+template <int COLS>
+struct DmaOuter {
+    static constexpr int PW = COLS / 64;
+    static constexpr int LPR = COLS / 4;          // lanes per k row
+    static constexpr int RPP = 64 / LPR;          // k rows per piece: 4 (64 columns) or 2 (128)
+    const float* sb;
+    unsigned vo[PW];
+    long step;
+    int rd;
+    __device__ __forceinline__ void init(const float* base, long ld, int col0, int ncols, int k0, int lane, int wv, int wsub) {
+        sb = sk_uniform(base + (long)k0 * ld + col0);
+        int c = (lane % LPR) * 4;
+        if (col0 + c >= ncols) c = 0;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) vo[i] = (unsigned)(((long)(RPP * (wv * PW + i) + lane / LPR) * ld + c) * 4);
+        step = (long)SK_BK * ld;
+        rd = (4 * (lane >> 5)) * COLS + wsub * (COLS / 2) + (lane & 31);
+    }
+    __device__ __forceinline__ void issue(int i, unsigned dst) const { sk_dma_s(sb, vo[i], dst); }
+    __device__ __forceinline__ void issue_tail(int i, unsigned dst, int kvalid, int lane, int wv) const {
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
+        sk_dma_f(RPP * (wv * PW + i) + lane / LPR < kvalid ? p : g_sk_zero, dst);
+    }
+    __device__ __forceinline__ void advance() { sb += step; }
+    template <int NB>
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[NB][4]) const {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b][j] = st[rd + (8 * s2 + j) * COLS + b * 32];
+    }
+};
+
+template <int MI, int NJ, int J0, int J1>
+__device__ __forceinline__ void dma_mma(const float (&a)[MI][4], const float (&b)[NJ][4], f32x16 (&acc)[MI][NJ]) {
+#pragma unroll
+    for (int j = J0; j < J1; ++j)
+#pragma unroll
+        for (int bi = 0; bi < MI; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < NJ; ++bj)
+                acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bi][j], b[bj][j], acc[bi][bj], 0, 0, 0);
+}
+
+// C[M,N] = epi(A[M,K] . B), grid.x = tiles (XCD-chunk remapped), grid.y = K splits (partials to P, rows_reduce_kernel finishes)
+template <int BM, int BN, bool B_KINNER>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_rows_dma_kernel(
+    RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
+    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split) {
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    constexpr int A_ST = BM * SK_BK, B_ST = SK_BK * BN, ST = A_ST + B_ST;
+    constexpr int PA = BM / 64, PB = BN / 64;                // DMA pieces per wave per step
+    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * ST];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const int tn = chunk % tiles_n;
+    const long m0 = m_beg + (long)(chunk / tiles_n) * BM;
+    const int n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int n = (kend - kbeg + SK_BK - 1) / SK_BK;
+    const int ktail = kend - kbeg - (n - 1) * SK_BK;          // valid k of the last step (4 .. 16)
+
+    DmaInner<BM> oa;
+    {
+        long roff[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            long r = m0 + 16 * (wv * PA + i) + (lane >> 2);
+            if (r >= M) r = m0;
+            roff[i] = row_offset(A, (unsigned)r);
+        }
+        oa.init(A.base, roff, kbeg, lane, wm);
+    }
+    DmaInner<BN> obi;
+    DmaOuter<BN> obo;
+    if (B_KINNER) {
+        long roff[PB];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            long r = n0 + 16 * (wv * PB + i) + (lane >> 2);
+            if (r >= N) r = n0;
+            roff[i] = r * ldb;
+        }
+        obi.init(Bm, roff, kbeg, lane, wn);
+    } else {
+        obo.init(Bm, ldb, n0, N, kbeg, lane, wv, wn);
+    }
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // piece pc of this wave for step `step` into stage `stage`: pieces 0 .. PA-1 of A, then PB of B
+    auto issue = [&](int pc, int step, int stage) {
+        const bool tail = step == n - 1 && ktail < SK_BK;
+        if (pc < PA) {
+            const unsigned d = lds0 + (unsigned)((stage * ST + (wv * PA + pc) * 256) * 4);
+            if (tail) oa.issue_tail(pc, d, ktail, lane);
+            else oa.issue(pc, d);
+        } else {
+            const int q = pc - PA;
+            const unsigned d = lds0 + (unsigned)((stage * ST + A_ST + (wv * PB + q) * 256) * 4);
+            if (B_KINNER) { if (tail) obi.issue_tail(q, d, ktail, lane); else obi.issue(q, d); }
+            else { if (tail) obo.issue_tail(q, d, ktail, lane, wv); else obo.issue(q, d); }
+        }
+    };
+    auto next = [&]() {
+        oa.advance();
+        if (B_KINNER) obi.advance();
+        else obo.advance();
+    };
+    auto ra = [&](const float* st, int s2, float (&v)[MI][4]) { oa.template read<MI>(st, lane, s2, v); };
+    auto rb = [&](const float* st, int s2, float (&v)[NJ][4]) {
+        if (B_KINNER) obi.template read<NJ>(st, lane, s2, v);
+        else obo.template read<NJ>(st, lane, s2, v);
+    };
+    constexpr int NP = PA + PB;                               // 2 .. 4 pieces per wave per step
+#pragma unroll
+    for (int s = 0; s < DMA_STAGES - 1; ++s)
+        if (s < n) {
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) issue(pc, s, s);
+            next();
+        }
+    if (n >= DMA_STAGES - 1) sk_wait_vm<(DMA_STAGES - 2) * NP>();
+    else sk_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    float a0[MI][4], b0[NJ][4], a1[MI][4], b1[NJ][4];
+    if (n > 0) {
+        ra(smem, 0, a0);
+        rb(smem + A_ST, 0, b0);
+    }
+    int cur = 0;
+    for (int t = 0; t < n; ++t) {
+        if (t + 1 < n) {
+            if (DMA_STAGES >= 4 && t + DMA_STAGES - 2 < n) sk_wait_vm<(DMA_STAGES >= 4 ? (DMA_STAGES - 3) * NP : 0)>();
+            else sk_wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        int nxt = cur + 1;
+        if (nxt == DMA_STAGES) nxt = 0;
+        const bool more = t + DMA_STAGES - 1 < n;
+        int tgt = cur + DMA_STAGES - 1;
+        if (tgt >= DMA_STAGES) tgt -= DMA_STAGES;
+        const float* st = smem + cur * ST;
+        dma_mma<MI, NJ, 0, 1>(a0, b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        ra(st, 1, a1);
+        rb(st + A_ST, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 1, 2>(a0, b0, acc);
+        if (more) issue(0, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 2, 3>(a0, b0, acc);
+        if (more) issue(1, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 3, 4>(a0, b0, acc);
+        if (more && NP > 2) issue(2, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 0, 1>(a1, b1, acc);
+        if (more) {
+            if (NP > 3) issue(3, t + DMA_STAGES - 1, tgt);
+            next();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < n) {
+            const float* sn = smem + nxt * ST;
+            ra(sn, 0, a0);
+            rb(sn + A_ST, 0, b0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 1, 4>(a1, b1, acc);
+        cur = nxt;
+    }
+    store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split);
+}
+
+}  // namespace

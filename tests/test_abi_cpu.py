@@ -291,13 +291,18 @@ def test_gemm_plans_tuned_table_and_model(nv):
 
 def test_stream_k_dispatch_policy_is_host_logic(nv, monkeypatch):
     """which launches go to the persistent stream-K kernels (csrc/gemm_sk.h): forward GEMMs with K >= 1024 and wgrads, above
-    a size floor, workspace permitting; LIDBOX_GEMM_SK=0 / LIDBOX_GEMM_SK_ALL=1 move the policy (A/B and test aids)"""
+    a size floor, workspace permitting, unless the measured table (csrc/gemm_tuned.h) holds a faster classic decomposition
+    for the shape; LIDBOX_GEMM_SK=0 / LIDBOX_GEMM_SK_ALL=1 move the policy (A/B and test aids)"""
     q = nv.lib.lidbox_gemm_plan_is_stream_k
     big = 1 << 30
     for var in ("LIDBOX_GEMM_SK", "LIDBOX_GEMM_SK_ALL", "LIDBOX_GEMM_SK_GRID", "LIDBOX_GEMM_SK_MIN_FLOP"):
         monkeypatch.delenv(var, raising=False)
-    # x-vector layers at bs 256 (SURVEY 8a): frame2 / frame3 forward (K = 1536) yes, K = 512 / 200 forward no, dgrad no
-    assert q(0, 25344, 512, 1536, big) == 1 and q(0, 8448, 512, 1536, big) == 1
+    # x-vector layers at bs 256 (SURVEY 8a): frame2 forward (K = 1536) yes, frame3 forward no (4.125 tiles per CU: the table
+    # lists 64 x 64 tiles for it), K = 512 / 200 forward no, dgrad no
+    assert q(0, 25344, 512, 1536, big) == 1 and q(0, 8448, 512, 1536, big) == 0
+    monkeypatch.setenv("LIDBOX_GEMM_NO_TUNED", "1")
+    assert q(0, 8448, 512, 1536, big) == 1
+    monkeypatch.delenv("LIDBOX_GEMM_NO_TUNED")
     assert q(0, 8448, 1500, 512, big) == 0 and q(0, 50688, 512, 200, big) == 0
     assert q(1, 8448, 512, 1500, big) == 0 and q(1, 25344, 1024, 512, big) == 0
     # wgrads (kind 2: K = K1) above 6 GFLOP yes, frame4's 4.4 GFLOP and the dense head no
