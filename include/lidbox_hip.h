@@ -184,6 +184,10 @@ int lidbox_gemm_last_launches(int* out3);
 /* Kernel family of that same call: 0 = register-staged kernels (gemm_rows_kernel / gemm_tn_kernel), 1 = the same
  * decomposition on the LDS-DMA operand path (gemm_rows_dma_kernel: 16-byte aligned operands), 2 = stream-K. */
 int lidbox_gemm_last_family(void);
+/* Pieces per tile (2 .. 8) when lidbox_gemm_nn / _nt (kind 0 / 1) would stream the last partial round of tiles of this
+ * shape along K inside the one launch (LDS-DMA family, 16-byte aligned operands, a workspace of workspace_bytes: 16 KiB of
+ * arrival counters + one tile-sized slab per piece, no initialisation needed); 0 when every tile runs whole. */
+int lidbox_gemm_plan_stream_tail(int kind, long M, int N, int K, size_t workspace_bytes);
 
 /* Split-K workspace (bytes) that lets lidbox_gemm_nn / _nt fill the chip when M*N is small
  * (Dense layers at M = batch): partial sums are reduced in a fixed order with the epilogue

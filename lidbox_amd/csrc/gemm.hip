@@ -803,9 +803,10 @@ thread_local int g_first_tile[2] = {0, 0};
 // tiles' MFMA time; co-resident workgroups hide each other's barrier / staging stalls, a lone
 // workgroup cannot (measured: 1 WG/CU keeps the pipe ~50 % busy, 3+ WG/CU ~90 %).
 const int CAND[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-const double TILE_EFF[4] = {1.0, 0.95, 0.95, 0.88};      // staging traffic per flop grows as tiles shrink
-const int RESIDENT[4] = {BK == 16 ? 3 : 2, BK == 16 ? 6 : 3, BK == 16 ? 6 : 3, BK == 16 ? 8 : 4};   // workgroups per CU (VGPR / LDS limited)
-constexpr double FIXED_STEPS = 3.0;                      // prologue + epilogue of one tile, in K-steps
+// steady state of the LDS-DMA kernels (gemm_dma.h; profiles/r03_dma_staircase.txt): 137 / 134 / 133 / 131 TFLOP/s
+const double TILE_EFF[4] = {1.0, 0.98, 0.97, 0.955};
+const int RESIDENT[4] = {BK == 16 ? 3 : 2, BK == 16 ? 4 : 3, BK == 16 ? 4 : 3, BK == 16 ? 6 : 4};   // workgroups per CU (VGPR / LDS limited)
+const double FIXED_STEPS[4] = {6.0, 5.0, 5.0, 3.0};       // prologue + epilogue of one tile, in K-steps (fewer residents hide less of it)
 
 inline double conc_eff(double w) {
     if (w <= 1.0) return 0.55;
@@ -816,8 +817,14 @@ inline double conc_eff(double w) {
 
 inline double launch_cost(int c, long wgs, double ksteps) {
     const int bm = CAND[c][0], bn = CAND[c][1];
-    const double tile_t = (bm * bn / 16384.0) * (ksteps + FIXED_STEPS) / TILE_EFF[c];
-    const double per_cu = (double)lbx_cdiv(wgs, NUM_CU);
+    const double tile_t = (bm * bn / 16384.0) * (ksteps + FIXED_STEPS[c]) / TILE_EFF[c];
+    // one tile per workgroup costs ceil(tiles / CUs) tile times; past one whole round the remainder is streamed along K
+    // (DmaStream) and costs about its share
+    double per_cu = (double)lbx_cdiv(wgs, NUM_CU);
+    if (wgs > NUM_CU && wgs % NUM_CU != 0) {
+        const double fluid = (double)wgs / NUM_CU + 0.12;
+        if (fluid < per_cu) per_cu = fluid;
+    }
     const double conc = per_cu < RESIDENT[c] ? (double)wgs / NUM_CU : (double)RESIDENT[c];
     return per_cu * tile_t / conc_eff(conc < 1.0 ? 1.0 : conc);
 }
@@ -848,6 +855,28 @@ RowsChoice choose_rows(int kind, long M, int N, int K, size_t ws_bytes) {
         }
     }
     return best;
+}
+
+// the decomposition a launch uses: the planner's, or the tuning overrides LIDBOX_GEMM_PLAN / LIDBOX_GEMM_TILE
+RowsChoice choose_rows_env(int kind, long M, int N, int K, size_t wsb) {
+    RowsChoice ch = choose_rows(kind, M, N, K, wsb);
+    if (const char* f = getenv("LIDBOX_GEMM_PLAN")) {             // tuning aid (tools/gemm_sweep.py): "bm,bn,splits"
+        int bm = 0, bn = 0, sp = 0, wv = 4;
+        if (sscanf(f, "%d,%d,%d,%d", &bm, &bn, &sp, &wv) >= 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
+            !(BK > 16 && bm == 128 && bn == 128)) {
+            const int kps = (int)(lbx_cdiv(lbx_cdiv(K, sp), BK) * BK);
+            const int splits = (int)lbx_cdiv(K, kps);
+            if (splits == 1 || (size_t)splits * M * N * sizeof(float) <= wsb)
+                ch = RowsChoice{bm, bn, splits, kps, false, (wv == 8 && bm == 128 && BK == 16) ? 8 : 4};
+        }
+    } else if (const char* f = getenv("LIDBOX_GEMM_TILE")) {      // tuning aid: "128x128" etc.
+        int bm = 0, bn = 0;
+        if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
+            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K; ch.no_tail_split = false;
+            if (BK > 16 && bm == 128 && bn == 128) ch.bn = 64;
+        }
+    }
+    return ch;
 }
 
 template <int BM, int BN, bool B_KINNER>
@@ -881,15 +910,50 @@ inline int dma_mode() {
 
 template <int BM, int BN, bool B_KINNER>
 void launch_rows_dma_t(dim3 grid, hipStream_t st, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, float* P, long m_beg, long m_end,
-                       int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps) {
+                       int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps, const DmaStream& sp) {
     hipLaunchKernelGGL((gemm_rows_dma_kernel<BM, BN, B_KINNER>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi,
-                       aux, tiles_n, ntiles, kps);
+                       aux, tiles_n, ntiles, kps, sp);
+}
+
+// Streamed remainder of an unsplit decomposition (gemm_dma.h: DmaStream): g pieces per tile of the last partial round,
+// chosen for the fewest rounds of pieces (in tile times), pieces of at least DMA_STREAM_MIN_STEPS K steps.
+// LIDBOX_GEMM_STREAM_TAIL=0 switches it off (A/B aid), =g forces g pieces.
+constexpr int DMA_STREAM_MIN_STEPS = 8;
+constexpr int DMA_STREAM_MAX_G = 8;
+struct DmaStreamPlan {
+    int g = 0;                  // 0: no streamed remainder
+    long whole = 0, rem = 0;    // whole tiles, streamed tiles
+    size_t ws_need = 0;
+};
+inline DmaStreamPlan dma_stream_plan(int bm, int bn, long M, int N, int K) {
+    DmaStreamPlan pl;
+    int force = -1;
+    if (const char* e = getenv("LIDBOX_GEMM_STREAM_TAIL")) force = atoi(e);
+    if (force == 0) return pl;
+    const long tiles = lbx_cdiv(M, bm) * lbx_cdiv(N, bn);
+    const long rem = tiles % NUM_CU;
+    if (tiles < NUM_CU || rem == 0) return pl;
+    const int nk = (int)lbx_cdiv(K, SK_BK);
+    int best = 1;
+    double best_cost = 1.0;                                   // unstreamed: the remainder costs one tile time
+    for (int g = 2; g <= DMA_STREAM_MAX_G && nk / g >= DMA_STREAM_MIN_STEPS; ++g) {
+        // rounds of pieces, each 1 / g of a tile time, plus the hand-off (slab write, the last arriver reads g slabs)
+        const double cost = (double)lbx_cdiv(rem * g, (long)NUM_CU) / g + 0.03 + 0.01 * g;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = g; }
+    }
+    if (force > 1 && nk / force >= 2 && force <= 64) best = force;
+    else if (best_cost > 0.9) return pl;
+    if (best < 2) return pl;
+    pl.g = best; pl.rem = rem; pl.whole = tiles - rem;
+    pl.ws_need = SK_COUNTER_BYTES + (size_t)rem * best * bm * bn * sizeof(float);
+    return pl;
 }
 
 // one launch (+ its split-K reduce) over the row range [m_beg, m_end) with a given decomposition
 template <bool B_KINNER>
 int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, long m_beg,
-                      long m_end, int K, int N, int epi, const float* aux, float* P, hipStream_t st, bool dma_ok = false) {
+                      long m_end, int K, int N, int epi, const float* aux, float* P, hipStream_t st, bool dma_ok = false,
+                      const DmaStreamPlan* stream = nullptr, void* ws = nullptr) {
     const long Msub = m_end - m_beg;
     if (Msub <= 0) return LIDBOX_OK;
     const int tiles_n = (int)lbx_cdiv(N, ch.bn);
@@ -900,9 +964,22 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
     if (ch.splits > 1) ++g_last_launches[2];
 #define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
 #define LBX_ROWS8(BM_, BN_) launch_rows8_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
-#define LBX_ROWS_DMA(BM_, BN_) launch_rows_dma_t<BM_, BN_, B_KINNER>(grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
+#define LBX_ROWS_DMA(BM_, BN_) launch_rows_dma_t<BM_, BN_, B_KINNER>(grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, ntiles_k, ch.k_per_split, sp)
     if (dma_ok && al && dma_mode() != 0) {
         g_last_family = 1;
+        DmaStream sp;
+        unsigned ntiles_k = (unsigned)ntiles;
+        if (stream && stream->g > 1 && ch.splits == 1) {
+            sp.pieces = (unsigned)(stream->rem * stream->g);
+            sp.npad = (sp.pieces + 7u) & ~7u;
+            sp.g = stream->g;
+            sp.first_tile = (unsigned)stream->whole;
+            sp.epoch = sk_next_epoch();
+            sp.counters = (unsigned*)ws;
+            sp.slabs = (float*)((char*)ws + SK_COUNTER_BYTES);
+            ntiles_k = (unsigned)stream->whole;
+            grid.x = sp.npad + ntiles_k;
+        }
         if (ch.bm == 128 && ch.bn == 128) LBX_ROWS_DMA(128, 128);
         else if (ch.bm == 128) LBX_ROWS_DMA(128, 64);
         else if (ch.bn == 128) LBX_ROWS_DMA(64, 128);
@@ -940,23 +1017,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     g_last_family = 0;
     if (M == 0 || N == 0) return LIDBOX_OK;
     const size_t wsb = ws ? ws_bytes : 0;
-    RowsChoice ch = choose_rows(B_KINNER ? 1 : 0, M, N, K, wsb);
-    if (const char* f = getenv("LIDBOX_GEMM_PLAN")) {             // tuning aid (tools/gemm_sweep.py): "bm,bn,splits"
-        int bm = 0, bn = 0, sp = 0, wv = 4;
-        if (sscanf(f, "%d,%d,%d,%d", &bm, &bn, &sp, &wv) >= 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
-            !(BK > 16 && bm == 128 && bn == 128)) {
-            const int kps = (int)(lbx_cdiv(lbx_cdiv(K, sp), BK) * BK);
-            const int splits = (int)lbx_cdiv(K, kps);
-            if (splits == 1 || (size_t)splits * M * N * sizeof(float) <= wsb)
-                ch = RowsChoice{bm, bn, splits, kps, false, (wv == 8 && bm == 128 && BK == 16) ? 8 : 4};
-        }
-    } else if (const char* f = getenv("LIDBOX_GEMM_TILE")) {      // tuning aid: "128x128" etc.
-        int bm = 0, bn = 0;
-        if (sscanf(f, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) {
-            ch.bm = bm; ch.bn = bn; ch.splits = 1; ch.k_per_split = K; ch.no_tail_split = false;
-            if (BK > 16 && bm == 128 && bn == 128) ch.bn = 64;
-        }
-    }
+    const RowsChoice ch = choose_rows_env(B_KINNER ? 1 : 0, M, N, K, wsb);
     // float4 paths: A rows and K multiple of 4; B: NN needs N%4 (columns), NT needs K%4 (rows)
     const bool al = rows_aligned(A) && K % 4 == 0 && aligned16(Bm) && ldb % 4 == 0 &&
                     (B_KINNER ? true : N % 4 == 0);
@@ -977,7 +1038,6 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
             if (sk.ok && wsb >= sk.ws_need && sk_extent_ok(A, K)) {
                 sk_set_lds_attr();
                 g_last_launches[0] = 1;
-            g_last_family = 2;
                 g_last_family = 2;
                 g_first_tile[0] = SK_BM; g_first_tile[1] = SK_BN;
                 unsigned* counters = (unsigned*)ws;
@@ -1019,6 +1079,11 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     // decomposition is unsplit and leaves such a tail, launch it over the largest row prefix whose
     // workgroup count is a whole number of rounds, and hand the few remaining rows to a second
     // launch planned on its own (small tiles, split along K) -- if the cost model agrees.
+    if (dma_ok && dma_mode() != 0 && ch.splits == 1 && aligned16(ws)) {
+        const DmaStreamPlan spl = dma_stream_plan(ch.bm, ch.bn, M, N, K);
+        if (spl.g > 1 && wsb >= spl.ws_need)
+            return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st, dma_ok, &spl, ws);
+    }
     const bool no_tail_split = ch.no_tail_split || getenv("LIDBOX_GEMM_NO_TAIL_SPLIT") != nullptr;
     if (!no_tail_split && ch.splits == 1) {
         const int tiles_n = (int)lbx_cdiv(N, ch.bn);
@@ -1110,7 +1175,7 @@ extern "C" int lidbox_gemm_plan_query(int kind, long M, int N, int K, size_t wor
         const TnPlan pl = tn_plan(M, K, N);
         out4[0] = pl.bm; out4[1] = pl.bn; out4[2] = pl.splits; out4[3] = (int)pl.rows_per_split;
     } else {
-        const RowsChoice ch = choose_rows(kind, M, N, K, workspace_bytes);
+        const RowsChoice ch = choose_rows_env(kind, M, N, K, workspace_bytes);
         out4[0] = ch.bm; out4[1] = ch.bn; out4[2] = ch.splits; out4[3] = ch.k_per_split;
     }
     return LIDBOX_OK;
@@ -1131,10 +1196,19 @@ extern "C" int lidbox_gemm_plan_is_stream_k(int kind, long M, int N, int K, size
 
 extern "C" int lidbox_gemm_plan_waves(int kind, long M, int N, int K, size_t workspace_bytes) {
     if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 1) return 4;
-    return choose_rows(kind, M, N, K, workspace_bytes).waves;
+    return choose_rows_env(kind, M, N, K, workspace_bytes).waves;
 }
 
 extern "C" int lidbox_gemm_last_family(void) { return g_last_family; }
+
+extern "C" int lidbox_gemm_plan_stream_tail(int kind, long M, int N, int K, size_t workspace_bytes) {
+    if (M <= 0 || N <= 0 || K <= 0 || kind < 0 || kind > 1 || dma_mode() == 0) return 0;
+    if (!getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && lidbox_gemm_plan_is_stream_k(kind, M, N, K, workspace_bytes)) return 0;
+    const RowsChoice ch = choose_rows_env(kind, M, N, K, workspace_bytes);
+    if (ch.splits != 1) return 0;
+    const DmaStreamPlan spl = dma_stream_plan(ch.bm, ch.bn, M, N, K);
+    return (spl.g > 1 && workspace_bytes >= spl.ws_need) ? spl.g : 0;
+}
 
 extern "C" int lidbox_gemm_last_launches(int* out3) {
     LBX_ARG(out3, "out3 != NULL");
@@ -1150,6 +1224,11 @@ extern "C" size_t lidbox_gemm_rows_workspace(long M, int N, int K) {
         const RowsChoice ch = choose_rows(kind, M, N, K, (size_t)64 << 20);
         if (ch.splits > 1 && (size_t)ch.splits * M * N * sizeof(float) > need) need = (size_t)ch.splits * M * N * sizeof(float);
     }
+    for (int bm = 64; bm <= 128; bm += 64)               // streamed remainder of any tile shape the planner may pick
+        for (int bn = 64; bn <= 128; bn += 64) {
+            const DmaStreamPlan spl = dma_stream_plan(bm, bn, M, N, K);
+            if (spl.g > 1 && spl.ws_need > need) need = spl.ws_need;
+        }
     for (int kind = 0; kind < 2; ++kind) {
         const SkRows sk = sk_rows_plan(kind, M, N, K);
         if (sk.ok && sk.ws_need > need) need = sk.ws_need;

@@ -92,11 +92,62 @@ __device__ __forceinline__ void dma_mma(const float (&a)[MI][4], const float (&b
                 acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[bi][j], b[bj][j], acc[bi][bj], 0, 0, 0);
 }
 
-// C[M,N] = epi(A[M,K] . B), grid.x = tiles (XCD-chunk remapped), grid.y = K splits (partials to P, rows_reduce_kernel finishes)
+// Streamed remainder (stream-K for the last partial round only).  One tile per workgroup costs ceil(tiles / 256) tile
+// times: the CU that got one tile more than the others finishes alone (measured staircase, profiles/r03_dma_staircase.txt:
+// 64 x 64 x 1536 tiles, 4 per CU 107 us, 4.125 per CU 124 us, 5 per CU 124 us).  The R = tiles % 256 tiles of the last
+// partial round are therefore cut along K into g pieces each; the R * g pieces take the FIRST blockIdx values (they start
+// with the first wave of whole tiles, and their hand-off is over long before the launch ends), each piece leaves its
+// partial sums in a slab of the workspace (accumulator order, write-through: gemm_sk.h) and takes a ticket on the tile's
+// arrival counter; the last arriver sums the g slabs in k order -- a fixed order whoever it is -- and runs the epilogue.
+struct DmaStream {
+    unsigned npad = 0;          // blockIdx.x < npad: piece workgroups (pieces rounded up to a multiple of 8: keeps block % 8 = XCD
+                                // for the whole tiles behind them); the padding blocks exit
+    unsigned pieces = 0;        // R * g
+    int g = 1;
+    unsigned first_tile = 0;    // chunk index of the first streamed tile (= number of whole tiles)
+    unsigned epoch = 0;
+    unsigned* counters = nullptr;
+    float* slabs = nullptr;     // [pieces][BM * BN]
+};
+
+template <int MI, int NJ>
+__device__ __forceinline__ void dma_slab_store(float* slab, const f32x16 (&acc)[MI][NJ], int wv, int lane) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sk_uniform(slab)), 0, MI * NJ * 4096 * 4, 0x00020000);
+#pragma unroll
+    for (int bi = 0; bi < MI; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NJ; ++bj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4_t x = {acc[bi][bj][4 * r4], acc[bi][bj][4 * r4 + 1], acc[bi][bj][4 * r4 + 2], acc[bi][bj][4 * r4 + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), r,
+                                                       ((((wv * (MI * NJ) + bi * NJ + bj) * 4 + r4) * 64 + lane) * 4) * 4, 0, /*sc1*/ 16);
+            }
+}
+template <int MI, int NJ>
+__device__ __forceinline__ void dma_slab_add(const float* slab, f32x16 (&acc)[MI][NJ], int wv, int lane) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sk_uniform(slab)), 0, MI * NJ * 4096 * 4, 0x00020000);
+#pragma unroll
+    for (int bi = 0; bi < MI; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NJ; ++bj) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4_t x = __builtin_bit_cast(
+                    f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, ((((wv * (MI * NJ) + bi * NJ + bj) * 4 + r4) * 64 + lane) * 4) * 4, 0, /*sc1*/ 16));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[bi][bj][4 * r4 + j] += x[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// C[M,N] = epi(A[M,K] . B), grid.x = [streamed pieces] + whole tiles (XCD-chunk remapped), grid.y = K splits (partials to P,
+// rows_reduce_kernel finishes; never together with streamed pieces)
 template <int BM, int BN, bool B_KINNER>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_rows_dma_kernel(
     RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
-    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split) {
+    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split, DmaStream sp) {
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int A_ST = BM * SK_BK, B_ST = SK_BK * BN, ST = A_ST + B_ST;
     constexpr int PA = BM / 64, PB = BN / 64;                // DMA pieces per wave per step
@@ -106,13 +157,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
-    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const int split = blockIdx.y;
+    unsigned chunk;
+    int kbeg, kend, part = -1;
+    unsigned rem_t = 0;
+    if (blockIdx.x < sp.npad) {                               // wave-uniform: a piece of a streamed tile
+        if (blockIdx.x >= sp.pieces) return;
+        rem_t = blockIdx.x / (unsigned)sp.g;
+        part = (int)(blockIdx.x - rem_t * (unsigned)sp.g);
+        chunk = sp.first_tile + rem_t;
+        const int nk = (K + SK_BK - 1) / SK_BK;
+        kbeg = (part * nk / sp.g) * SK_BK;
+        kend = min(K, ((part + 1) * nk / sp.g) * SK_BK);
+    } else {
+        chunk = xcd_chunk_id(blockIdx.x - sp.npad, ntiles);
+        kbeg = split * k_per_split;
+        kend = min(K, kbeg + k_per_split);
+    }
     const int tn = chunk % tiles_n;
     const long m0 = m_beg + (long)(chunk / tiles_n) * BM;
     const int n0 = tn * BN;
-    const int split = blockIdx.y;
-    const int kbeg = split * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
     const int n = (kend - kbeg + SK_BK - 1) / SK_BK;
     const int ktail = kend - kbeg - (n - 1) * SK_BK;          // valid k of the last step (4 .. 16)
 
@@ -230,6 +294,36 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
         __builtin_amdgcn_sched_barrier(0);
         dma_mma<MI, NJ, 1, 4>(a1, b1, acc);
         cur = nxt;
+    }
+    if (part >= 0) {
+        constexpr int SLAB = BM * BN;
+        dma_slab_store<MI, NJ>(sp.slabs + (size_t)blockIdx.x * SLAB, acc, wv, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // every wave's slab rows are out, and nobody reads the ring any more
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) {
+            // arrival counter = (launch epoch << 8) | arrivals; a word of another epoch counts as zero (gemm_sk.h)
+            unsigned old = __hip_atomic_load(sp.counters + rem_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned cnt;
+            for (;;) {
+                cnt = (old >> 8) == sp.epoch ? (old & 255u) : 0u;
+                if (__hip_atomic_compare_exchange_strong(sp.counters + rem_t, &old, (sp.epoch << 8) | (cnt + 1u), __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    break;
+            }
+            *flag = cnt;
+        }
+        __syncthreads();
+        if (*flag != (unsigned)(sp.g - 1)) return;            // not the last arriver
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int q = 0; q < sp.g; ++q)                        // k order: the same sum whoever arrives last
+            dma_slab_add<MI, NJ>(sp.slabs + ((size_t)rem_t * sp.g + q) * SLAB, acc, wv, lane);
+        if (tid == 0) __hip_atomic_store(sp.counters + rem_t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split);
 }

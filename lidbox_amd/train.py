@@ -186,6 +186,8 @@ class Trainer:
         # it (SequentialTDNN.fused_output_ok); LIDBOX_NO_FUSED_OUTPUT=1 keeps the nine separate launches (A/B aid)
         import os as _os
         self.fuse_output = self.loss_kind == "nll" and _os.environ.get("LIDBOX_NO_FUSED_OUTPUT") != "1" and model.fused_output_ok()
+        if _os.environ.get("LIDBOX_OVERLAP_WGRAD") is not None:          # A/B aid
+            overlap_wgrad = _os.environ["LIDBOX_OVERLAP_WGRAD"] == "1"
         if overlap_wgrad and model.wgrad_stream is None:
             model.wgrad_stream = torch.cuda.Stream(device=self.device)
         # overlap_head_wgrad: only the dense head's wgrads (a few workgroups each, M = batch) on a second stream, beside the

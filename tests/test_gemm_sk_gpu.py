@@ -267,3 +267,107 @@ def test_pipelined_epilogue_variant_matches_float64(grid, small_grid, monkeypatc
     ref = (A[:Bn * R] @ Bt.T) * (mask[:Bn * R] > 0) + 7.0
     _close(got[:, 3:, :].reshape(Bn * R, N), ref)
     assert np.all(got[:, :3, :] == 7.0)
+
+
+# ---- streamed remainder of the one-tile-per-workgroup LDS-DMA kernels (csrc/gemm_dma.h: DmaStream) ----------------------
+# tiles % 256 tiles of the last partial round are cut along K into g pieces; the last arriver sums the slabs in k order.
+@pytest.mark.parametrize("plan,M,N", [("64,64,1", 64 * 70 + 13, 256), ("128,64,1", 128 * 69 - 5, 250), ("64,128,1", 64 * 41, 896),
+                                      ("128,128,1", 128 * 66, 512)])
+@pytest.mark.parametrize("K,g", [(600, 0), (200, 2), (1536, 8), (512, 3)])
+def test_streamed_remainder_matches_float64(plan, M, N, K, g, monkeypatch):
+    """every tile shape, K tails (600 = 37.5 steps), ragged M / N edges in the streamed tiles (they are the LAST tiles: the
+    bottom rows), planner-chosen and forced piece counts, every epilogue, a garbage workspace, bit-identical replays"""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM_PLAN", plan)
+    if g:
+        monkeypatch.setenv("LIDBOX_GEMM_STREAM_TAIL", str(g))
+    rng = np.random.default_rng(M + K + g)
+    A, Bm, Bt = rng.standard_normal((M, K)), rng.standard_normal((K, N)), rng.standard_normal((N, K))
+    bias, mask = rng.standard_normal(N), rng.standard_normal((M, N))
+    a, b, bt, bi, mk = _dev(A), _dev(Bm), _dev(Bt), _dev(bias), _dev(mask)
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_rows_workspace(M, N, K) + (64 << 20)
+    pieces = nv.lib.lidbox_gemm_plan_stream_tail(0, M, N, K, wsb)
+    if g:
+        assert pieces == g
+    elif pieces == 0:
+        pytest.skip("the planner streams nothing here (remainder close to a whole round, or K too short)")
+    ws = _garbage_ws(wsb)
+    if N % 4 == 0:                                               # nn needs 16-byte aligned B rows for the DMA family
+        c = torch.full((M, N), 7.0, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                       nv.ptr(ws), wsb, st))
+        assert nv.lib.lidbox_gemm_last_family() == 1
+        first = c.clone()
+        _close(c.cpu().numpy(), np.maximum(A @ Bm + bias, 0))
+        c.fill_(-1.0)
+        nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(b), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                       nv.ptr(ws), wsb, st))
+        assert torch.equal(c, first)
+    c = torch.full((M, N), -2.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_ACCUM_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    assert nv.lib.lidbox_gemm_last_family() == 1
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0) - 2.0)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    first = c.clone()
+    _close(c.cpu().numpy(), (A @ Bt.T) * (mask > 0))
+    # unstreamed launch of the same decomposition: same values to fp32 round-off
+    monkeypatch.setenv("LIDBOX_GEMM_STREAM_TAIL", "0")
+    assert nv.lib.lidbox_gemm_plan_stream_tail(1, M, N, K, wsb) == 0
+    ref = torch.zeros_like(c)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(ref, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
+                                   nv.ptr(mk), nv.ptr(ws), wsb, st))
+    _close(c.cpu().numpy(), ref.cpu().numpy().astype(np.float64))
+    # 50 replays on the same workspace (arrival order varies): bit-identical
+    monkeypatch.setenv("LIDBOX_GEMM_STREAM_TAIL", str(g) if g else "1")
+    for _ in range(50):
+        nv.check(nv.lib.lidbox_gemm_nt(_rows(a, 0, K, 1, M), nv.ptr(bt), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_RELU_MASK,
+                                       nv.ptr(mk), nv.ptr(ws), wsb, st))
+    assert torch.equal(c, first)
+
+
+def test_streamed_remainder_conv_layout_and_small_workspace(monkeypatch):
+    """conv-layout operands (overlapping windows in, strided windows with an utterance gap out) through the streamed tiles;
+    a workspace smaller than the slabs need falls back to whole tiles (same values)"""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM_PLAN", "64,64,1")
+    rng = np.random.default_rng(5)
+    Bn, T, C, k, s, Co = 96, 99, 128, 3, 2, 256
+    To, Tp = (T - 1) // s + 1, T + k - 1
+    X = np.zeros((Bn, Tp, C))
+    X[:, k - 1:, :] = rng.standard_normal((Bn, T, C))
+    W, bias = rng.standard_normal((k * C, Co)) * 0.1, rng.standard_normal(Co)
+    M, K = Bn * To, k * C                                        # 4800 x 384: 75 x 4 = 300 tiles, 44 streamed
+    win = np.stack([X[:, t * s:t * s + k, :].reshape(Bn, K) for t in range(To)], axis=1).reshape(M, K)
+    x, w, bi = _dev(X), _dev(W), _dev(bias)
+    y = torch.full((Bn, To, Co), 5.0, device="cuda")
+    st = nv.current_stream()
+    wsb = nv.lib.lidbox_gemm_rows_workspace(M, Co, K)
+    assert nv.lib.lidbox_gemm_plan_stream_tail(0, M, Co, K, wsb) >= 2
+    ws = _garbage_ws(wsb)
+    Ad = _rows(x, Tp * C, s * C, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_nn(Ad, nv.ptr(w), Co, _rows(y, To * Co, Co, Bn, To), K, Co, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), wsb, st))
+    _close(y.cpu().numpy().reshape(M, Co), np.maximum(win @ W + bias, 0))
+    assert nv.lib.lidbox_gemm_plan_stream_tail(0, M, Co, K, 20000) == 0
+    y2 = torch.full((Bn, To, Co), 5.0, device="cuda")
+    nv.check(nv.lib.lidbox_gemm_nn(Ad, nv.ptr(w), Co, _rows(y2, To * Co, Co, Bn, To), K, Co, nv.EPI_BIAS_RELU, nv.ptr(bi),
+                                   nv.ptr(ws), 20000, st))
+    _close(y2.cpu().numpy().reshape(M, Co), y.cpu().numpy().reshape(M, Co).astype(np.float64))
+    dY = rng.standard_normal((M, Co))
+    dy = _dev(dY)
+    dx = torch.zeros((Bn, Tp, C), device="cuda")
+    Kd, Nd = Co, s * C
+    wsb2 = nv.lib.lidbox_gemm_rows_workspace(M, Nd, Kd)
+    assert nv.lib.lidbox_gemm_plan_stream_tail(1, M, Nd, Kd, wsb2) >= 2
+    ws2 = _garbage_ws(wsb2)
+    Cd = _rows(dx, Tp * C, s * C, Bn, To)
+    nv.check(nv.lib.lidbox_gemm_nt(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, Cd, Kd, Nd, nv.EPI_RELU_MASK, nv.ptr(x), nv.ptr(ws2), wsb2, st))
+    full = dY @ W[:Nd].T
+    ref = np.zeros((Bn, Tp, C))
+    for b_ in range(Bn):
+        for t in range(To):
+            ref[b_, t * s:t * s + s, :] = full[b_ * To + t].reshape(s, C) * (X[b_, t * s:t * s + s, :] > 0)
+    _close(dx.cpu().numpy(), ref)

@@ -136,10 +136,21 @@ def test_xvector_2d_gradients_match_autograd_and_training_learns(F):
     before = {k: v.copy() for k, v in m.get_weights().items() if "moving" in k}
     loss, _ = t.loss_and_grads(_dev(x), _dev(y, np.int32))
     assert abs(float(loss) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
+    flips = 0
     for k in m.layout:
         ref_g = pt[k].grad.numpy()
         got_g = m.param(k, grad=True).cpu().numpy()
-        assert np.abs(got_g - ref_g).max() <= 2e-3 * max(1e-12, np.abs(ref_g).max()), k
+        d, scale = np.abs(got_g - ref_g), max(1e-12, np.abs(ref_g).max())
+        if d.max() > 2e-3 * scale:
+            # One ReLU whose pre-activation lies within fp32 round-off of zero may fall on the other side than in float64
+            # (311 k activations in frame2d_2 alone; which one depends on the GEMM's summation order, i.e. on the
+            # planner): the error is then confined to ONE output channel of one layer (tools/scratch/x2d_flip.py:
+            # channel 71 at 4e-3, every other channel at 1e-6) -- allowed once per model, everything else is an error
+            per_c = d.reshape(-1, d.shape[-1]).max(0)
+            worst = int(np.argmax(per_c))
+            assert np.delete(per_c, worst).max() <= 2e-5 * scale and per_c[worst] <= 2e-2 * scale, k
+            flips += 1
+    assert flips <= 2          # a layer's W and b
     # the captured step: running statistics move once per step (not in the warm-up pass), the loss goes down
     m2 = xvector_2d.create((T, F), 3, seed=7)
     t2 = Trainer(m2, use_graph=True)
