@@ -1,0 +1,176 @@
+// gemm16_dma.h -- bf16-storage rows GEMM (lidbox_gemm_bf16s_nt: reference xvector.py:38-43,53-64 under a bfloat16 compute
+// policy, see gemm_bf16.hip) on the LDS-DMA operand path, included by gemm_bf16.hip.
+//
+// Why: the launches of one bf16 train step are SHORT (8 448 x 512 x 512 at bs 256 = 4.4 GFLOP, 23 us on the 128 x 128
+// register-staged kernel = 0.08 of the bf16 MFMA peak): one or two K steps deep per CU, they spend their time in the first
+// round trip to memory, the staging chain global -> VGPR -> ds_write -> barrier, and the C epilogue of the one workgroup a
+// CU holds.  Here both operand tiles of a step go from global memory to LDS with global_load_lds_dwordx4 (no staging
+// registers, no ds_write) into a ring of S stages, the tile shape is a template parameter (64 x 64 tiles put 4+ independent
+// workgroups on a CU: their round trips and epilogues overlap), and one s_barrier per step publishes a stage.
+//
+// Layout.  Both operands have the contraction index contiguous in HBM (A = bf16 shadow rows, B = weight shadow [N][K]).
+// A step is 64 k = one 128-byte line per row = 8 chunks of 16 bytes.  The LDS image of a DMA is lane-linear (lane i lands
+// at base + 16 i), so a wave instruction moves 8 rows x 128 B and the swizzle is applied on the SOURCE side: lane i =
+// (row i >> 3, position i & 7) fetches chunk (i & 7) ^ (row & 7) of its row.  The MFMA operand of v_mfma_f32_32x32x16_bf16
+// (lane -> row lane & 31, 8 consecutive k at 16 ks + 8 (lane >> 5)) is then one ds_read_b128 at position chunk ^ (row & 7):
+// every 8 consecutive rows cover all 32 banks once -- conflict-free.
+// K tails (K % 64 != 0; K % 8 == 0 always) take their missing chunks from a 16-byte zero source (flat-form DMA on that
+// step only); rows past M read the tile's first row (never stored).
+#pragma once
+
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int D16_BK = 64;                  // bf16 per row per step
+constexpr int D16_ROW_BYTES = D16_BK * 2;   // 128
+
+template <int ROWS>
+struct Dma16Operand {
+    static constexpr int PW = ROWS / 32;    // pieces (8 rows x 128 B) per wave per step
+    const float* sb;                        // wave-uniform byte base (+ k of the next step to issue)
+    unsigned vo[PW];                        // this lane's byte offsets: row offset + swizzled chunk
+    int kq;                                 // first k of this lane's chunk inside a step
+    int rd;                                 // LDS read base (bytes inside the operand's stage): row of the first block
+
+    __device__ __forceinline__ void init(const RowsH& X, long row0, long nrows, int kbeg, int lane, int wv, int wsub) {
+        sb = sk_uniform(reinterpret_cast<const float*>(X.base + kbeg));
+        const int chunk = (lane & 7) ^ (lane >> 3);
+        kq = chunk * 8;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            long r = row0 + 8 * (wv * PW + i) + (lane >> 3);
+            if (r >= nrows) r = row0;
+            vo[i] = (unsigned)((row_offset(X, (unsigned)r) + chunk * 8) * 2);
+        }
+        rd = (wsub * (ROWS / 2) + (lane & 31)) * D16_ROW_BYTES;
+    }
+    __device__ __forceinline__ void issue(int i, unsigned dst) const { sk_dma_s(sb, vo[i], dst); }
+    // last step of a K range that is not a multiple of 64: chunks at or past kvalid come from the zero source
+    __device__ __forceinline__ void issue_tail(int i, unsigned dst, int kvalid) const {
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
+        sk_dma_f(kq < kvalid ? p : g_sk_zero, dst);
+    }
+    __device__ __forceinline__ void advance() { sb += D16_ROW_BYTES / 4; }
+    // operand registers of block b (32 rows) for k slice ks (16 k): lane -> row lane & 31, k 16 ks + 8 (lane >> 5) ..+7
+    __device__ __forceinline__ bf16x8 read(const char* st, int lane, int b, int ks) const {
+        const int pos = (2 * ks + (lane >> 5)) ^ (lane & 7);
+        return *reinterpret_cast<const bf16x8*>(st + rd + b * 32 * D16_ROW_BYTES + pos * 16);
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void d16_wait_le() {
+    sk_wait_vm<N>();
+}
+
+// C[M,N] = epi(A[M,K] . B[N,K]^T), bf16 operands, fp32 accumulate; grid.x = tiles (XCD-chunk remapped), grid.y = K splits
+template <int BM, int BN, int STAGES, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm16s_rows_dma_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
+                                                                    float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
+                                                                    const float* __restrict__ aux, int tiles_n, unsigned ntiles,
+                                                                    int k_per_split, const unsigned short* __restrict__ mask16) {
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    constexpr int A_ST = BM * D16_ROW_BYTES, ST = (BM + BN) * D16_ROW_BYTES;      // bytes
+    constexpr int PA = BM / 32, PB = BN / 32, NP = PA + PB;                       // DMA pieces per wave per step: 4 .. 8
+    constexpr int NKS = D16_BK / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem16d[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem16d);
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const int tn = chunk % tiles_n;
+    const long m0 = m_beg + (long)(chunk / tiles_n) * BM;
+    const int n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int n = (kend - kbeg + D16_BK - 1) / D16_BK;
+    const int ktail = kend - kbeg - (n - 1) * D16_BK;          // valid k of the last step: 8 .. 64
+
+    Dma16Operand<BM> oa;
+    Dma16Operand<BN> ob;
+    oa.init(A, m0, M, kbeg, lane, wv, wm);
+    ob.init(Bw, n0, N, kbeg, lane, wv, wn);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // piece pc of this wave for step `step` into stage `stage`: pieces 0 .. PA-1 of A, then PB of B
+    auto issue = [&](int pc, int step, int stage) {
+        const bool tail = step == n - 1 && ktail < D16_BK;
+        if (pc < PA) {
+            const unsigned d = lds0 + (unsigned)(stage * ST + (wv * PA + pc) * 1024);
+            if (tail) oa.issue_tail(pc, d, ktail);
+            else oa.issue(pc, d);
+        } else {
+            const int q = pc - PA;
+            const unsigned d = lds0 + (unsigned)(stage * ST + A_ST + (wv * PB + q) * 1024);
+            if (tail) ob.issue_tail(q, d, ktail);
+            else ob.issue(q, d);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < n) {
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) issue(pc, s, s);
+            oa.advance();
+            ob.advance();
+        }
+    int cur = 0;
+    for (int t = 0; t < n; ++t) {
+        // step t's pieces have landed (this wave's; the barrier covers the others'): the steps issued after it may stay in flight
+        const int later = min(STAGES - 2, n - 1 - t);
+        if (later >= 2) d16_wait_le<2 * NP>();
+        else if (later == 1) d16_wait_le<NP>();
+        else d16_wait_le<0>();
+        __builtin_amdgcn_s_barrier();
+        const bool more = t + STAGES - 1 < n;
+        int tgt = cur + STAGES - 1;
+        if (tgt >= STAGES) tgt -= STAGES;                       // the stage step t - 1 was read from: free since the barrier
+        const char* st = smem16d + cur * ST;
+        bf16x8 a[2][MI], b[2][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = oa.read(st, lane, i, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[0][j] = ob.read(st + A_ST, lane, j, 0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int c = ks & 1, nx = c ^ 1;
+            if (ks + 1 < NKS) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[nx][i] = oa.read(st, lane, i, ks + 1);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[nx][j] = ob.read(st + A_ST, lane, j, ks + 1);
+            }
+            // the DMAs of step t + STAGES - 1 go out between the MFMA groups (an issue holds the wave ~56 cycles)
+            if (more) {
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    if (pc * NKS / NP == ks) issue(pc, t + STAGES - 1, tgt);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            oa.advance();
+            ob.advance();
+        }
+        ++cur;
+        if (cur == STAGES) cur = 0;
+    }
+    store_rows_tile<MI, NJ, true>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16, mask16);
+}
+
+}  // namespace

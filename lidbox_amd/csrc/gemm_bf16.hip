@@ -570,6 +570,10 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
     store_rows_tile<2, 2, true>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16, mask16);
 }
 
+}  // namespace
+#include "gemm16_dma.h"
+namespace {
+
 // ------------------------------------------------------------------------------------------------
 // bf16-STORAGE wgrad (lidbox_gemm_bf16s_tn): P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N] with both operands bfloat16
 // in HBM and the contraction index = the ROW (A = the bf16 shadow of the layer input, read through the implicit-row
@@ -964,6 +968,91 @@ int launch_rows16(const char* fn, lidbox_rows_t A, const float* Bm, long ldb, li
     return launch_range(0, M, pl);
 }
 
+// ---- LDS-DMA variant (gemm16_dma.h): tile shape / ring depth per problem
+struct Dma16Choice {
+    int bm = 0, bn = 0, stages = 0;     // bm == 0: the register-staged kernel
+    int splits = 1, k_per_split = 0;
+};
+
+// LIDBOX_GEMM16S_DMA: "0" off, "bm,bn,stages[,splits]" forces a variant (tuning aid, tools/gemm16_sweep.py); unset: policy
+Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes) {
+    Dma16Choice c;
+    int bm = 0, bn = 0, stg = 0, sp = 0;
+    if (const char* e = getenv("LIDBOX_GEMM16S_DMA")) {
+        if (sscanf(e, "%d,%d,%d,%d", &bm, &bn, &stg, &sp) < 3) return c;
+        if (!((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && stg >= 2 && stg <= 4)) return c;
+    } else {
+        // Measured per layer at bs 256 (profiles/r03_bf16_dma_variants.txt, us per call, register-staged 128 x 128 first):
+        // launches that put fewer than ~1.5 tiles of 128 x 128 on a CU finish sooner as 64 x 128 tiles, two stages
+        // (8448 x 512, K 512 / 1536: 22.0 -> 17.2, 39.1 -> 30.8), short-K launches (K <= 512: a tile is 8 steps, its
+        // epilogue half its life) as 64 x 64 (25344 x 512: 53.6 -> 49.0; 8448 x 1536: 54.0 -> 48.7); long-K launches that
+        // fill the chip stay on the 128 x 128 kernel (25344 x 512 x 1536: 71.8 vs 70.3-105).  Deeper rings lose: the
+        // launches are latency-, not bandwidth-bound, and every stage costs a resident workgroup.
+        const long t128 = lbx_cdiv(M, 128L) * lbx_cdiv((long)N, 128L);
+        if (t128 < NUM_CU / 2) return c;                       // split-K territory (dense head): register-staged kernel
+        if (t128 < 3 * NUM_CU / 2) { bm = 64; bn = 128; stg = 2; }
+        else if (K <= 512) { bm = 64; bn = 64; stg = 2; }
+        else return c;
+    }
+    c.bm = bm; c.bn = bn; c.stages = stg;
+    const long tiles = lbx_cdiv(M, (long)bm) * lbx_cdiv((long)N, (long)bn);
+    long s = sp > 0 ? sp : 1;
+    if (sp <= 0 && tiles < 2 * NUM_CU) {                       // small-M problems: split along K until the chip is covered twice
+        s = (2 * NUM_CU) / tiles;
+        const long max_s = K / (2 * D16_BK);
+        if (s > max_s) s = max_s;
+        if (s > 64) s = 64;
+    }
+    while (s > 1 && (size_t)s * M * N * sizeof(float) > ws_bytes) --s;
+    if (s < 1) s = 1;
+    c.k_per_split = (int)(lbx_cdiv(lbx_cdiv((long)K, s), (long)D16_BK) * D16_BK);
+    c.splits = (int)lbx_cdiv((long)K, (long)c.k_per_split);
+    return c;
+}
+
+template <int BM, int BN, int STAGES, int OCC>
+int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M,
+                         int K, int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st) {
+    constexpr size_t lds_bytes = (size_t)STAGES * (BM + BN) * D16_ROW_BYTES;
+    static bool attr_set = false;
+    if (lds_bytes > 65536 && !attr_set) {
+        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_dma_kernel<BM, BN, STAGES, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+        attr_set = true;
+    }
+    const int tiles_n = (int)lbx_cdiv((long)N, (long)BN);
+    const long ntiles = lbx_cdiv(M, (long)BM) * tiles_n;
+    hipLaunchKernelGGL((gemm16s_rows_dma_kernel<BM, BN, STAGES, OCC>), dim3((unsigned)ntiles, (unsigned)dc.splits), dim3(256), lds_bytes, st,
+                       Ah, Bh, Co, S, P, 0L, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, dc.k_per_split, mask16);
+    LBX_LAUNCH_OK();
+    if (dc.splits > 1) {
+        long g = lbx_cdiv(M * N, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, dc.splits, 0L, M, N, Co, epi, aux, S,
+                           mask16);
+        LBX_LAUNCH_OK();
+    }
+    return LIDBOX_OK;
+}
+
+int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
+                       int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st) {
+#define LBX_D16(BM_, BN_, ST_, OCC_) \
+    if (dc.bm == BM_ && dc.bn == BN_ && dc.stages == ST_) return launch_rows16s_dma_t<BM_, BN_, ST_, OCC_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st)
+    LBX_D16(64, 64, 2, 5);
+    LBX_D16(64, 64, 3, 3);
+    LBX_D16(64, 64, 4, 2);
+    LBX_D16(128, 64, 2, 3);
+    LBX_D16(128, 64, 3, 2);
+    LBX_D16(64, 128, 2, 3);
+    LBX_D16(64, 128, 3, 2);
+    LBX_D16(128, 128, 2, 2);
+    LBX_D16(128, 128, 3, 1);
+#undef LBX_D16
+    lidbox_set_error("lidbox_gemm_bf16s_nt: no LDS-DMA instantiation for tile %d x %d, %d stages", dc.bm, dc.bn, dc.stages);
+    return LIDBOX_E_INVALID;
+}
+
 int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, lidbox_rows_out_t Cd, void* C16, int K, int N,
                    int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t st, const unsigned short* mask16) {
     const long M = (long)A.batch * A.rows_per_batch;
@@ -975,6 +1064,17 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
         lidbox_set_error("%s: invalid argument: bf16-storage operands need 16-byte aligned bases and K, ldb, row and batch "
                          "strides (in bf16 elements) that are multiples of 8", fn);
         return LIDBOX_E_INVALID;
+    }
+    const RowsOutD Co_{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
+    const RowsH Ah_{(const __bf16*)A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch};
+    const RowsH Bh_{(const __bf16*)B16, 0, ldb, 1, 0};
+    {
+        const Dma16Choice dc = choose_dma16(M, N, K, ws ? ws_bytes : 0);
+        // 32-bit byte offsets per lane inside the kernel: the operands' extents must fit
+        const double a_ext = ((double)(A.batch - 1) * (double)A.batch_stride + (double)A.rows_per_batch * (double)A.row_stride + K) * 2.0;
+        const double b_ext = ((double)N * (double)ldb + K) * 2.0;
+        if (dc.bm != 0 && a_ext < 4.0e9 && b_ext < 4.0e9)
+            return launch_rows16s_dma(dc, Ah_, Bh_, Co_, (unsigned short*)C16, (float*)ws, M, K, N, epi, aux, mask16, st);
     }
     const Rows16Plan pl = plan_rows16(M, N, K, ws ? ws_bytes : 0, BKS);
     const size_t lds_bytes = 4 * (size_t)TILE_S * sizeof(__bf16);

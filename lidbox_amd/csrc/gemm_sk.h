@@ -30,10 +30,9 @@
 #pragma once
 
 #include "gemm_shared.h"
+#include "lds_dma.h"
 
 namespace {
-
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 16;
 constexpr int SK_A_STAGE = SK_BM * SK_BK, SK_B_STAGE = SK_BK * SK_BN, SK_STAGE = SK_A_STAGE + SK_B_STAGE;   // floats
@@ -52,8 +51,6 @@ constexpr int SK_SLAB = SK_BM * SK_BN;            // floats of one partial tile
 constexpr size_t SK_COUNTER_BYTES = 16384;        // head of the workspace: one arrival counter per streamed tile (<= 4096)
 constexpr size_t SK_LDS_BYTES = (size_t)SK_STAGES * SK_STAGE * sizeof(float);
 
-__device__ __attribute__((aligned(16))) float g_sk_zero[4];        // source of the chunks past K of a tail step
-
 struct SkPlan {
     int tiles_n, ntiles;
     int nk;                 // K steps per tile (the last one may be partial)
@@ -64,33 +61,6 @@ struct SkPlan {
                             // g >= 1: each streamed tile is cut into g equal parts, one workgroup each (the remainder of
                             //         whole rounds: few slabs, the other workgroups go straight to their whole tiles)
 };
-
-// LDS-DMA of 16 bytes per lane: lane i of the wave lands at lds_dst + 16 i (M0 = wave-uniform destination).
-__device__ __forceinline__ void sk_dma_s(const float* sbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
-                 : "memory");
-}
-__device__ __forceinline__ void sk_dma_f(const float* p, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(p), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
-                 : "memory");
-}
-// a pointer every lane holds the same value of, provably so for the compiler (SGPR pair): the "s" operands of the DMA
-// statements otherwise cost a waterfall loop each
-__device__ __forceinline__ const float* sk_uniform(const float* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const float*)(((unsigned long long)hi << 32) | lo);
-}
-template <int N>
-__device__ __forceinline__ void sk_wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // ---- K-inner operand: 128 rows x 16 k per step.  Piece i of wave w = rows 16 (2w + i) .. + 15, four lanes per row.
 struct SkInner {
@@ -332,7 +302,6 @@ __device__ __forceinline__ void sk_kloop(float* smem, unsigned lds0, int wv, int
 // Slabs travel WRITE-THROUGH (sc1 stores, sc1 loads): a hand-off needs no agent-scope release / acquire fence then -- a
 // release (buffer_wbl2) writes back EVERY dirty line of the XCD's L2, the output tiles of 95 other workgroups included,
 // and cost more than the K loop of a short tile (frame4, bs 256: 103 us with fences vs 51 us on the classic kernels).
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_slab_rsrc(const float* slab) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sk_uniform(slab)), 0, SK_SLAB * 4, 0x00020000);
 }
