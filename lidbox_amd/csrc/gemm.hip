@@ -1287,7 +1287,6 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
             rows_aligned(A) && rows_aligned(Bd) && sk_extent_ok(A, K1) && sk_extent_ok(Bd, N)) {
             sk_set_lds_attr();
             g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1;
-    g_last_family = 0;
             g_last_family = 2;
             float* P = (float*)workspace;
             float* Pc = bias_grad ? P + (size_t)sk.splits * K1 * N : nullptr;
@@ -1310,6 +1309,20 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     float* P = (float*)workspace;
     float* Pc = bias_grad ? P + (size_t)pl.splits * K1 * N : nullptr;
     const unsigned grid = (unsigned)(ntiles * pl.splits);
+    // the same decomposition on the LDS-DMA operand path (gemm_dma.h): 16-byte aligned operands with 32-bit extents
+    if (al && dma_mode() != 0 && sk_extent_ok(A, K1) && sk_extent_ok(Bd, N) && pl.rows_per_split % SK_BK == 0) {
+        g_last_family = 1;
+#define LBX_TN_DMA(BM_, BN_) hipLaunchKernelGGL((gemm_tn_dma_kernel<BM_, BN_>), dim3(grid), dim3(256), 0, st, to_dev(A), to_dev(Bd), P, Pc, M, K1, N, tiles_n, ntiles, pl.rows_per_split)
+        if (pl.bm == 128 && pl.bn == 128) LBX_TN_DMA(128, 128);
+        else if (pl.bm == 128) LBX_TN_DMA(128, 64);
+        else if (pl.bn == 128) LBX_TN_DMA(64, 128);
+        else LBX_TN_DMA(64, 64);
+#undef LBX_TN_DMA
+        LBX_LAUNCH_OK();
+        launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, (long)K1 * N, N, Cm, ldc, accumulate, bias_grad, st);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    }
 #define LBX_TN(BM_, BN_) launch_tn_t<BM_, BN_>(al, grid, st, to_dev(A), to_dev(Bd), P, Pc, M, K1, N, tiles_n, ntiles, pl.rows_per_split)
 #if LBX_GEMM_BK == 16
     if (pl.bm == 128 && pl.bn == 128) LBX_TN(128, 128);

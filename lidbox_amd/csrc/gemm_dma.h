@@ -328,4 +328,176 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
     store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split);
 }
 
+// K-outer operand whose k index is an implicit activation row (tn: the contraction runs over the rows), 16 rows x COLS
+// columns per step; LDS image [k][COLS]; a piece = 1 KB = RPP rows.  32-bit element offsets advanced with adds only
+// (SkOuterRows of gemm_sk.h for any tile width).
+template <int COLS>
+struct DmaOuterRows {
+    static constexpr int PW = COLS / 64;
+    static constexpr int LPR = COLS / 4;          // lanes per row
+    static constexpr int RPP = 64 / LPR;          // rows per piece: 4 (64 columns) or 2 (128)
+    const float* sb;
+    int off[PW];
+    unsigned tt[PW];
+    int a_step, a_wrap;
+    unsigned rpb;
+    int mleft[PW];
+    int rd;
+
+    __device__ __forceinline__ void init(const RowsD& X, int col0, int ncols, long mbeg, long mend, int lane, int wv, int wsub) {
+        sb = sk_uniform(X.base + col0);
+        int c = (lane % LPR) * 4;
+        if (col0 + c >= ncols) c = 0;
+        a_step = (int)(SK_BK * X.rs);
+        a_wrap = X.batch == 1 ? 0 : (int)(X.bs - (long)X.rpb * X.rs);
+        rpb = X.batch == 1 ? 0xffffffffu : (unsigned)X.rpb;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const long m = mbeg + RPP * (wv * PW + i) + lane / LPR;
+            const unsigned bq = X.batch == 1 ? 0u : (unsigned)m / rpb;
+            tt[i] = (unsigned)m - (X.batch == 1 ? 0u : bq * rpb);
+            off[i] = (int)((long)bq * X.bs + (long)tt[i] * X.rs) + c;
+            mleft[i] = (int)(mend - m);
+        }
+        rd = (4 * (lane >> 5)) * COLS + wsub * (COLS / 2) + (lane & 31);
+    }
+    __device__ __forceinline__ void issue(int i, unsigned dst, bool tail) {
+        if (!tail) {
+            sk_dma_s(sb, (unsigned)off[i] * 4u, dst);
+        } else {
+            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + (size_t)((unsigned)off[i] * 4u));
+            sk_dma_f(mleft[i] > 0 ? p : g_sk_zero, dst);
+        }
+        mleft[i] -= SK_BK;
+        tt[i] += SK_BK;
+        off[i] += a_step;
+        while (tt[i] >= rpb) { tt[i] -= rpb; off[i] += a_wrap; }
+    }
+    template <int NB>
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[NB][4]) const {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b][j] = st[rd + (8 * s2 + j) * COLS + b * 32];
+    }
+};
+
+// wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N] (+ Pc[split][N] = column sums of B[Mslice] from the stages in
+// LDS), the decomposition of gemm_tn_kernel (gemm.hip) on the LDS-DMA operand path with the tile shape as a template
+// parameter; grid.x = tiles x splits (tile fastest: co-resident workgroups share a slice's rows in L2)
+template <int BM, int BN>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_tn_dma_kernel(
+    RowsD A, RowsD Bd, float* __restrict__ P, float* __restrict__ Pc, long M, int K1, int N, int tiles_n, int ntiles, long rows_per_split) {
+    constexpr int MI = BM / 64, NJ = BN / 64;
+    constexpr int A_ST = SK_BK * BM, B_ST = SK_BK * BN, ST = A_ST + B_ST;
+    constexpr int PA = BM / 64, PB = BN / 64, NP = PA + PB;
+    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * ST];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int i0 = tk * BM, n0 = tn * BN;
+    const long mbeg = (long)split * rows_per_split;
+    long mend = mbeg + rows_per_split;
+    if (mend > M) mend = M;
+    const int n = (int)((mend - mbeg + SK_BK - 1) / SK_BK);
+    const int tail_step = ((mend - mbeg) % SK_BK != 0) ? n - 1 : -1;
+
+    DmaOuterRows<BM> oa;
+    DmaOuterRows<BN> ob;
+    oa.init(A, i0, K1, mbeg, mend, lane, wv, wm);
+    ob.init(Bd, n0, N, mbeg, mend, lane, wv, wn);
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
+    const bool do_csum = (Pc != nullptr) && tk == 0 && tid < BN;
+
+    auto issue = [&](int pc, int step, int stage) {
+        if (pc < PA) oa.issue(pc, lds0 + (unsigned)((stage * ST + (wv * PA + pc) * 256) * 4), step == tail_step);
+        else ob.issue(pc - PA, lds0 + (unsigned)((stage * ST + A_ST + (wv * PB + (pc - PA)) * 256) * 4), step == tail_step);
+    };
+    auto ra = [&](const float* st, int s2, float (&v)[MI][4]) { oa.template read<MI>(st, lane, s2, v); };
+    auto rb = [&](const float* st, int s2, float (&v)[NJ][4]) {
+        ob.template read<NJ>(st, lane, s2, v);
+        if (do_csum && s2 == 0) {
+#pragma unroll
+            for (int kk = 0; kk < SK_BK; ++kk) csum += st[kk * BN + tid];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < DMA_STAGES - 1; ++s)
+        if (s < n) {
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) issue(pc, s, s);
+        }
+    if (n >= DMA_STAGES - 1) sk_wait_vm<(DMA_STAGES - 2) * NP>();
+    else sk_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    float a0[MI][4], b0[NJ][4], a1[MI][4], b1[NJ][4];
+    if (n > 0) {
+        ra(smem, 0, a0);
+        rb(smem + A_ST, 0, b0);
+    }
+    int cur = 0;
+    for (int t = 0; t < n; ++t) {
+        if (t + 1 < n) sk_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        int nxt = cur + 1;
+        if (nxt == DMA_STAGES) nxt = 0;
+        const bool more = t + DMA_STAGES - 1 < n;
+        int tgt = cur + DMA_STAGES - 1;
+        if (tgt >= DMA_STAGES) tgt -= DMA_STAGES;
+        const float* st = smem + cur * ST;
+        dma_mma<MI, NJ, 0, 1>(a0, b0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        ra(st, 1, a1);
+        rb(st + A_ST, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 1, 2>(a0, b0, acc);
+        if (more) issue(0, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 2, 3>(a0, b0, acc);
+        if (more) issue(1, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 3, 4>(a0, b0, acc);
+        if (more && NP > 2) issue(2, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 0, 1>(a1, b1, acc);
+        if (more && NP > 3) issue(3, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < n) {
+            const float* sn = smem + nxt * ST;
+            ra(sn, 0, a0);
+            rb(sn + A_ST, 0, b0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 1, 4>(a1, b1, acc);
+        cur = nxt;
+    }
+    float* Pd = P + (long)split * K1 * N;
+    const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+    for (int bj = 0; bj < NJ; ++bj) {
+        const int col = n0 + wn * (32 * NJ) + bj * 32 + l;
+        if (col >= N) continue;
+#pragma unroll
+        for (int bi = 0; bi < MI; ++bi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * (32 * MI) + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
+            }
+    }
+    if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
+}
+
 }  // namespace
