@@ -157,7 +157,12 @@ class KernelTimer:
                     self.nv.check(self.nv.lib.lidbox_gemm_last_launches(out3))
                     nk = max(1, out3[0])
                     if self.nv.lib.lidbox_gemm_last_family() == 1:     # the LDS-DMA instantiation of the same tile shape
-                        key = key.replace("gemm_rows_kernel<", "gemm_rows_dma_kernel<")
+                        key = key.replace("gemm_rows_kernel<", "gemm_rows_dma_kernel<").replace("gemm_tn_kernel<", "gemm_tn_dma_kernel<")
+                elif self.ENTRY[_n] == 13:
+                    out3 = (ctypes.c_int * 3)()
+                    self.nv.check(self.nv.lib.lidbox_gemm_bf16s_last_variant(out3))
+                    if out3[0]:
+                        key = "gemm16s_rows_dma_kernel<%d, %d, %d>" % (out3[0], out3[1], out3[2])
                 self.records.setdefault(key, []).append((e0, e1, work, nk))
                 return rc
             setattr(self.nv.lib, name, wrapper)
@@ -223,6 +228,9 @@ def pmc_traffic(kernel_key, bf16=False):
         name = "gemm_rows%s_kernel<%s, %s, %s, true>" % (m.group(1), m.group(2), m.group(3), "true" if m.group(4) == "NT" else "false")
     elif kernel_key.startswith("gemm_tn_kernel<"):
         name = kernel_key[:-1] + ", true>"
+    elif kernel_key.startswith("gemm16s_rows_dma_kernel<"):          # rocprofv3 lists the fourth template argument (occupancy) too
+        cands = [k for k in kern if k.startswith(kernel_key[:-1] + ",")]
+        name = cands[0] if cands else None
     elif kernel_key == "fused_feat512_kernel":
         cands = [k for k in kern if k.startswith("fused_feat512_kernel<2,")]
         name = cands[0] if cands else None

@@ -257,6 +257,9 @@ int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_ro
  * lidbox_gemm_bf16_tn (xvector.py:38-43 under a bfloat16 policy); the bias gradient is the fp32 sum of the shadow's
  * values.  Needs 16-byte aligned bases, row / batch strides % 8 == 0, and K1 / N % 8 == 0 or rows padded to a multiple
  * of 8 elements (row_stride >= the width rounded up to 8: a 1500-channel gradient lives in a 1504-wide shadow). */
+/* Kernel variant of the calling thread's most recent lidbox_gemm_bf16s_nt (profiling tools): out3 = {tile rows, tile columns,
+ * LDS ring stages} of the LDS-DMA instantiation gemm16s_rows_dma_kernel, or zeros for the register-staged 128 x 128 kernel. */
+int lidbox_gemm_bf16s_last_variant(int* out3);
 size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N);
 int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ldc, int K1, int N,
                          int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,

@@ -76,6 +76,7 @@ _SIGS = {
     "lidbox_gemm_plan_query": (_i, [_i, _l, _i, _i, _sz, _vp]),
     "lidbox_gemm_last_launches": (_i, [_vp]),
     "lidbox_gemm_last_family": (_i, []),
+    "lidbox_gemm_bf16s_last_variant": (_i, [_vp]),
     "lidbox_gemm_plan_stream_tail": (_i, [_l, _i, _i, _i, _sz]),
     "lidbox_gemm_plan_waves": (_i, [_i, _l, _i, _i, _sz]),
     "lidbox_gemm_plan_is_stream_k": (_i, [_i, _l, _i, _i, _sz]),

@@ -1035,6 +1035,8 @@ int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh
     return LIDBOX_OK;
 }
 
+thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the calling thread's last lidbox_gemm_bf16s_nt (0: register-staged)
+
 int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
                        int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st) {
 #define LBX_D16(BM_, BN_, ST_, OCC_) \
@@ -1073,6 +1075,10 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
         // 32-bit byte offsets per lane inside the kernel: the operands' extents must fit
         const double a_ext = ((double)(A.batch - 1) * (double)A.batch_stride + (double)A.rows_per_batch * (double)A.row_stride + K) * 2.0;
         const double b_ext = ((double)N * (double)ldb + K) * 2.0;
+        g16_last_variant[0] = g16_last_variant[1] = g16_last_variant[2] = 0;
+        if (dc.bm != 0 && a_ext < 4.0e9 && b_ext < 4.0e9) {
+            g16_last_variant[0] = dc.bm; g16_last_variant[1] = dc.bn; g16_last_variant[2] = dc.stages;
+        }
         if (dc.bm != 0 && a_ext < 4.0e9 && b_ext < 4.0e9)
             return launch_rows16s_dma(dc, Ah_, Bh_, Co_, (unsigned short*)C16, (float*)ws, M, K, N, epi, aux, mask16, st);
     }
@@ -1142,6 +1148,12 @@ extern "C" int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb
     if (validate_rows_call(__func__, A16, (const float*)B16, ldb, Cv, K, N, epi, aux, K)) return LIDBOX_E_INVALID;
     return launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epi, mask16 ? nullptr : aux, workspace, workspace_bytes,
                           (hipStream_t)stream, mask16 ? (const unsigned short*)aux : nullptr);
+}
+
+extern "C" int lidbox_gemm_bf16s_last_variant(int* out3) {
+    LBX_ARG(out3, "out3 != NULL");
+    out3[0] = g16_last_variant[0]; out3[1] = g16_last_variant[1]; out3[2] = g16_last_variant[2];
+    return LIDBOX_OK;
 }
 
 extern "C" size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N) {

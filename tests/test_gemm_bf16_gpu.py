@@ -203,12 +203,17 @@ def test_bf16_gemm_tail_split_matches_single_launch(M, K, N):
     assert np.all(got[:, :3, :] == 7.0)
 
 
+@pytest.mark.parametrize("variant", [None, "64,64,2", "64,64,3", "128,64,2", "64,128,2", "128,128,2", "128,128,3"])
 @pytest.mark.parametrize("M,K,N", [(128, 32, 128), (200, 200, 512), (33, 1536, 512), (1000, 264, 40), (5, 8, 8),
                                    (256, 3000, 512), (700, 512, 1024), (1, 8, 4), (50688 // 8, 200, 512)])
-def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N):
+def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N, variant, monkeypatch):
     """lidbox_gemm_bf16s_nt: operands already bf16 in HBM ([M][K] and [N][K]); same numbers as the fp32-source kernel on the
-    unrounded originals; the bf16 shadow of C equals bf16(C); split-K, epilogues, converters"""
+    unrounded originals; the bf16 shadow of C equals bf16(C); split-K, epilogues, converters.
+    variant: None = the library's own choice (small problems: the register-staged 128 x 128 kernel), "bm,bn,stages" = that
+    instantiation of the LDS-DMA kernel (csrc/gemm16_dma.h; K tails of 8 .. 56 past a 64-deep step, ragged M / N edges)"""
     from lidbox_amd import _native as nv
+    if variant is not None:
+        monkeypatch.setenv("LIDBOX_GEMM16S_DMA", variant)
     rng = np.random.default_rng(M * 5 + K)
     A, B, bias = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal(N)
     ref = _bf16(A) @ _bf16(B).T
@@ -229,6 +234,10 @@ def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N):
     nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, rc, nv.ptr(c16), K, N, nv.EPI_NONE, None, None, 0, st))
     _close(c.cpu().numpy(), ref)
     assert torch.equal(c16, c.bfloat16())
+    out3 = (nv.C.c_int * 3)()
+    nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(out3))
+    if variant:
+        assert list(out3) == [int(v) for v in variant.split(",")]
     # the fp32-source kernel on the same data gives the same product (to summation order)
     c_old = torch.zeros((M, N), device="cuda")
     if K % 4 == 0:
@@ -435,3 +444,29 @@ def test_bf16_storage_gemm_shadow_only_output_and_bf16_mask(M, K, N):
     with pytest.raises(ValueError):                              # the flag without a mask epilogue
         nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(b16), K, nv.Rows(None, 0, N, 1, M), nv.ptr(only), K, N,
                                              nv.EPI_BIAS | nv.EPI_MASK_BF16, nv.ptr(mask16), None, 0, st))
+
+
+@pytest.mark.parametrize("M,K,N,want", [(8448, 512, 512, [64, 128, 2]), (8448, 512, 1536, [64, 64, 2]), (25344, 1024, 512, [0, 0, 0])])
+def test_bf16_storage_gemm_policy_at_layer_sizes(M, K, N, want):
+    """x-vector layer shapes at bs 256: which kernel lidbox_gemm_bf16s_nt picks on its own (csrc/gemm_bf16.hip:
+    choose_dma16 -- few tiles per CU: 64 x 128 LDS-DMA tiles; short K: 64 x 64; long K on a full chip: the register-staged
+    128 x 128 kernel) and that the product is the bf16-operand product whichever it is"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(K + N)
+    A, B = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)
+    a16, b16 = torch.from_numpy(A).cuda().bfloat16(), torch.from_numpy(B).cuda().bfloat16()
+    mask = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+    c = torch.full((M, N), 1.0, device="cuda")
+    c16 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    st = nv.current_stream()
+    wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(M, N, K))
+    ws = _ws(wsb)
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(nv.Rows(a16.data_ptr(), 0, K, 1, M), nv.ptr(b16), K, _rows(c, 0, N, 1, M), nv.ptr(c16), K, N,
+                                         nv.EPI_ACCUM_RELU_MASK, nv.ptr(mask), nv.ptr(ws), wsb, st))
+    out3 = (nv.C.c_int * 3)()
+    nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(out3))
+    assert list(out3) == want
+    ref = (a16.float().double() @ b16.float().double().T) * (mask > 0) + 1.0          # float64 product of the bf16 operands, on the GPU
+    err = float((c.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
+    assert torch.equal(c16, c.bfloat16())
