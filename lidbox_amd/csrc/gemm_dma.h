@@ -12,6 +12,9 @@ namespace {
 #ifndef LBX_DMA_STAGES
 #define LBX_DMA_STAGES 3
 #endif
+#ifndef LBX_DMA_LATE_READ
+#define LBX_DMA_LATE_READ 0                 // rows kernel only: see the variant in its K loop
+#endif
 constexpr int DMA_STAGES = LBX_DMA_STAGES;
 
 // K-inner operand, ROWS = 64 or 128 rows x 16 k per step; a wave issues ROWS / 64 pieces of 16 rows (four lanes per row)
@@ -249,11 +252,48 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
     else sk_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     float a0[MI][4], b0[NJ][4], a1[MI][4], b1[NJ][4];
+#if !LBX_DMA_LATE_READ
     if (n > 0) {
         ra(smem, 0, a0);
         rb(smem + A_ST, 0, b0);
     }
+#endif
     int cur = 0;
+#if LBX_DMA_LATE_READ
+    // A/B variant, measured and not adopted (profiles/r03_dma_loop_variants_ab.txt): no operand registers carried across
+    // the barrier -- the wait then only covers step t (the pieces of step t + 1 stay in flight: two steps of prefetch
+    // distance on three stages), at the price of an exposed LDS read behind every barrier
+    for (int t = 0; t < n; ++t) {
+        if (t + 1 < n) sk_wait_vm<NP>();
+        else sk_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const bool more = t + DMA_STAGES - 1 < n;
+        int tgt = cur + DMA_STAGES - 1;
+        if (tgt >= DMA_STAGES) tgt -= DMA_STAGES;
+        const float* st = smem + cur * ST;
+        ra(st, 0, a0);
+        rb(st + A_ST, 0, b0);
+        ra(st, 1, a1);
+        rb(st + A_ST, 1, b1);
+        if (more) issue(0, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 0, 2>(a0, b0, acc);
+        if (more) issue(1, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 2, 4>(a0, b0, acc);
+        if (more && NP > 2) issue(2, t + DMA_STAGES - 1, tgt);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 0, 2>(a1, b1, acc);
+        if (more) {
+            if (NP > 3) issue(3, t + DMA_STAGES - 1, tgt);
+            next();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_mma<MI, NJ, 2, 4>(a1, b1, acc);
+        ++cur;
+        if (cur == DMA_STAGES) cur = 0;
+    }
+#else
     for (int t = 0; t < n; ++t) {
         if (t + 1 < n) {
             if (DMA_STAGES >= 4 && t + DMA_STAGES - 2 < n) sk_wait_vm<(DMA_STAGES >= 4 ? (DMA_STAGES - 3) * NP : 0)>();
@@ -295,6 +335,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
         dma_mma<MI, NJ, 1, 4>(a1, b1, acc);
         cur = nxt;
     }
+#endif
     if (part >= 0) {
         constexpr int SLAB = BM * BN;
         dma_slab_store<MI, NJ>(sp.slabs + (size_t)blockIdx.x * SLAB, acc, wv, lane);

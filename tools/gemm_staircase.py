@@ -1,6 +1,6 @@
 """time vs tile count for one tile shape: the quantisation staircase of the rows kernels (fp32, nn, N=512)"""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lidbox_amd import _native as nv
 plan = sys.argv[1] if len(sys.argv) > 1 else "64,64,1"
