@@ -218,6 +218,18 @@ int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1
                    int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                    lidbox_stream_t stream);
 
+/* A layer's dgrad and wgrad in one call -- both read the output gradient dY [M, Co]:
+ *     dX rows = epilogue(dY . W^T)        exactly lidbox_gemm_nt(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ...)
+ *     dW [K1, Co] (ldc) (+)= X^T . dY     exactly lidbox_gemm_tn(X, dY, dW, ldc, K1, Co, accumulate, bias_grad, ws_tn, ...)
+ * Small problems (the dense head: M = batch rows, both planned as 64 x 64 tiles that fit the chip at once) go out as ONE
+ * kernel launch followed by their reduces; everything else is the two calls, wgrad first.  Bit-identical to the two calls
+ * either way.  The two workspaces must not overlap (the two GEMMs run concurrently). */
+/* 1 when lidbox_gemm_nt_tn would launch this pair (16-byte aligned operands) as one kernel (profiling tools). */
+int lidbox_gemm_plan_is_pair(long M, int Co, int N, int K1, size_t ws_nt_bytes, size_t ws_tn_bytes);
+int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
+                      const float* aux, void* ws_nt, size_t ws_nt_bytes, lidbox_rows_t X, float* dW, long ldc, int K1,
+                      int accumulate, float* bias_grad, void* ws_tn, size_t ws_tn_bytes, lidbox_stream_t stream);
+
 /* ---- bf16-compute variants (BASELINE config 5: "bf16 compute / fp32 master") -------------------
  * Same arguments, layouts, epilogues and determinism as lidbox_gemm_nn / _nt / _tn.  Every buffer
  * stays fp32 in HBM; both operands are rounded to bfloat16 (round-to-nearest-even) while they are

@@ -85,6 +85,8 @@ _SIGS = {
     "lidbox_gemm_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "lidbox_gemm_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_plan_is_pair": (_i, [_l, _i, _i, _i, _sz, _sz]),
+    "lidbox_gemm_nt_tn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, Rows, _vp, _l, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_bf16_rows_workspace": (_sz, [_l, _i, _i]),
     "lidbox_gemm_bf16_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_bf16_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -1339,6 +1339,112 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     return LIDBOX_OK;
 }
 
+inline long pair_max_blocks() {
+    if (const char* e = getenv("LIDBOX_GEMM_PAIR_MAX_BLOCKS")) return atol(e);     // A/B aid
+    return 12L * NUM_CU;           // two rounds of resident workgroups: frame4 at bs 256 (97 -> 88 us); beyond that the pair gains nothing
+}
+
+// whether dgrad (M x N, K = Co) + wgrad (K1 x Co over M rows) of 16-byte aligned operands go out as one launch
+bool pair_plan(long M, int Co, int N, int K1, size_t ws_nt_bytes, size_t ws_tn_bytes, RowsChoice* ch_out, TnPlan* pl_out) {
+    if (dma_mode() == 0 || getenv("LIDBOX_GEMM_NO_PAIR") != nullptr || M < 1 || N < 1 || K1 < 1 || Co < 1) return false;
+    if (Co % 4 != 0 || K1 % 4 != 0) return false;
+    const RowsChoice ch = choose_rows_env(1, M, N, Co, ws_nt_bytes);
+    const TnPlan pl = tn_plan(M, K1, Co);
+    const SkTn sk = sk_tn_plan(M, K1, Co);
+    const bool sk_rows = !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && lidbox_gemm_plan_is_stream_k(1, M, N, Co, ws_nt_bytes);
+    const bool sk_tn = sk.ok && !getenv("LIDBOX_GEMM_TN_PLAN") && !sk_tuned_out(2, M, Co, K1) && ws_tn_bytes >= sk.ws_need;
+    const size_t tn_need = ((size_t)pl.splits * K1 * Co + (size_t)pl.splits * Co) * sizeof(float);
+    const long rows_blocks = lbx_cdiv(M, 64L) * lbx_cdiv((long)N, 64L) * ch.splits;
+    const long tn_blocks = lbx_cdiv((long)K1, 64L) * lbx_cdiv((long)Co, 64L) * pl.splits;
+    if (!(ch.bm == 64 && ch.bn == 64 && ch.waves == 4 && pl.bm == 64 && pl.bn == 64 && !sk_rows && !sk_tn && ws_tn_bytes >= tn_need &&
+          (ch.splits == 1 || (size_t)ch.splits * M * N * sizeof(float) <= ws_nt_bytes) && rows_blocks + tn_blocks <= pair_max_blocks()))
+        return false;
+    if (ch_out) *ch_out = ch;
+    if (pl_out) *pl_out = pl;
+    return true;
+}
+
+// A layer's dgrad and wgrad, both reading the output gradient dY [M, Co]:
+//     dX rows = epi(dY . W^T)      (lidbox_gemm_nt:  A = dY, B = W [N][Co], C = dX, K = Co)
+//     dW [K1, Co] = X^T . dY, db   (lidbox_gemm_tn:  A = X [M, K1], B = dY)
+// When both are small 64 x 64-tile launches of the LDS-DMA family (the dense head: M = batch rows) they go out as ONE launch
+// (gemm_nt_tn_pair_kernel, gemm_dma.h) followed by their reduces; otherwise this is exactly the two calls.  Results are
+// bit-identical to the two calls either way (same bodies, tiles and summation orders).
+extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
+                                 const float* aux, void* ws_nt, size_t ws_nt_bytes, lidbox_rows_t X, float* dW, long ldc, int K1,
+                                 int accumulate, float* bias_grad, void* ws_tn, size_t ws_tn_bytes, lidbox_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)dY.batch * dY.rows_per_batch;
+    bool pair = dma_mode() != 0 && getenv("LIDBOX_GEMM_NO_PAIR") == nullptr && M >= 1 && N >= 1 && K1 >= 1 && Co >= 1 && W && dW && ws_tn &&
+                ws_nt != ws_tn;
+    if (pair) {
+        if (validate_rows_call(__func__, dY, W, ldb, dX, Co, N, epilogue, aux, Co)) return LIDBOX_E_INVALID;
+        if (check_rows(__func__, X.base, X.batch_stride, X.row_stride, X.batch, X.rows_per_batch)) return LIDBOX_E_INVALID;
+        LBX_ARG((long)X.batch * X.rows_per_batch == M && ldc >= Co, "X and dY row counts differ, or ldc < Co");
+    }
+    RowsChoice ch{};
+    TnPlan pl{};
+    if (pair) {
+        const size_t wsb = ws_nt ? ws_nt_bytes : 0;
+        const bool al_rows = rows_aligned(dY) && aligned16(W) && ldb % 4 == 0 && sk_extent_ok(dY, Co) && (double)N * ldb * 4.0 < 4.0e9 &&
+                             aligned16(ws_nt);
+        const bool al_tn = rows_aligned(X) && sk_extent_ok(X, K1) && aligned16(ws_tn);
+        pair = al_rows && al_tn && pair_plan(M, Co, N, K1, wsb, ws_tn_bytes, &ch, &pl);
+    }
+    if (!pair) {
+        int rc = lidbox_gemm_tn(X, dY, dW, ldc, K1, Co, accumulate, bias_grad, ws_tn, ws_tn_bytes, stream);
+        if (rc) return rc;
+        return lidbox_gemm_nt(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ws_nt_bytes, stream);
+    }
+    PairRows r;
+    r.A = to_dev(dY); r.Bm = W; r.ldb = ldb;
+    r.Cd = RowsOutD{dX.base, dX.batch_stride, dX.row_stride, dX.batch, dX.rows_per_batch};
+    r.P = (float*)ws_nt; r.M = M; r.K = Co; r.N = N; r.epi = epilogue; r.aux = aux;
+    r.tiles_n = (int)lbx_cdiv((long)N, 64L);
+    r.ntiles = (unsigned)(lbx_cdiv(M, 64L) * r.tiles_n);
+    r.k_per_split = ch.k_per_split; r.nx = r.ntiles; r.partial = ch.splits > 1 ? 1 : 0;
+    if (ch.splits == 1 && ws_nt) {                              // the streamed remainder of the separate launch, same pieces
+        const DmaStreamPlan spl = dma_stream_plan(64, 64, M, N, Co);
+        if (spl.g > 1 && ws_nt_bytes >= spl.ws_need) {
+            r.sp.pieces = (unsigned)(spl.rem * spl.g);
+            r.sp.npad = (r.sp.pieces + 7u) & ~7u;
+            r.sp.g = spl.g;
+            r.sp.first_tile = (unsigned)spl.whole;
+            r.sp.epoch = sk_next_epoch();
+            r.sp.counters = (unsigned*)ws_nt;
+            r.sp.slabs = (float*)((char*)ws_nt + SK_COUNTER_BYTES);
+            r.ntiles = (unsigned)spl.whole;
+            r.nx = r.sp.npad + r.ntiles;
+        }
+    }
+    PairTn t;
+    t.A = to_dev(X); t.Bd = to_dev(dY);
+    t.P = (float*)ws_tn; t.Pc = bias_grad ? t.P + (size_t)pl.splits * K1 * Co : nullptr;
+    t.M = M; t.K1 = K1; t.N = Co; t.tiles_n = (int)lbx_cdiv((long)Co, 64L);
+    t.ntiles = (int)(lbx_cdiv((long)K1, 64L) * t.tiles_n);
+    t.rows_per_split = pl.rows_per_split;
+    const unsigned rows_blocks = r.nx * (unsigned)ch.splits;
+    const unsigned grid = rows_blocks + (unsigned)(t.ntiles * pl.splits);
+    g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1 + (ch.splits > 1 ? 1 : 0);
+    g_last_family = 1;
+    hipLaunchKernelGGL(gemm_nt_tn_pair_kernel, dim3(grid), dim3(256), 0, st, r, t, rows_blocks);
+    LBX_LAUNCH_OK();
+    if (ch.splits > 1) {
+        long g = lbx_cdiv(M * N, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)r.P, ch.splits, 0L, M, N, r.Cd, epilogue,
+                           aux);
+        LBX_LAUNCH_OK();
+    }
+    launch_splitk_reduce((const float*)t.P, (const float*)t.Pc, pl.splits, (long)K1 * Co, Co, dW, ldc, accumulate, bias_grad, st);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_gemm_plan_is_pair(long M, int Co, int N, int K1, size_t ws_nt_bytes, size_t ws_tn_bytes) {
+    return pair_plan(M, Co, N, K1, ws_nt_bytes, ws_tn_bytes, nullptr, nullptr) ? 1 : 0;
+}
+
 extern "C" size_t lidbox_colsum_workspace(long M, int N) {
     long slices = lbx_cdiv(M, 256);
     if (slices > 128) slices = 128;

@@ -148,32 +148,32 @@ __device__ __forceinline__ void dma_slab_add(const float* slab, f32x16 (&acc)[MI
 // C[M,N] = epi(A[M,K] . B), grid.x = [streamed pieces] + whole tiles (XCD-chunk remapped), grid.y = K splits (partials to P,
 // rows_reduce_kernel finishes; never together with streamed pieces)
 template <int BM, int BN, bool B_KINNER>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_rows_dma_kernel(
-    RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
-    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split, DmaStream sp) {
+__device__ __forceinline__ void rows_dma_body(const RowsD& A, const float* __restrict__ Bm, long ldb, const RowsOutD& Cd, float* __restrict__ P,
+                                              long m_beg, long M, int K, int N, int epi, const float* __restrict__ aux, int tiles_n,
+                                              unsigned ntiles, int k_per_split, const DmaStream& sp, unsigned bx, unsigned by, int partial,
+                                              float* smem) {
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int A_ST = BM * SK_BK, B_ST = SK_BK * BN, ST = A_ST + B_ST;
     constexpr int PA = BM / 64, PB = BN / 64;                // DMA pieces per wave per step
-    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * ST];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
-    const int split = blockIdx.y;
+    const int split = (int)by;
     unsigned chunk;
     int kbeg, kend, part = -1;
     unsigned rem_t = 0;
-    if (blockIdx.x < sp.npad) {                               // wave-uniform: a piece of a streamed tile
-        if (blockIdx.x >= sp.pieces) return;
-        rem_t = blockIdx.x / (unsigned)sp.g;
-        part = (int)(blockIdx.x - rem_t * (unsigned)sp.g);
+    if (bx < sp.npad) {                               // wave-uniform: a piece of a streamed tile
+        if (bx >= sp.pieces) return;
+        rem_t = bx / (unsigned)sp.g;
+        part = (int)(bx - rem_t * (unsigned)sp.g);
         chunk = sp.first_tile + rem_t;
         const int nk = (K + SK_BK - 1) / SK_BK;
         kbeg = (part * nk / sp.g) * SK_BK;
         kend = min(K, ((part + 1) * nk / sp.g) * SK_BK);
     } else {
-        chunk = xcd_chunk_id(blockIdx.x - sp.npad, ntiles);
+        chunk = xcd_chunk_id(bx - sp.npad, ntiles);
         kbeg = split * k_per_split;
         kend = min(K, kbeg + k_per_split);
     }
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
 #endif
     if (part >= 0) {
         constexpr int SLAB = BM * BN;
-        dma_slab_store<MI, NJ>(sp.slabs + (size_t)blockIdx.x * SLAB, acc, wv, lane);
+        dma_slab_store<MI, NJ>(sp.slabs + (size_t)bx * SLAB, acc, wv, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                      // every wave's slab rows are out, and nobody reads the ring any more
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
@@ -366,7 +366,19 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
             dma_slab_add<MI, NJ>(sp.slabs + ((size_t)rem_t * sp.g + q) * SLAB, acc, wv, lane);
         if (tid == 0) __hip_atomic_store(sp.counters + rem_t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split);
+    store_rows_tile<MI, NJ>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, nullptr, nullptr, partial);
+}
+
+template <int BM, int BN>
+constexpr int dma_stage_floats() { return (BM + BN) * SK_BK; }
+
+template <int BM, int BN, bool B_KINNER>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_rows_dma_kernel(
+    RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
+    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split, DmaStream sp) {
+    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * dma_stage_floats<BM, BN>()];
+    rows_dma_body<BM, BN, B_KINNER>(A, Bm, ldb, Cd, P, m_beg, M, K, N, epi, aux, tiles_n, ntiles, k_per_split, sp, blockIdx.x, blockIdx.y,
+                                    gridDim.y > 1 ? 1 : 0, smem);
 }
 
 // K-outer operand whose k index is an implicit activation row (tn: the contraction runs over the rows), 16 rows x COLS
@@ -427,19 +439,18 @@ struct DmaOuterRows {
 // LDS), the decomposition of gemm_tn_kernel (gemm.hip) on the LDS-DMA operand path with the tile shape as a template
 // parameter; grid.x = tiles x splits (tile fastest: co-resident workgroups share a slice's rows in L2)
 template <int BM, int BN>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_tn_dma_kernel(
-    RowsD A, RowsD Bd, float* __restrict__ P, float* __restrict__ Pc, long M, int K1, int N, int tiles_n, int ntiles, long rows_per_split) {
+__device__ __forceinline__ void tn_dma_body(const RowsD& A, const RowsD& Bd, float* __restrict__ P, float* __restrict__ Pc, long M, int K1, int N,
+                                            int tiles_n, int ntiles, long rows_per_split, unsigned bx, float* smem) {
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int A_ST = SK_BK * BM, B_ST = SK_BK * BN, ST = A_ST + B_ST;
     constexpr int PA = BM / 64, PB = BN / 64, NP = PA + PB;
-    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * ST];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
-    const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;
+    const int tile = (int)(bx % (unsigned)ntiles);
+    const int split = (int)(bx / (unsigned)ntiles);
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int i0 = tk * BM, n0 = tn * BN;
     const long mbeg = (long)split * rows_per_split;
@@ -539,6 +550,52 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 :
             }
     }
     if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_tn_dma_kernel(
+    RowsD A, RowsD Bd, float* __restrict__ P, float* __restrict__ Pc, long M, int K1, int N, int tiles_n, int ntiles, long rows_per_split) {
+    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * dma_stage_floats<BM, BN>()];
+    tn_dma_body<BM, BN>(A, Bd, P, Pc, M, K1, N, tiles_n, ntiles, rows_per_split, blockIdx.x, smem);
+}
+
+// Two independent GEMMs that read the same output gradient -- a layer's dgrad (nt) and its wgrad (tn) -- in ONE launch of
+// 64 x 64 tiles: block b < rows_blocks runs the dgrad's block (b % rows_nx, b / rows_nx), the others the wgrad's.  For the
+// dense head (M = batch rows: each of the two alone puts a handful of workgroups on the chip for 10-19 us of launch and
+// round-trip latency) the pair costs what the longer one costs.  Same bodies, same block -> tile maps, same summation
+// orders as the separate launches: bit-identical results.
+struct PairRows {
+    RowsD A;
+    const float* Bm;
+    long ldb;
+    RowsOutD Cd;
+    float* P;
+    long M;
+    int K, N, epi;
+    const float* aux;
+    int tiles_n;
+    unsigned ntiles;
+    int k_per_split;
+    unsigned nx;                // blocks per K split (pieces + whole tiles)
+    int partial;                // K splits > 1: raw partial sums to P
+    DmaStream sp;
+};
+struct PairTn {
+    RowsD A, Bd;
+    float* P;
+    float* Pc;
+    long M;
+    int K1, N, tiles_n, ntiles;
+    long rows_per_split;
+};
+__global__ __launch_bounds__(256, 6) void gemm_nt_tn_pair_kernel(PairRows r, PairTn t, unsigned rows_blocks) {
+    __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * dma_stage_floats<64, 64>()];
+    if (blockIdx.x < rows_blocks) {
+        rows_dma_body<64, 64, true>(r.A, r.Bm, r.ldb, r.Cd, r.P, 0, r.M, r.K, r.N, r.epi, r.aux, r.tiles_n, r.ntiles, r.k_per_split, r.sp,
+                                    blockIdx.x % r.nx, blockIdx.x / r.nx, r.partial, smem);
+    } else {
+        tn_dma_body<64, 64>(t.A, t.Bd, t.P, t.Pc, t.M, t.K1, t.N, t.tiles_n, t.ntiles, t.rows_per_split, blockIdx.x - rows_blocks, smem);
+    }
 }
 
 }  // namespace

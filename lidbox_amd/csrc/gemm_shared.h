@@ -69,12 +69,14 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
                                                 const RowsOutD& Cd, float* __restrict__ P, int split,
                                                 unsigned long long mask_bits = 0ull, bool have_mask_bits = false,
                                                 unsigned short* __restrict__ shadow = nullptr,
-                                                const unsigned short* __restrict__ mask16 = nullptr) {
+                                                const unsigned short* __restrict__ mask16 = nullptr,
+                                                int partial_override = -1) {
     // shadow (bf16-storage GEMMs, gemm_bf16.hip): a bfloat16 copy of every finished value at the same element offset as C
     // (round-to-nearest-even) -- the operand the next GEMM reads; never written for split-K partial sums.
     // Epilogue kind as four uniform flags (no per-element switch); bias and column state hoisted.
     const int h = lane >> 5, l = lane & 31;
-    const bool partial = gridDim.y > 1;
+    // partial_override: 0 / 1 from kernels whose K splits are not grid.y (gemm_dma.h: several GEMMs in one launch)
+    const bool partial = partial_override < 0 ? gridDim.y > 1 : partial_override != 0;
     const bool has_bias = !partial && (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU);
     const bool do_relu = !partial && (epi == LIDBOX_EPI_BIAS_RELU || epi == LIDBOX_EPI_ACCUM_RELU || epi == LIDBOX_EPI_RELU);
     const bool has_mask = !partial && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);

@@ -777,15 +777,21 @@ class SequentialTDNN:
             din = x.shape[1]
             dy = _rows(ws.dh[j].data_ptr(), 0, d.units, 1, B)
             A_rows = _rows(x.data_ptr(), 0, din, 1, B)
+            dst = ws.dpooled if j == 0 else ws.dh[j - 1]
+            relu_prev = j > 0 and self.denses[j - 1].relu
+            epi, aux = (nv.EPI_RELU_MASK, nv.ptr(x)) if relu_prev else (nv.EPI_NONE, None)
+            dst_rows = _rows(dst.data_ptr(), 0, din, 1, B)
+            if self.dense_gemm.name == "float32" and self.wgrad_stream is None and self.head_wgrad_stream is None:
+                # wgrad and dgrad of the layer read the same dy: one launch when both are small (lidbox_gemm_nt_tn), the
+                # wgrad's partial sums in the second workspace
+                nv.check(lib.lidbox_gemm_nt_tn(dy, self._p(d.name + ".W"), d.units, dst_rows, d.units, din, epi, aux, gws, gws_n,
+                                               A_rows, self._p(d.name + ".W", True), d.units, din, 0, self._p(d.name + ".b", True),
+                                               nv.ptr(ws.gemm_ws2), ws.gemm_ws2.numel(), st))
+                continue
             self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(self.dense_gemm.tn(
                 A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)),
                 head=True)
-            dst = ws.dpooled if j == 0 else ws.dh[j - 1]
-            relu_prev = j > 0 and self.denses[j - 1].relu
-            nv.check(self.dense_gemm.nt(dy, self._p(d.name + ".W"), d.units,
-                                        _rows(dst.data_ptr(), 0, din, 1, B), d.units, din,
-                                        nv.EPI_RELU_MASK if relu_prev else nv.EPI_NONE,
-                                        nv.ptr(x) if relu_prev else None, gws, gws_n, st))
+            nv.check(self.dense_gemm.nt(dy, self._p(d.name + ".W"), d.units, dst_rows, d.units, din, epi, aux, gws, gws_n, st))
         # ---- pooling (fused with the ReLU backward of the last conv)
         att = self.attention
         last = ws.act[-1] if att is None else ws.hw
@@ -844,6 +850,7 @@ class SequentialTDNN:
             self._backward_dilated(ws, i, dy)
             return
         A_rows = self._conv_rows_in(ws, i)
+        pair_wgrad = False
         # bf16 shadow of dact[i+1]: written by conv i+1's dgrad epilogues / the pooling backward, or converted here when it
         # came from a fp32-source launch (same-layout shadows only)
         dy16 = ws.dact16[i + 1] if self.bf16_storage else None
@@ -858,6 +865,9 @@ class SequentialTDNN:
             A16, B16 = self._rows16(A_rows, ws.act[i], ws.act16[i]), self._rows16(dy, ws.dact[i + 1], dy16)
             self._launch_wgrad(ws, lambda w, n, s_: nv.check(lib.lidbox_gemm_bf16s_tn(
                 A16, B16, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
+        elif (self.gemm.name == "float32" and self.wgrad_stream is None and not self.bf16_storage and
+              not (i == 0 and not self.frontend)):
+            pair_wgrad = True             # goes out with the first dgrad group below (lidbox_gemm_nt_tn: one launch when both are small)
         else:
             self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
                 A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
@@ -929,6 +939,10 @@ class SequentialTDNN:
                 else:
                     Wg16 = ctypes.c_void_p(self._p16(c.name + ".W").value + 2 * g * c.s * cin * c.filters)
                     nv.check(lib.lidbox_gemm_bf16s_nt(A16, Wg16, c.filters, Cd, sh, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+            elif pair_wgrad and g == 0:
+                nv.check(lib.lidbox_gemm_nt_tn(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n,
+                                               A_rows, self._p(c.name + ".W", True), c.filters, K, 0, self._p(c.name + ".b", True),
+                                               nv.ptr(ws.gemm_ws2), ws.gemm_ws2.numel(), st))
             else:
                 nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
         if i == 0:

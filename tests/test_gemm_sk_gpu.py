@@ -371,3 +371,47 @@ def test_streamed_remainder_conv_layout_and_small_workspace(monkeypatch):
         for t in range(To):
             ref[b_, t * s:t * s + s, :] = full[b_ * To + t].reshape(s, C) * (X[b_, t * s:t * s + s, :] > 0)
     _close(dx.cpu().numpy(), ref)
+
+
+# ---- a layer's dgrad + wgrad as one launch (lidbox_gemm_nt_tn, csrc/gemm_dma.h: gemm_nt_tn_pair_kernel) ------------------
+@pytest.mark.parametrize("M,Co,N,K1,epi", [(256, 512, 3000, 3000, "none"), (256, 512, 512, 512, "mask"), (200, 64, 100, 100, "mask"),
+                                           (8448, 512, 512, 512, "mask")])
+def test_dgrad_wgrad_pair_is_bit_identical_to_the_two_calls(M, Co, N, K1, epi, monkeypatch):
+    """the dense head's shapes (M = 256 batch rows: 3000 -> 512 -> 512) go out as one kernel, ragged shapes too; a conv-size
+    problem falls back to the two launches; either way the results equal lidbox_gemm_tn + lidbox_gemm_nt bit for bit, and
+    float64 to round-off"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + N)
+    dY, W, X = rng.standard_normal((M, Co)), rng.standard_normal((N, Co)) * 0.1, rng.standard_normal((M, K1))
+    mask = rng.standard_normal((M, N))
+    dy, w, x, mk = _dev(dY), _dev(W), _dev(X), _dev(mask)
+    st = nv.current_stream()
+    ws1 = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, Co), 16) + 1024)
+    ws2 = _garbage_ws(max(nv.lib.lidbox_gemm_tn_workspace(M, K1, Co), 16) + 1024)
+    e = nv.EPI_RELU_MASK if epi == "mask" else nv.EPI_NONE
+    aux = nv.ptr(mk) if epi == "mask" else None
+    def run(pair):
+        dx = torch.full((M, N), 9.0, device="cuda"); dw = torch.full((K1, Co), 9.0, device="cuda"); db = torch.full((Co,), 9.0, device="cuda")
+        if pair:
+            nv.check(nv.lib.lidbox_gemm_nt_tn(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, e, aux, nv.ptr(ws1),
+                                              ws1.numel(), _rows(x, 0, K1, 1, M), nv.ptr(dw), Co, K1, 0, nv.ptr(db), nv.ptr(ws2), ws2.numel(), st))
+            launches = (nv.C.c_int * 3)()
+            nv.check(nv.lib.lidbox_gemm_last_launches(launches))
+        else:
+            nv.check(nv.lib.lidbox_gemm_tn(_rows(x, 0, K1, 1, M), _rows(dy, 0, Co, 1, M), nv.ptr(dw), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws2),
+                                           ws2.numel(), st))
+            nv.check(nv.lib.lidbox_gemm_nt(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, e, aux, nv.ptr(ws1), ws1.numel(), st))
+        return dx, dw, db
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    ref_dx = dY @ W.T
+    if epi == "mask":
+        ref_dx = ref_dx * (mask > 0)
+    _close(a[0].cpu().numpy(), ref_dx)
+    _close(a[1].cpu().numpy(), X.T @ dY)
+    _close(a[2].cpu().numpy(), dY.sum(0), rel=1e-5)
+    monkeypatch.setenv("LIDBOX_GEMM_NO_PAIR", "1")
+    c = run(True)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
