@@ -320,6 +320,28 @@ def test_stream_k_dispatch_policy_is_host_logic(nv, monkeypatch):
     assert q(1, 25344, 1024, 512, big) == 1 and q(0, 8448, 1500, 512, big) == 1
 
 
+def test_dgrad_wgrad_pair_policy_is_host_logic(nv, monkeypatch):
+    """lidbox_gemm_nt_tn launches a layer's dgrad + wgrad as ONE kernel when both are small 64 x 64 LDS-DMA launches
+    (csrc/gemm.hip: pair_plan): the dense head at any batch size the x-vector sees, frame4 at bs 256; chip-filling layers,
+    stream-K shapes and LIDBOX_GEMM_NO_PAIR=1 fall back to the two calls"""
+    q = nv.lib.lidbox_gemm_plan_is_pair
+    big = 1 << 30
+    for var in ("LIDBOX_GEMM_NO_PAIR", "LIDBOX_GEMM_PAIR_MAX_BLOCKS", "LIDBOX_GEMM_DMA", "LIDBOX_GEMM_PLAN", "LIDBOX_GEMM_TN_PLAN"):
+        monkeypatch.delenv(var, raising=False)
+    # (M, Co, N = rows of dX per window, K1): segment1 / segment2 at bs 256, frame4 (33 frames x 256 utterances)
+    assert q(256, 512, 3000, 3000, big, big) == 1 and q(256, 512, 512, 512, big, big) == 1
+    assert q(8448, 512, 512, 512, big, big) == 1
+    # frame3 (dgrad N = 1536: 3168 + 1536 blocks) and frame2 are beyond two rounds of resident workgroups
+    assert q(8448, 512, 1536, 1536, big, big) == 0 and q(25344, 512, 1024, 1536, big, big) == 0
+    # the wgrad's partial sums need their workspace
+    assert q(256, 512, 512, 512, big, 1024) == 0
+    monkeypatch.setenv("LIDBOX_GEMM_NO_PAIR", "1")
+    assert q(256, 512, 512, 512, big, big) == 0
+    monkeypatch.delenv("LIDBOX_GEMM_NO_PAIR")
+    monkeypatch.setenv("LIDBOX_GEMM_DMA", "0")
+    assert q(256, 512, 512, 512, big, big) == 0
+
+
 def test_lr_schedules_follow_keras(nv):
     """tf.keras.optimizers.schedules.ExponentialDecay / PiecewiseConstantDecay (reference keras_utils.py:137-139) as host
     functions of the optimizer step (Keras' 0-based `iterations`)"""
