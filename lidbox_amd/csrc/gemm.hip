@@ -31,6 +31,12 @@
 //     on one XCD's L2; the weight matrix (<= 3 MB) is L2-resident everywhere.
 //   * wgrad contracts over M = B*T (up to 50 688): always split; the bias gradient (column
 //     sums of dY) is accumulated from the dY tiles already in LDS by the k1-tile-0 workgroups.
+//   * Round 3: which KERNEL runs a decomposition.  16-byte aligned operands with 32-bit extents -- every layer of the models
+//     -- go through the LDS-DMA operand path: gemm_dma.h (the decompositions above, one tile per workgroup, with the last
+//     partial round of tiles streamed along K inside the launch; a layer's small dgrad + wgrad as one launch:
+//     lidbox_gemm_nt_tn) or, for long-K forward GEMMs and large wgrads, the persistent stream-K kernels of gemm_sk.h.  The
+//     register-staged kernels of THIS file keep everything else (unaligned operands, LIDBOX_GEMM_DMA=0) and remain the
+//     reference implementation the A/B tools compare against.  Dispatch: launch_rows / lidbox_gemm_tn below.
 // Roofline: MFMA fp32, 157.3 TFLOP/s.
 #include <stdlib.h>
 

@@ -3,6 +3,11 @@
 // on the source side and read with ds_read_b128, K-outer operands read with ds_read_b32.  Tiles 64 x 64, 128 x 64, 64 x 128,
 // 128 x 128 (four waves 2 x 2, MI x NJ blocks of 32 x 32 per wave).  Same contracts / epilogues as gemm_rows_kernel
 // (reference xvector.py:38-43,53-64, cnn.py:32-41); 16-byte aligned operands only.
+//   rows_dma_body / gemm_rows_dma_kernel   forward (nn) and dgrad (nt) with the fused epilogues; K splits through P, or the last
+//                                          partial round of tiles streamed along K inside the launch (DmaStream)
+//   tn_dma_body / gemm_tn_dma_kernel       wgrad over M slices, P[split][K1][N] + bias-gradient partials into gemm_shared.h's reduce
+//   gemm_nt_tn_pair_kernel                 a layer's dgrad + wgrad (64 x 64 tiles) as one launch (lidbox_gemm_nt_tn)
+// The bodies are device functions so that several GEMMs can share a launch; measurements behind every choice: DESIGN.md 4.2c.
 #pragma once
 
 #include "gemm_sk.h"
