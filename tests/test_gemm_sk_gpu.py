@@ -415,3 +415,31 @@ def test_dgrad_wgrad_pair_is_bit_identical_to_the_two_calls(M, Co, N, K1, epi, m
     c = run(True)
     for u, v in zip(a, c):
         assert torch.equal(u, v)
+
+
+def test_dgrad_wgrad_pair_shared_workspace_and_bad_arguments():
+    """one workspace for both halves: the call must not run them concurrently (it falls back to wgrad, then dgrad -- same
+    values); invalid descriptors are rejected with the error text of the underlying entry points"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(3)
+    M, Co, N, K1 = 256, 512, 512, 512
+    dY, W, X = rng.standard_normal((M, Co)), rng.standard_normal((N, Co)) * 0.1, rng.standard_normal((M, K1))
+    dy, w, x = _dev(dY), _dev(W), _dev(X)
+    st = nv.current_stream()
+    ws = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, Co), nv.lib.lidbox_gemm_tn_workspace(M, K1, Co)) + 1024)
+    dx = torch.zeros((M, N), device="cuda"); dw = torch.zeros((K1, Co), device="cuda"); db = torch.zeros((Co,), device="cuda")
+    nv.check(nv.lib.lidbox_gemm_nt_tn(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, nv.EPI_NONE, None, nv.ptr(ws),
+                                      ws.numel(), _rows(x, 0, K1, 1, M), nv.ptr(dw), Co, K1, 0, nv.ptr(db), nv.ptr(ws), ws.numel(), st))
+    launches = (nv.C.c_int * 3)()
+    nv.check(nv.lib.lidbox_gemm_last_launches(launches))
+    _close(dx.cpu().numpy(), dY @ W.T)
+    _close(dw.cpu().numpy(), X.T @ dY)
+    _close(db.cpu().numpy(), dY.sum(0), rel=1e-5)
+    # row counts of X and dY differ
+    rc = nv.lib.lidbox_gemm_nt_tn(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, nv.EPI_NONE, None, nv.ptr(ws), ws.numel(),
+                                  _rows(x, 0, K1, 1, M - 1), nv.ptr(dw), Co, K1, 0, nv.ptr(db), None, 0, st)
+    assert rc != 0 and b"row counts" in nv.lib.lidbox_hip_last_error()
+    # a mask epilogue without its mask
+    rc = nv.lib.lidbox_gemm_nt_tn(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, nv.EPI_RELU_MASK, None, nv.ptr(ws),
+                                  ws.numel(), _rows(x, 0, K1, 1, M), nv.ptr(dw), Co, K1, 0, nv.ptr(db), nv.ptr(ws), ws.numel(), st)
+    assert rc != 0 and b"aux" in nv.lib.lidbox_hip_last_error()
