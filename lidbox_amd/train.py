@@ -342,7 +342,7 @@ class Trainer:
                                          1.0, nv.ptr(self.adam_state), nv.current_stream()))
 
     # ---------------------------------------------------------------- graph plumbing
-    def _capture(self, fn):
+    def _capture(self, fn, with_collectives=False):
         # The cyclic collector must not run while the stream is capturing: freeing a dead Trainer's graphs / streams
         # from inside a capture is an illegal HIP call in global capture mode and aborts the process (seen when a
         # test's garbage was collected during the next test's capture).  torch.cuda.graph() collects once on entry.
@@ -350,7 +350,10 @@ class Trainer:
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(g, pool=self._pool()):
+            # a capture that contains collectives runs beside the backend's watchdog thread, whose event queries a
+            # "global" capture would treat as errors of THIS capture: thread-local error mode there
+            mode = dict(capture_error_mode="thread_local") if with_collectives else {}
+            with torch.cuda.graph(g, pool=self._pool(), **mode):
                 fn()
         finally:
             if gc_was_enabled:
@@ -402,7 +405,16 @@ class Trainer:
                     segs[-1]()
                 self.sync.warm()
                 torch.cuda.synchronize(self.device)
-                entry["graphs"] = (self._capture(whole).replay,)
+                try:
+                    entry["graphs"] = (self._capture(whole, with_collectives=True).replay,)
+                except Exception as exc:      # a backend build that cannot capture its collectives: host-launched ones instead
+                    import warnings
+                    warnings.warn("capturing the gradient all-reduces into the step graph failed (%s: %s); falling back to "
+                                  "host-launched collectives between graph segments" % (type(exc).__name__, exc))
+                    self.sync._pending.clear()
+                    torch.cuda.synchronize(self.device)
+                    adam_seg = self._capture(segs[-1]).replay if os.environ.get("LIDBOX_ADAM_GRAPH") else segs[-1]
+                    entry["graphs"] = tuple(self._capture(seg).replay for seg in segs[:-1]) + (adam_seg,)
             elif self.sync.active:
                 # the optimizer segment is two small kernels behind the last collective: launched directly unless
                 # LIDBOX_ADAM_GRAPH is set (a graph launch costs more than it saves there)
