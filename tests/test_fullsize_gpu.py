@@ -68,8 +68,8 @@ def test_config2_sharded_gradient_equals_global_gradient():
     kernels, 1.01e-5 since round 3 -- the stream-K kernels (csrc/gemm_sk.h) cut tiles at k positions that depend on the
     number of rows, so a shard's forward activations differ from the same utterances' inside the global batch by fp32
     round-off (~1e-7), which ReLU masks near zero amplify.  Any other reordering moves the gradient as much: the global
-    gradient itself differs by 1.4e-5 between the two kernel families (tools/scratch/gradnoise.py; each GEMM alone is within
-    2.5e-6 of float64 at both sizes, tools/scratch/big_shapes.py).  The bound below is 2e-5 (measured 1.5e-5); every tensor
+    gradient itself differs by 1.4e-5 between the two kernel families (tools/scratch/gradnoise.py at commit 0ed6482; each GEMM alone is within
+    2.5e-6 of float64 at both sizes, tools/scratch/big_shapes.py, same commit).  The bound below is 2e-5 (measured 1.5e-5); every tensor
     is also held to 3e-4 of its largest entry (measured worst: frame5.b, 1.7e-4 -- column sums of dy with heavy
     cancellation; 6e-5 when both sizes run the same kernel family)."""
     from lidbox_amd import _native as nv

@@ -144,7 +144,7 @@ def test_xvector_2d_gradients_match_autograd_and_training_learns(F):
         if d.max() > 2e-3 * scale:
             # One ReLU whose pre-activation lies within fp32 round-off of zero may fall on the other side than in float64
             # (311 k activations in frame2d_2 alone; which one depends on the GEMM's summation order, i.e. on the
-            # planner): the error is then confined to ONE output channel of one layer (tools/scratch/x2d_flip.py:
+            # planner): the error is then confined to ONE output channel of one layer (tools/scratch/x2d_flip.py at commit 0ed6482:
             # channel 71 at 4e-3, every other channel at 1e-6) -- allowed once per model, everything else is an error
             per_c = d.reshape(-1, d.shape[-1]).max(0)
             worst = int(np.argmax(per_c))
