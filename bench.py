@@ -76,6 +76,9 @@ def parse_args():
     ap.add_argument("--resident-batches", type=int, default=4,
                     help="different batches kept in HBM per rank; the timed loop rotates over them")
     ap.add_argument("--config", type=int, choices=[1, 3, 4], default=1, help="BASELINE.json configs[] index (see the module docstring)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default run (config 1, fp32, one GPU) only: do not append the configs[3] fp32 and configs[4] bf16-shard "
+                         "measurements as `secondary` (profiling passes use this so that per-kernel counters are not mixed across workloads)")
     ap.add_argument("--compute-dtype", choices=["float32", "bfloat16"], default=None,
                     help="GEMM arithmetic; float32 is the BASELINE metric's configuration, bfloat16 = config 5's "
                          "bf16-compute / fp32-master variant of the same workload (default: what the configuration names)")
@@ -215,14 +218,16 @@ def source_hash():
     return h.hexdigest()
 
 
-def pmc_traffic(kernel_key, bf16=False):
+def pmc_traffic(kernel_key, bf16=False, tag=None):
     """HBM bytes per launch of `kernel_key` from the newest committed PMC summary (profiles/*traffic*.json,
     produced by tools/traffic_from_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
     same command) -- bench.py cannot run rocprofv3 on itself.  Returns None unless the summary carries the hash of
     the kernel sources this process runs (a summary of older kernels is stale, not a measurement)."""
     import glob
     import re
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")) if f.endswith("_bf16.json") == bool(bf16))
+    # summaries by workload: *_traffic.json (config 1 fp32), *_traffic_bf16.json, *_traffic_config3.json, *_traffic_config4.json
+    suffix = "_traffic%s.json" % (tag if tag is not None else ("_bf16" if bf16 else ""))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")) if f.endswith(suffix))
     if not files:
         return None
     try:
@@ -307,18 +312,174 @@ def respawn_under_launcher(args):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(respawn_under_launcher(args))
+def make_workload(config, compute_dtype, B, world, dev):
+    """model / feature front-end / loss / bookkeeping of one BASELINE.json configuration"""
     from lidbox_amd import _native as nv
     from lidbox_amd.features import audio
     from lidbox_amd.losses import SparseAngularProximity
     from lidbox_amd.metrics import SparseAverageDetectionCost
     from lidbox_amd.models import cnn, xvector
     from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    bf16 = compute_dtype == "bfloat16"
+    num_langs = 100 if config == 4 else NUM_LANGS
+    plan = audio.get_plan(SAMPLE_RATE, 400, 160, device=dev)
+    w = dict(num_langs=num_langs, metric=None, bf16=bf16, config=config, batch=B,
+             traffic_tag={1: "_bf16" if bf16 else "", 3: "_config3", 4: "_config4"}[config])
+    if config == 3:
+        # BASELINE configs[3]: MFCC(1:13) + CMVN -> cnn (reference cnn.py:25-45, tf_utils.py:180-185, features/__init__.py:22-32)
+        w["model"] = cnn.create((198, 12), num_langs, seed=0, device=dev, compute_dtype=compute_dtype)
+        w["feature"], w["loss"] = dict(plan=plan, kind=nv.FEAT_MFCC, cmvn=True), "sparse_categorical_crossentropy"
+        w["flops_per_utt"], w["feature_bytes"] = FLOPS_PER_UTT_TRAIN_CNN, BYTES_PER_UTT_FEATURE_MFCC
+        w["cpu_cfg"] = dict(config="cnn", what="MFCC + CMVN + CNN classifier fwd/bwd + Adam")
+        w["workload"] = "MFCC(1:13)+CMVN + cnn 4-lang train step, bs=%d per GPU, %s (BASELINE configs[3])" % (B, "bf16 compute" if bf16 else "fp32")
+        w["metric_name"] = "utterances/sec (16kHz x 2s) MFCC+CMVN + CNN classifier train step"
+        w["model_name"] = "lidbox.models.cnn"
+    elif config == 4:
+        # BASELINE configs[4], one GPU's shard: x-vector trunk -> segment1 (no activation) -> L2 norm -> AP loss + C_avg
+        # (reference losses.py:25-52, metrics.py:51-103; SURVEY 8d: the head is this build's documented choice)
+        convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
+                 xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
+                 xvector.frame_layer(1500, 1, 1, name="frame5")]
+        w["model"] = SequentialTDNN((198, 40), convs, "stats", [DenseSpec("segment1", 512, relu=False)], output_activation=None, seed=0,
+                                    device=dev, compute_dtype=compute_dtype)
+        w["metric"] = SparseAverageDetectionCost(num_langs, np.linspace(-np.pi, 0, 100))
+        w["feature"], w["loss"] = dict(plan=plan, kind=nv.FEAT_LOGMEL), SparseAngularProximity(num_langs, 512)
+        w["flops_per_utt"], w["feature_bytes"] = FLOPS_PER_UTT_TRAIN_AP, BYTES_PER_UTT_FEATURE
+        w["cpu_cfg"] = dict(config="ap", what="log-mel + x-vector trunk + angular-proximity loss fwd/bwd + Adam")
+        w["workload"] = ("log-mel + x-vector trunk + angular-proximity loss + C_avg, 100 languages, bs=%d per GPU, %s (BASELINE configs[4], "
+                         "one GPU's shard of 8 x 512)" % (B, "bf16 compute / fp32 master weights" if bf16 else "fp32"))
+        w["metric_name"] = "utterances/sec (16kHz x 2s) log-mel + x-vector + angular-proximity train step"
+        w["model_name"] = "lidbox.models.xvector trunk + SparseAngularProximity"
+    else:
+        w["model"] = xvector.create((198, 40), num_langs, seed=0, device=dev, compute_dtype=compute_dtype)
+        w["feature"], w["loss"] = dict(plan=plan, kind=nv.FEAT_LOGMEL), "sparse_categorical_crossentropy"
+        w["flops_per_utt"], w["feature_bytes"] = FLOPS_PER_UTT_TRAIN, BYTES_PER_UTT_FEATURE
+        w["cpu_cfg"] = dict(config="xvector", what="log-mel + x-vector fwd/bwd + Adam")
+        w["workload"] = ("log-mel + x-vector 4-lang train step, bs=%d per GPU, %s (BASELINE configs[%d]%s)"
+                         % (B, "bf16 MFMA operands and bf16 activations / gradients in the Conv1D layers, fp32 accumulate, fp32 dense head and master weights" if bf16 else "fp32",
+                            1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""))
+        w["metric_name"] = "utterances/sec (16kHz x 2s) log-mel + x-vector train step"
+        w["model_name"] = "lidbox.models.xvector"
+    return w
+
+
+def resident_batches(n, B, world, rank, num_langs, dev):
+    """SURVEY 8d recipe, seeds 1234, 1235, ...: this rank's contiguous shard of each global batch, resident in HBM"""
     from lidbox_amd.testutil import synthetic_batch
-    from lidbox_amd.train import Trainer, init_distributed, shard_bounds
+    from lidbox_amd.train import shard_bounds
+    lo, hi = shard_bounds(B * world, rank, world)
+    out = []
+    for i in range(max(1, n)):
+        sig, labels = synthetic_batch(B * world, num_langs, SAMPLE_RATE, DURATION_S, seed=1234 + i)
+        out.append((torch.from_numpy(sig[lo:hi]).to(dev), torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)))
+        del sig
+    return out
+
+
+def timed_steps(trainer, batches, warmup, steps, sync_all):
+    """one untimed pass over every resident batch captures its graph (so that no capture lands in the timed region
+    whatever --warmup is), then the W warm-up steps, then exactly K timed steps between two barrier + synchronize pairs"""
+    first_loss = None
+    for xb, yb in batches:
+        l0 = trainer.train_step(xb, yb)
+        if first_loss is None:
+            first_loss = float(l0)
+    for i in range(warmup):
+        trainer.train_step(*batches[i % len(batches)])
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = trainer.train_step(*batches[i % len(batches)])
+    sync_all()
+    return time.perf_counter() - t0, first_loss, float(loss)
+
+
+def kernel_pass(nv, w, trainer, batch, nsteps):
+    """per-kernel HIP-event timing: instrumented eager pass over the same steps -> (roofline, kernels, roofline_feature)"""
+    from lidbox_amd.train import Trainer
+    bf16 = w["bf16"]
+    peak_mfma = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    eager = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=False)
+    eager.m, eager.v, eager.adam_state = trainer.m, trainer.v, trainer.adam_state
+    eager.train_step(*batch)
+    torch.cuda.synchronize()
+    with KernelTimer(nv, w["feature_bytes"]) as kt:
+        for _ in range(nsteps):
+            eager.train_step(*batch)
+        ks = kt.summary()
+    gemms = {k: v for k, v in ks.items() if k != "fused_feat512_kernel"}
+    dom = max(gemms, key=lambda k: gemms[k]["total_ms"])
+    d = gemms[dom]
+    ach = d["rate"] / 1e12
+    traffic = pmc_traffic(dom, tag=w["traffic_tag"])
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak_mfma, "unit": "TFLOP/s",
+                "frac": round(ach / peak_mfma, 4), "traffic": traffic,
+                "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
+                "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
+                "hbm_floor_us": round(1e6 * (traffic or 0) / (PEAK_HBM_GBS * 1e9), 2) or None,
+                "mfma_floor_us": round(1e6 * d["work_per_launch"] / (peak_mfma * 1e12), 2),
+                "bracket_overhead_us": round(1e3 * kt.bracket_overhead_ms, 2),
+                "note": "HIP-event brackets around the C-ABI calls that launch this instantiation (minus what an "
+                        "empty bracket measures), divided by the kernel launches they made "
+                        "(lidbox_gemm_last_launches; a bracket also covers the split-K reduce kernel where one "
+                        "follows); rocprofv3 --stats lists the same instantiation by this name; the two floors "
+                        "are PMC HBM bytes / 8 TB/s and flops / the MFMA peak per launch"}
+    gemm_ms = sum(v["total_ms"] for v in gemms.values()) / nsteps
+    gemm_flops = sum(v["rate"] * v["total_ms"] * 1e-3 for v in gemms.values()) / nsteps
+    kernels = {k: {"launches_per_step": v["launches"] // nsteps, "ms_per_step": round(v["total_ms"] / nsteps, 4),
+                   "rate": round(v["rate"] / (1e9 if k == "fused_feat512_kernel" else 1e12), 2),
+                   "rate_unit": "GB/s" if k == "fused_feat512_kernel" else "TFLOP/s"}
+               for k, v in ks.items()}
+    kernels["all_gemm"] = {"ms_per_step": round(gemm_ms, 4), "rate": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "rate_unit": "TFLOP/s"}
+    feat = None
+    f = ks.get("fused_feat512_kernel")
+    if f:
+        gbs = f["rate"] / 1e9
+        feat = {"kernel": "fused_feat512_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("fused_feat512_kernel", tag=w["traffic_tag"]),
+                "avg_launch_us": round(f["avg_us"], 2), "bytes_per_launch": int(f["work_per_launch"])}
+    del eager
+    return roofline, kernels, feat
+
+
+def secondary_run(nv, config, compute_dtype, B, dev, args):
+    """one more BASELINE configuration on this GPU, same step count, same timing protocol: an entry of `secondary`"""
+    from lidbox_amd.train import Trainer
+    w = make_workload(config, compute_dtype, B, 1, dev)
+    batches = resident_batches(args.resident_batches, B, 1, 0, w["num_langs"], dev)
+    trainer = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=not args.no_graph, num_buckets=1, metric=w["metric"])
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+    elapsed, first_loss, final_loss = timed_steps(trainer, batches, args.warmup, args.steps, sync_all)
+    if not np.isfinite(final_loss):
+        raise SystemExit("non-finite loss %r in secondary config %d" % (final_loss, config))
+    ms = 1e3 * elapsed / args.steps
+    value = B * args.steps / elapsed
+    out = {"config": {"workload": w["workload"], "baseline_config": config, "reference_model": w["model_name"], "per_gpu_batch": B,
+                      "languages": w["num_langs"], "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6)},
+           "metric": w["metric_name"], "dtype": "bf16" if w["bf16"] else "f32", "value": round(value, 1), "unit": "utterances/s",
+           "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup,
+           "step_tflops": round(value * w["flops_per_utt"] / 1e12, 2)}
+    if w["metric"] is not None:
+        out["config"]["c_avg"] = round(float(w["metric"].result()), 4)
+    if not args.no_kernel_timing:
+        rf, _, feat = kernel_pass(nv, w, trainer, batches[0], min(args.steps, 5))
+        out["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
+                                              "avg_launch_us", "gflop_per_launch")}
+        if feat:
+            out["roofline_feature"] = {k: feat[k] for k in ("kernel", "frac", "traffic", "avg_launch_us")}
+    del trainer, batches, w
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_launcher(args))
+    from lidbox_amd import _native as nv
+    from lidbox_amd.train import Trainer, init_distributed
     import torch.distributed as dist
 
     # RCCL prints a version banner to STDOUT when its first communicator comes up (during the warm-up steps); the
@@ -334,59 +495,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    # ---- synthetic global batches (SURVEY 8d recipe, seeds 1234, 1235, ...), this rank's contiguous shard of each
-    #      resident in HBM
     B = args.batch
     global_B = B * world
-    num_langs = 100 if args.config == 4 else NUM_LANGS
-    lo, hi = shard_bounds(global_B, rank, world)
-    batches = []
-    for i in range(max(1, args.resident_batches)):
-        sig, labels = synthetic_batch(global_B, num_langs, SAMPLE_RATE, DURATION_S, seed=1234 + i)
-        batches.append((torch.from_numpy(sig[lo:hi]).to(dev), torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)))
-        del sig
-    sig_d, lab_d = batches[0]
-
-    bf16 = args.compute_dtype == "bfloat16"
-    peak_mfma = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    plan = audio.get_plan(SAMPLE_RATE, 400, 160, device=dev)
-    metric = None
-    if args.config == 3:
-        # BASELINE configs[3]: MFCC(1:13) + CMVN -> cnn (reference cnn.py:25-45, tf_utils.py:180-185, features/__init__.py:22-32)
-        model = cnn.create((198, 12), num_langs, seed=0, device=dev, compute_dtype=args.compute_dtype)
-        feature, loss_spec = dict(plan=plan, kind=nv.FEAT_MFCC, cmvn=True), "sparse_categorical_crossentropy"
-        flops_per_utt, feature_bytes = FLOPS_PER_UTT_TRAIN_CNN, BYTES_PER_UTT_FEATURE_MFCC
-        cpu_cfg = dict(config="cnn", what="MFCC + CMVN + CNN classifier fwd/bwd + Adam")
-        workload = "MFCC(1:13)+CMVN + cnn 4-lang train step, bs=%d per GPU, %s (BASELINE configs[3])" % (B, "bf16 compute" if bf16 else "fp32")
-        metric_name = "utterances/sec (16kHz x 2s) MFCC+CMVN + CNN classifier train step"
-        model_name = "lidbox.models.cnn"
-    elif args.config == 4:
-        # BASELINE configs[4], one GPU's shard: x-vector trunk -> segment1 (no activation) -> L2 norm -> AP loss + C_avg
-        # (reference losses.py:25-52, metrics.py:51-103; SURVEY 8d: the head is this build's documented choice)
-        convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
-                 xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
-                 xvector.frame_layer(1500, 1, 1, name="frame5")]
-        model = SequentialTDNN((198, 40), convs, "stats", [DenseSpec("segment1", 512, relu=False)], output_activation=None, seed=0,
-                               device=dev, compute_dtype=args.compute_dtype)
-        metric = SparseAverageDetectionCost(num_langs, np.linspace(-np.pi, 0, 100))
-        feature, loss_spec = dict(plan=plan, kind=nv.FEAT_LOGMEL), SparseAngularProximity(num_langs, 512)
-        flops_per_utt, feature_bytes = FLOPS_PER_UTT_TRAIN_AP, BYTES_PER_UTT_FEATURE
-        cpu_cfg = dict(config="ap", what="log-mel + x-vector trunk + angular-proximity loss fwd/bwd + Adam")
-        workload = ("log-mel + x-vector trunk + angular-proximity loss + C_avg, 100 languages, bs=%d per GPU, %s (BASELINE configs[4], "
-                    "one GPU's shard of 8 x 512)" % (B, "bf16 compute / fp32 master weights" if bf16 else "fp32"))
-        metric_name = "utterances/sec (16kHz x 2s) log-mel + x-vector + angular-proximity train step"
-        model_name = "lidbox.models.xvector trunk + SparseAngularProximity"
-    else:
-        model = xvector.create((198, 40), num_langs, seed=0, device=dev, compute_dtype=args.compute_dtype)
-        feature, loss_spec = dict(plan=plan, kind=nv.FEAT_LOGMEL), "sparse_categorical_crossentropy"
-        flops_per_utt, feature_bytes = FLOPS_PER_UTT_TRAIN, BYTES_PER_UTT_FEATURE
-        cpu_cfg = dict(config="xvector", what="log-mel + x-vector fwd/bwd + Adam")
-        workload = ("log-mel + x-vector 4-lang train step, bs=%d per GPU, %s (BASELINE configs[%d]%s)"
-                    % (B, "bf16 MFMA operands and bf16 activations / gradients in the Conv1D layers, fp32 accumulate, fp32 dense head and master weights" if bf16 else "fp32",
-                       1 if world == 1 else 2, " workload at config 5's precision" if bf16 else ""))
-        metric_name = "utterances/sec (16kHz x 2s) log-mel + x-vector train step"
-        model_name = "lidbox.models.xvector"
-    trainer = Trainer(model, loss=loss_spec, feature=feature, use_graph=not args.no_graph, num_buckets=args.buckets, metric=metric)
+    w = make_workload(args.config, args.compute_dtype, B, world, dev)
+    bf16, num_langs, metric = w["bf16"], w["num_langs"], w["metric"]
+    batches = resident_batches(args.resident_batches, B, world, rank, num_langs, dev)
+    trainer = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=not args.no_graph, num_buckets=args.buckets, metric=metric)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -394,26 +508,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # one untimed pass over every resident batch captures its graph (so that no capture lands in the timed region
-    # whatever --warmup is), then the W warm-up steps, then exactly K timed steps
-    first_loss = None
-    for xb, yb in batches:
-        l0 = trainer.train_step(xb, yb)
-        if first_loss is None:
-            first_loss = float(l0)
-    for i in range(args.warmup):
-        trainer.train_step(*batches[i % len(batches)])
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = trainer.train_step(*batches[i % len(batches)])
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed_local, first_loss, final_loss = timed_steps(trainer, batches, args.warmup, args.steps, sync_all)
+    elapsed = elapsed_local
+    rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         elapsed = float(t.item())
-    final_loss = float(loss)
+        rank_ms = {"min": round(1e3 * float(tmin.item()) / args.steps, 4), "max": round(1e3 * elapsed / args.steps, 4)}
     if not np.isfinite(final_loss):
         raise SystemExit("non-finite loss %r" % final_loss)
 
@@ -429,8 +533,9 @@ def main():
     torch.cuda.synchronize(dev)
     step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
 
+    sync_active = trainer.sync.active
     result = {
-        "metric": metric_name,
+        "metric": w["metric_name"],
         "value": round(value, 1), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
@@ -438,73 +543,52 @@ def main():
                         "p90_ms": round(step_ms[min(len(step_ms) - 1, (9 * len(step_ms)) // 10)], 4), "steps": len(step_ms),
                         "note": "HIP events around each of K further graph-replayed steps (host launch gaps included); "
                                 "`value` / `ms_per_step` are the wall-clock mean of the timed region"},
-        "config": {"workload": workload, "baseline_config": args.config if world == 1 or args.config != 1 else 2,
-                   "reference_model": model_name,
+        "config": {"workload": w["workload"], "baseline_config": args.config if world == 1 or args.config != 1 else 2,
+                   "reference_model": w["model_name"],
                    "global_batch": global_B, "per_gpu_batch": B, "samples_per_utt": 32000, "frames": 198, "mel": 40,
-                   "languages": num_langs, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world, "grad_buckets": trainer.sync.num_buckets if world > 1 else 1,
+                   "languages": num_langs, "optimizer": "Adam(1e-3, eps=1e-7)", "parallelism": "dp%d" % world,
+                   "grad_buckets": trainer.sync.num_buckets if sync_active else 1,
+                   # what the timed steps did with the gradient exchange: none (one process) | in_graph (RCCL all-reduces
+                   # captured inside the step's hipGraph) | segmented (host-launched between graph segments) | eager
+                   "grad_sync": trainer.grad_sync_mode,
+                   "allreduce_bytes_per_step": 4 * int(w["model"].num_flat) if sync_active else 0,
                    "hip_graph": not args.no_graph, "resident_batches": len(batches),
                    "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6),
                    "loss_note": "SURVEY 8d's synthetic languages (one sine frequency each) are separable: the loss reaches ~0 within a "
                                 "few dozen Adam steps; every step still runs the full dense forward / backward / optimizer work"},
     }
+    if rank_ms is not None:
+        result["rank_ms_per_step"] = rank_ms
+        bounds = trainer.sync.bounds
+        result["config"]["allreduce_bucket_bytes"] = [4 * (b - a) for a, b in zip(bounds, bounds[1:])]
 
     sys.stdout.flush()
     # RCCL writes its banner through C stdio, which is fully buffered when stdout is not a terminal: flush the C
     # streams while descriptor 1 still points at stderr, or the banner would come out at exit, behind the JSON line
     import ctypes
     ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        if not args.no_kernel_timing and world == 1:
+            nsteps = min(args.steps, 10)
+            result["roofline"], result["kernels"], feat = kernel_pass(nv, w, trainer, batches[0], nsteps)
+            if feat:
+                result["roofline_feature"] = feat
+        # whole-step view of the same roofline: algorithmic train flops / step time
+        result["step_tflops"] = round(value / world * w["flops_per_utt"] / 1e12, 2)
+        if metric is not None:
+            result["config"]["c_avg"] = round(float(metric.result()), 4)
+        # the other single-GPU configurations of BASELINE.json in the same process (default invocation only): configs[3]
+        # in fp32 and one GPU's shard of configs[4] in bf16, same step count and timing protocol
+        if (world == 1 and args.config == 1 and not bf16 and not args.no_secondary and args.batch == PER_GPU_BATCH
+                and not os.environ.get("LIDBOX_FORCE_GRAD_SYNC")):
+            del trainer
+            torch.cuda.empty_cache()
+            result["secondary"] = [secondary_run(nv, 3, "float32", 256, dev, args), secondary_run(nv, 4, "bfloat16", 512, dev, args)]
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, batch=B, num_langs=num_langs, **w["cpu_cfg"])
     os.dup2(saved_stdout_fd, 1)
     os.close(saved_stdout_fd)
     if rank == 0:
-        # ---- per-kernel HIP-event timing: instrumented eager pass over the same steps
-        if not args.no_kernel_timing and world == 1:
-            eager = Trainer(model, loss=loss_spec, feature=feature, use_graph=False)
-            eager.m, eager.v, eager.adam_state = trainer.m, trainer.v, trainer.adam_state
-            eager.train_step(sig_d, lab_d)
-            torch.cuda.synchronize()
-            nsteps = min(args.steps, 10)
-            with KernelTimer(nv, feature_bytes) as kt:
-                for _ in range(nsteps):
-                    eager.train_step(sig_d, lab_d)
-                ks = kt.summary()
-            gemms = {k: v for k, v in ks.items() if k != "fused_feat512_kernel"}
-            dom = max(gemms, key=lambda k: gemms[k]["total_ms"])
-            d = gemms[dom]
-            ach = d["rate"] / 1e12
-            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
-                                  "peak": peak_mfma, "unit": "TFLOP/s",
-                                  "frac": round(ach / peak_mfma, 4), "traffic": pmc_traffic(dom, bf16),
-                                  "launches_per_step": d["launches"] // nsteps, "avg_launch_us": round(d["avg_us"], 2),
-                                  "gflop_per_launch": round(d["work_per_launch"] / 1e9, 3),
-                                  "hbm_floor_us": round(1e6 * (pmc_traffic(dom, bf16) or 0) / (PEAK_HBM_GBS * 1e9), 2) or None,
-                                  "mfma_floor_us": round(1e6 * d["work_per_launch"] / (peak_mfma * 1e12), 2),
-                                  "bracket_overhead_us": round(1e3 * kt.bracket_overhead_ms, 2),
-                                  "note": "HIP-event brackets around the C-ABI calls that launch this instantiation (minus what an "
-                                          "empty bracket measures), divided by the kernel launches they made "
-                                          "(lidbox_gemm_last_launches; a bracket also covers the split-K reduce kernel where one "
-                                          "follows); rocprofv3 --stats lists the same instantiation by this name; the two floors "
-                                          "are PMC HBM bytes / 8 TB/s and flops / the MFMA peak per launch"}
-            gemm_ms = sum(v["total_ms"] for v in gemms.values()) / nsteps
-            gemm_flops = sum(v["rate"] * v["total_ms"] * 1e-3 for v in gemms.values()) / nsteps
-            result["kernels"] = {k: {"launches_per_step": v["launches"] // nsteps, "ms_per_step": round(v["total_ms"] / nsteps, 4),
-                                     "rate": round(v["rate"] / (1e9 if k == "fused_feat512_kernel" else 1e12), 2),
-                                     "rate_unit": "GB/s" if k == "fused_feat512_kernel" else "TFLOP/s"}
-                                 for k, v in ks.items()}
-            result["kernels"]["all_gemm"] = {"ms_per_step": round(gemm_ms, 4),
-                                             "rate": round(gemm_flops / (gemm_ms * 1e-3) / 1e12, 2), "rate_unit": "TFLOP/s"}
-            f = ks.get("fused_feat512_kernel")
-            if f:
-                gbs = f["rate"] / 1e9
-                result["roofline_feature"] = {"kernel": "fused_feat512_kernel", "bound": "hbm", "achieved": round(gbs, 1),
-                                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                              "traffic": pmc_traffic("fused_feat512_kernel", bf16), "avg_launch_us": round(f["avg_us"], 2),
-                                              "bytes_per_launch": int(f["work_per_launch"])}
-        # whole-step view of the same roofline: algorithmic train flops / step time
-        result["step_tflops"] = round(value / world * flops_per_utt / 1e12, 2)
-        if metric is not None:
-            result["config"]["c_avg"] = round(float(metric.result()), 4)
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds, batch=B, num_langs=num_langs, **cpu_cfg)
         print(json.dumps(result), flush=True)
     if dist.is_available() and dist.is_initialized():
         if world > 1:

@@ -750,6 +750,11 @@ inline bool sk_extent_ok(const lidbox_rows_t& r, long cols) {
     return last * 4.0 < 4.0e9;
 }
 
+// the B operand's 32-bit lane offsets: B[N][K] (nt) spans N rows of ldb floats, B[K][N] (nn) K rows (+ the 16-row lane term)
+inline bool sk_b_extent_ok(bool b_kinner, int K, int N, long ldb) {
+    return ((double)(b_kinner ? N : K) + 16.0) * (double)ldb * 4.0 < 4.0e9;
+}
+
 void sk_set_lds_attr() {
     static const bool done = [] {
         (void)hipFuncSetAttribute((const void*)gemm_sk_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS_BYTES);
@@ -1032,7 +1037,8 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     float* P = (float*)ws;
 
     // persistent stream-K kernel (gemm_sk.h): aligned problems that fill the chip, workspace permitting
-    if (al && !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && aligned16(ws) && !sk_tuned_out(B_KINNER ? 1 : 0, M, N, K)) {
+    if (al && !getenv("LIDBOX_GEMM_PLAN") && !getenv("LIDBOX_GEMM_TILE") && aligned16(ws) && !sk_tuned_out(B_KINNER ? 1 : 0, M, N, K) &&
+        sk_b_extent_ok(B_KINNER, K, N, ldb)) {
         // the pipelined variant: its in-loop epilogue addresses C rows with at most one utterance wrap per 32-row block
         // (its drain stages the mask / old values of C through LDS-DMA: 16-byte aligned C rows, whole 16-byte column chunks)
         const bool has_mask_ = epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK;
@@ -1079,7 +1085,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
         }
     }
 
-    const bool dma_ok = al && sk_extent_ok(A, K) && (double)N * ldb * 4.0 < 4.0e9;
+    const bool dma_ok = al && sk_extent_ok(A, K) && sk_b_extent_ok(B_KINNER, K, N, ldb);
     // Tail quantisation: with W workgroups on 256 CUs the last partial round runs at the pace of a
     // full one (measured: the last 3 % of frame2's rows cost 21 % of its time).  When the main
     // decomposition is unsplit and leaves such a tail, launch it over the largest row prefix whose
@@ -1392,7 +1398,7 @@ extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lid
     TnPlan pl{};
     if (pair) {
         const size_t wsb = ws_nt ? ws_nt_bytes : 0;
-        const bool al_rows = rows_aligned(dY) && aligned16(W) && ldb % 4 == 0 && sk_extent_ok(dY, Co) && (double)N * ldb * 4.0 < 4.0e9 &&
+        const bool al_rows = rows_aligned(dY) && aligned16(W) && ldb % 4 == 0 && sk_extent_ok(dY, Co) && sk_b_extent_ok(true, Co, N, ldb) &&
                              aligned16(ws_nt);
         const bool al_tn = rows_aligned(X) && sk_extent_ok(X, K1) && aligned16(ws_tn);
         pair = al_rows && al_tn && pair_plan(M, Co, N, K1, wsb, ws_tn_bytes, &ch, &pl);

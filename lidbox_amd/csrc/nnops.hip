@@ -690,15 +690,16 @@ __global__ __launch_bounds__(256) void cavg_result_kernel(const float* __restric
 struct AdamState {
     long long step;
     float lr_t;
-    float lr_now;            // > 0: the learning rate of this step (a schedule, written by the host before the step: a captured
-                             // graph replays with it); 0: the `lr` argument
+    float lr_now;            // any non-zero BIT PATTERN: |lr_now| is the learning rate of this step (a schedule, written by the host
+                             // before the step: a captured graph replays with it; a scheduled rate of exactly 0 is written as -0.0f);
+                             // all bits zero (a freshly zeroed state): no schedule, the `lr` argument
 };
 
 // one thread: advance the step and publish the bias-corrected learning rate for this step
 __global__ void adam_prepare_kernel(AdamState* st, float lr, float b1, float b2) {
     const long long t = ++st->step;
     const double c = sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
-    const float base = st->lr_now > 0.f ? st->lr_now : lr;
+    const float base = __float_as_uint(st->lr_now) != 0u ? fabsf(st->lr_now) : lr;
     st->lr_t = (float)((double)base * c);
 }
 

@@ -400,7 +400,10 @@ class KerasWrapper:
                 if steps_per_epoch is not None and step >= int(steps_per_epoch):
                     break
                 xs, ys = self._stage(x, y)
-                losses.append((self.trainer.train_step(xs, ys).clone(), xs.shape[0]))
+                # data parallelism: the global batch of this step, exchanged on every rank at every step (rank-symmetric; the
+                # shards of a last, smaller batch need not shrink together)
+                gb = self.trainer.global_batch_of(xs.shape[0]) if self.trainer.sync.active else None
+                losses.append((self.trainer.train_step(xs, ys, global_batch=gb).clone(), xs.shape[0]))
                 n += xs.shape[0]
             logs = {"loss": float(sum(float(l) * b for l, b in losses) / max(1, n))}
             self.trainer.sync_state()        # data parallelism: the replicas' BatchNormalization running statistics, averaged before they are used

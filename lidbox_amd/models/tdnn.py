@@ -587,7 +587,8 @@ class SequentialTDNN:
             cin = Co
 
     def _fe_dropout_seed(self, i):
-        return (self.dropout_seed + 0xD1B54A32D192ED03 * (i + 1)) & (2 ** 64 - 1)
+        # dropout_seed_mix: the Trainer's per-rank offset under data parallelism (train.Trainer._rank_mix), 0 otherwise
+        return (self.dropout_seed + getattr(self, "dropout_seed_mix", 0) + 0xD1B54A32D192ED03 * (i + 1)) & (2 ** 64 - 1)
 
     def _dropout_step_ptr(self):
         """device int64 that keys the FrameLayer2D dropout masks: the Trainer points it at its Adam step (a fresh mask per

@@ -174,8 +174,7 @@ class Trainer:
         f32 = dict(dtype=torch.float32, device=self.device)
         self.m = torch.zeros(model.num_flat, **f32)
         self.v = torch.zeros(model.num_flat, **f32)
-        self.adam_state = torch.zeros(16, dtype=torch.uint8, device=self.device)     # {int64 step, float lr_t}
-        model.dropout_step = self.adam_state      # FrameLayer2D dropout masks follow the optimizer step (tdnn._dropout_step_ptr)
+        self.adam_state = torch.zeros(16, dtype=torch.uint8, device=self.device)     # {int64 step, float lr_t, float lr_now}
         bounds, splits = plan_buckets(model, num_buckets)
         self.splits = [] if splits is None else ([splits] if isinstance(splits, int) else list(splits))   # ascending conv indices
         self.split_conv = self.splits[-1] if self.splits else None
@@ -200,13 +199,32 @@ class Trainer:
         self._warming = False            # True during the pre-capture warm-up pass: streaming metrics must not count it
         self._graphs = {}
         self._static = {}
-        self._global_batch = {}          # local shard size -> sum of the ranks' shard sizes (data parallelism)
+        self._first_batch = None         # (local shard size, global batch) of the first step without an explicit global_batch
         self._step_global_batch = None   # what the caller of the running step passed (train_step(..., global_batch=))
+        self.grad_sync_mode = "none"     # what the last built step does with the gradient exchange: none | in_graph | segmented | eager
+        self._size_stream = None
+
+    @property
+    def adam_state(self):
+        return self._adam_state
+
+    @adam_state.setter
+    def adam_state(self, t):
+        """{int64 step, float lr_t, float lr_now} on the device.  Re-pointing it (bench.py shares one state between a graph
+        and an eager trainer) invalidates the host's view of it: the learning-rate schedule re-reads the device step."""
+        self._adam_state = t
+        self.__dict__.pop("_lr_view", None)
+        self.__dict__.pop("_host_step", None)
 
     # ---------------------------------------------------------------- pieces of a step
     def _forward_loss(self, ws, inputs, labels):
         lib, st = nv.lib, nv.current_stream()
         model = self.model
+        # FrameLayer2D dropout masks (tdnn._dropout_step_ptr / _fe_dropout_seed) follow THIS trainer's optimizer step and
+        # rank: bound when the step is issued / captured, not when a Trainer is constructed (a second Trainer on the same
+        # model -- bench.py's eager one -- must not re-key the first one's masks)
+        model.dropout_step = self.adam_state
+        model.dropout_seed_mix = self._rank_mix()
         in_ptr, in_bs, _, C = ws.input_target()              # act[0] behind the first Conv1D's causal zero rows, or the 2-D front-end's input
         if self.feature is not None:
             plan, kind = self.feature["plan"], self.feature["kind"]
@@ -264,30 +282,54 @@ class Trainer:
         if self.loss_kind == "nll" and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)
 
+    def _rank_mix(self):
+        """per-rank offset of every dropout seed under data parallelism (0 for a single process)"""
+        if not self.sync.active:
+            return 0
+        return (0x9E3779B97F4A7C15 * (self.sync.dist.get_rank(self.sync.group) + 1)) & (2 ** 63 - 1)
+
     def _dropout_seed(self):
         """the model's dropout seed, offset per data-parallel rank: the mask of local row b must not repeat on every rank"""
-        seed = self.model.dropout_seed
-        if self.sync.active:
-            seed = (seed + 0x9E3779B97F4A7C15 * (self.sync.dist.get_rank(self.sync.group) + 1)) & (2 ** 63 - 1)
-        return seed
+        return (self.model.dropout_seed + self._rank_mix()) & (2 ** 63 - 1)
 
     def _loss_scale(self, B):
         """d(mean loss)/d(per-example loss).  Under data parallelism the mean is over the GLOBAL batch, so that uneven
         shards (`shard_bounds` gives the remainder to the first ranks) still yield the gradient of the global-batch mean
-        after the all-reduce(sum).  The global batch is what the caller passed to `train_step(..., global_batch=)`;
-        without it the ranks' shard sizes are summed (one small all-reduce) the first time a LOCAL shard size is seen
-        and remembered per local size -- enough when every rank's shard size changes together (a smaller last batch
-        split by `shard_bounds` changes it on every rank or is passed explicitly).  The scale is a kernel argument, so
-        it is part of the key of a captured step."""
+        after the all-reduce(sum).  The global batch is what the caller passed to `train_step(..., global_batch=)`.
+        Without it the ranks' shard sizes are summed ONCE, at every rank's first step (a collective every rank enters:
+        rank-symmetric), and that sum stands for as long as this rank's shard size stays what it was then.  A shard size
+        that changes later needs the explicit argument: whether the other ranks' sizes changed too cannot be known without
+        a collective, and a collective only SOME ranks enter would pair with the others' gradient all-reduce (a hang or a
+        mismatched exchange) -- so that case raises instead.  `global_batch_of` is the rank-symmetric exchange callers use
+        per step (`KerasWrapper.fit` does).  The scale is a kernel argument, so it is part of the key of a captured step."""
         if not self.sync.active:
             return 1.0 / B
         if self._step_global_batch is not None:
             return 1.0 / self._step_global_batch
-        if B not in self._global_batch:
-            t = torch.tensor([B], dtype=torch.int64, device=self.device)
-            self.sync.dist.all_reduce(t, group=self.sync.group)
-            self._global_batch[B] = int(t.item())
-        return 1.0 / self._global_batch[B]
+        if self._first_batch is None:
+            self._first_batch = (B, self.global_batch_of(B))
+        if B != self._first_batch[0]:
+            raise ValueError("data parallelism: this rank's shard size changed from %d to %d and no global_batch was passed; "
+                             "pass train_step(..., global_batch=) (Trainer.global_batch_of(B) computes it on every rank)"
+                             % (self._first_batch[0], B))
+        return 1.0 / self._first_batch[1]
+
+    def global_batch_of(self, B):
+        """sum of the ranks' shard sizes for the coming step: ONE tiny all-reduce that EVERY rank must enter (call it on
+        every rank or on none).  It runs on its own stream so that the host waits for the exchange only, not for the
+        train steps still queued on the compute stream."""
+        if not self.sync.active:
+            return int(B)
+        if self.sync.cuda:
+            if self._size_stream is None:
+                self._size_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._size_stream):
+                t = torch.tensor([int(B)], dtype=torch.int64, device=self.device)
+                self.sync.dist.all_reduce(t, group=self.sync.group)
+                return int(t.item())
+        t = torch.tensor([int(B)], dtype=torch.int64)
+        self.sync.dist.all_reduce(t, group=self.sync.group)
+        return int(t.item())
 
     def _ap_buffers(self, ws, D):
         if not hasattr(ws, "ap_zn"):
@@ -324,15 +366,22 @@ class Trainer:
 
     def _set_lr(self):
         """learning-rate schedule (opt["lr_schedule"]: optimizer step, 0-based as Keras' `iterations` -> lr): the value of
-        the coming step goes into the device-side Adam state, where the captured optimizer kernels read it"""
+        the coming step goes into the device-side Adam state, where the captured optimizer kernels read it.  The step
+        index is the device's own counter, read once (and again whenever `adam_state` is re-pointed) and then advanced
+        on the host only after a step has been issued (`_lr_advance`), so a step that raises does not shift the schedule.
+        A scheduled rate of exactly 0 is written as -0.0: an all-zero word means "no schedule" to the kernel."""
         sched = self.opt.get("lr_schedule")
         if sched is None:
             return
-        if not hasattr(self, "_lr_view"):
+        if "_lr_view" not in self.__dict__:
             self._lr_view = self.adam_state[12:16].view(torch.float32)
             self._host_step = self.step_count
-        self._lr_view.fill_(float(sched(self._host_step)))
-        self._host_step += 1
+        lr = float(sched(self._host_step))
+        self._lr_view.fill_(lr if lr != 0.0 else -0.0)
+
+    def _lr_advance(self):
+        if "_host_step" in self.__dict__:
+            self._host_step += 1
 
     def _adam(self):
         o = self.opt
@@ -407,7 +456,11 @@ class Trainer:
                 torch.cuda.synchronize(self.device)
                 try:
                     entry["graphs"] = (self._capture(whole, with_collectives=True).replay,)
-                except Exception as exc:      # a backend build that cannot capture its collectives: host-launched ones instead
+                    self.grad_sync_mode = "in_graph"
+                except RuntimeError as exc:   # a backend build that cannot capture its collectives (HIP / RCCL errors surface as RuntimeError)
+                    if os.environ.get("LIDBOX_REQUIRE_INGRAPH_SYNC"):
+                        raise RuntimeError("LIDBOX_REQUIRE_INGRAPH_SYNC is set and capturing the gradient all-reduces into the "
+                                           "step graph failed: %s" % (exc,)) from exc
                     import warnings
                     warnings.warn("capturing the gradient all-reduces into the step graph failed (%s: %s); falling back to "
                                   "host-launched collectives between graph segments" % (type(exc).__name__, exc))
@@ -415,13 +468,22 @@ class Trainer:
                     torch.cuda.synchronize(self.device)
                     adam_seg = self._capture(segs[-1]).replay if os.environ.get("LIDBOX_ADAM_GRAPH") else segs[-1]
                     entry["graphs"] = tuple(self._capture(seg).replay for seg in segs[:-1]) + (adam_seg,)
+                    self.grad_sync_mode = "segmented"
             elif self.sync.active:
                 # the optimizer segment is two small kernels behind the last collective: launched directly unless
                 # LIDBOX_ADAM_GRAPH is set (a graph launch costs more than it saves there)
+                if os.environ.get("LIDBOX_REQUIRE_INGRAPH_SYNC"):
+                    raise RuntimeError("LIDBOX_REQUIRE_INGRAPH_SYNC is set but the gradient exchange of this step cannot be captured "
+                                       "(backend %r, LIDBOX_SEGMENTED_SYNC=%r)" % (self.sync.dist.get_backend(self.sync.group),
+                                                                                  os.environ.get("LIDBOX_SEGMENTED_SYNC")))
                 adam_seg = self._capture(segs[-1]).replay if os.environ.get("LIDBOX_ADAM_GRAPH") else segs[-1]
                 entry["graphs"] = tuple(self._capture(seg).replay for seg in segs[:-1]) + (adam_seg,)
+                self.grad_sync_mode = "segmented"
             else:
                 entry["graphs"] = (self._capture(lambda: [seg() for seg in segs]).replay,)
+                self.grad_sync_mode = "none"
+        else:
+            self.grad_sync_mode = "eager" if self.sync.active else "none"
         return entry
 
     # ---------------------------------------------------------------- public API
@@ -459,6 +521,7 @@ class Trainer:
                         self.sync.launch(nb - 1 - k)              # bucket (nb-1-k) is complete after stage k
                 self.sync.wait()
                 run[-1]()                                         # Adam
+            self._lr_advance()
             if self.sync_state_every_step:
                 self.sync_state()
             return ws.loss[0]

@@ -65,7 +65,7 @@ _WORKER = textwrap.dedent("""
     cavg, per_th = metric.result(return_per_threshold=True)
     if rank == 0:
         np.savez(out_path, flat=model.flat.cpu().numpy(), losses=l.numpy(), cavg=float(cavg), per_th=per_th.cpu().numpy(),
-                 tp=metric.tp.cpu().numpy(), fn=metric.fn.cpu().numpy())
+                 tp=metric.tp.cpu().numpy(), fn=metric.fn.cpu().numpy(), grad_sync=tr.grad_sync_mode)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -104,6 +104,7 @@ def test_two_rank_step_equals_single_process_step(tmp_path, use_graph, num_bucke
     script.write_text(_WORKER % {"root": ROOT})
     single = _run(script, 1, use_graph, tmp_path / "single.npz", num_buckets)
     dual = _run(script, 2, use_graph, tmp_path / "dual.npz", num_buckets)
+    assert str(dual["grad_sync"]) == ("segmented" if use_graph else "eager") and str(single["grad_sync"]) == "none"
     # same loss trajectory and the same weights after 3 Adam steps, to fp32 summation-order tolerance
     assert np.allclose(single["losses"], dual["losses"], rtol=1e-5, atol=1e-6), (single["losses"], dual["losses"])
     # Adam normalises each update to ~lr, so a weight whose gradient is ~0 can legitimately flip sign on a
@@ -125,7 +126,7 @@ def test_rccl_backend_between_graph_segments_world1():
     so init_process_group('nccl'), the side-stream all_reduce launches and the three-segment hipGraph replay are
     all exercised exactly as in the N-GPU bench (the reduction itself is the identity at world 1)."""
     import json
-    env = dict(os.environ, LIDBOX_FORCE_GRAD_SYNC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LIDBOX_FORCE_GRAD_SYNC="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LIDBOX_REQUIRE_INGRAPH_SYNC="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
            "--batch", "32", "--no-cpu-baseline", "--no-kernel-timing"]
@@ -136,6 +137,22 @@ def test_rccl_backend_between_graph_segments_world1():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["steps"] == 5 and r["value"] > 0
     assert np.isfinite(r["config"]["final_loss"])
+    # the capture of the collectives must have SUCCEEDED (LIDBOX_REQUIRE_INGRAPH_SYNC turns the segmented fallback into an
+    # error) and the line says which form the timed steps used
+    assert r["config"]["grad_sync"] == "in_graph", r["config"]
+    assert r["config"]["grad_buckets"] == 3 and r["config"]["allreduce_bytes_per_step"] == 4 * 4510176
+
+
+def test_segmented_sync_is_refused_when_in_graph_is_required():
+    """LIDBOX_REQUIRE_INGRAPH_SYNC=1 + a step that cannot capture its collectives (forced segmented form): an error, not a
+    silently slower run"""
+    env = dict(os.environ, LIDBOX_FORCE_GRAD_SYNC="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LIDBOX_REQUIRE_INGRAPH_SYNC="1",
+               LIDBOX_SEGMENTED_SYNC="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--no-cpu-baseline", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode != 0 and "LIDBOX_REQUIRE_INGRAPH_SYNC" in (p.stdout + p.stderr)
 
 
 def test_bench_line_contract_single_process():
@@ -149,8 +166,16 @@ def test_bench_line_contract_single_process():
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_feature", "kernels"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_feature", "kernels", "secondary"):
         assert key in r, key
+    assert r["config"]["grad_sync"] == "none" and r["config"]["allreduce_bytes_per_step"] == 0
+    # the other two single-GPU configurations ride in the same line: configs[3] fp32 and one GPU's shard of configs[4] in bf16
+    sec = r["secondary"]
+    assert [x["config"]["baseline_config"] for x in sec] == [3, 4] and [x["dtype"] for x in sec] == ["f32", "bf16"]
+    for x in sec:
+        assert x["value"] > 0 and x["steps"] == 4 and np.isfinite(x["config"]["final_loss"])
+        assert abs(x["value"] - x["config"]["per_gpu_batch"] * 1e3 / x["ms_per_step"]) <= 1e-3 * x["value"]
+        assert 0 < x["roofline"]["frac"] < 1 and x["roofline"]["bound"] == "mfma"
     assert r["unit"] == "utterances/s" and r["dtype"] == "f32" and r["scaling"] == "weak" and r["vs_baseline"] is None
     assert r["config"]["global_batch"] == 256 and "model" not in r["config"]
     rf = r["roofline"]
@@ -181,7 +206,7 @@ def test_two_rccl_ranks_on_two_gpus_bench_line():
     """lights up on a multi-GPU box: `python bench.py --gpus 2` with NO launcher re-executes itself under
     torch.distributed.run, two ranks all-reduce over RCCL / xGMI between the hipGraph segments, one JSON line comes back"""
     import json
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LIDBOX_REQUIRE_INGRAPH_SYNC="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "64",
            "--no-cpu-baseline", "--no-kernel-timing"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -190,6 +215,7 @@ def test_two_rccl_ranks_on_two_gpus_bench_line():
     assert len(lines) == 1, lines
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 128 and r["config"]["parallelism"] == "dp2" and r["value"] > 0
+    assert r["config"]["grad_sync"] == "in_graph" and r["rank_ms_per_step"]["min"] <= r["rank_ms_per_step"]["max"]
 
 
 @needs_two_gpus
@@ -205,6 +231,7 @@ def test_two_rccl_ranks_step_equals_single_process_step(tmp_path):
     assert np.allclose(single["losses"], dual["losses"], rtol=1e-5, atol=1e-6)
     diff = np.abs(single["flat"] - dual["flat"])
     assert np.median(diff) <= 1e-6 and diff.max() <= 3 * 2e-3 + 1e-6
+    assert str(dual["grad_sync"]) == "in_graph" and str(single["grad_sync"]) == "none"
 
 
 _WORKER_TWO_SHAPES = textwrap.dedent("""
@@ -261,3 +288,45 @@ def test_global_batch_changes_while_one_ranks_shard_does_not(tmp_path, use_graph
     assert np.allclose(single["losses"], dual["losses"], rtol=2e-5, atol=1e-6), (single["losses"], dual["losses"])
     diff = np.abs(single["flat"] - dual["flat"])
     assert np.median(diff) <= 1e-6 and (diff > 2e-4).mean() <= 2e-3 and diff.max() <= 4 * 2e-3 + 1e-6
+
+
+_WORKER_SHARD_CHANGE = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, %(root)r)
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer, init_distributed
+    os.environ["LOCAL_RANK"] = "0"
+    rank, world, _ = init_distributed(backend="gloo")
+    torch.cuda.set_device(0)
+    sig, y = synthetic_batch(6, num_labels=4, duration_s=0.5)
+    sd, yd = torch.from_numpy(sig).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+    model = xvector.create((48, 40), 4, seed=0)
+    tr = Trainer(model, feature=dict(plan=audio.get_plan(16000, 400, 160), kind=nv.FEAT_LOGMEL), use_graph=False)
+    assert tr.sync.active and tr.global_batch_of(5) == 5
+    tr.train_step(sd, yd)                                  # first step: shard sizes summed once, on every rank
+    tr.train_step(sd[:4].contiguous(), yd[:4].contiguous(), global_batch=4)      # explicit: fine
+    try:
+        tr.train_step(sd[:4].contiguous(), yd[:4].contiguous())                  # a changed shard size without it: refused
+    except ValueError as e:
+        assert "global_batch" in str(e)
+        print("REFUSED")
+    tr.train_step(sd, yd)                                  # the first size still works
+    torch.cuda.synchronize()
+""")
+
+
+def test_changed_shard_size_without_global_batch_is_refused(tmp_path):
+    """under data parallelism a collective that only SOME ranks enter (the old per-new-local-size exchange) would
+    pair with the other ranks' gradient all-reduce; the shard sizes are summed once at the first step, and a later change
+    of this rank's size without `global_batch=` raises instead"""
+    script = tmp_path / "worker_shard_change.py"
+    script.write_text(_WORKER_SHARD_CHANGE % {"root": ROOT})
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), LIDBOX_FORCE_GRAD_SYNC="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "REFUSED" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

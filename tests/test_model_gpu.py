@@ -477,3 +477,23 @@ def test_learning_rate_schedule_reaches_the_captured_optimizer():
     for _ in range(3):
         t.train_step(xd, yd)
     assert float((w1 - w0).abs().max()) > 5e-4 and float((m.flat - w1).abs().max()) < 1e-9
+    # a schedule that returns EXACTLY 0 freezes the weights bit for bit (a zero rate must not fall back to the
+    # constant `lr` argument -- the host writes it as -0.0, an all-zero word means "no schedule")
+    pz = lr_schedule_from_config({"cls": "PiecewiseConstantDecay", "kwargs": {"boundaries": [0], "values": [1e-3, 0.0]}})
+    for use_graph in (False, True):
+        m = xvector.create((50, 24), 5, seed=7)
+        t = Trainer(m, use_graph=use_graph, optimizer=dict(lr_schedule=pz))
+        t.train_step(xd, yd)
+        w1 = m.flat.clone()
+        for _ in range(2):
+            t.train_step(xd, yd)
+        assert torch.equal(m.flat, w1) and t.step_count == 3
+    # the schedule follows the DEVICE step when the optimizer state is re-pointed (bench.py shares one state between two trainers)
+    m = xvector.create((50, 24), 5, seed=7)
+    t1 = Trainer(m, use_graph=False, optimizer=dict(lr_schedule=pz))
+    t1.train_step(xd, yd)
+    t2 = Trainer(m, use_graph=False, optimizer=dict(lr_schedule=pz))
+    t2.m, t2.v, t2.adam_state = t1.m, t1.v, t1.adam_state
+    w1 = m.flat.clone()
+    t2.train_step(xd, yd)                      # device step 1 -> the schedule's second value (0), not its first
+    assert torch.equal(m.flat, w1)
