@@ -97,8 +97,9 @@ class KernelTimer:
     i.e. by the names rocprofv3 --stats reports."""
 
     ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_gemm_nt_tn": 3, "lidbox_extract_features_fwd": -1,
+             "lidbox_gemm_tn_partial": 4, "lidbox_gemm_nt_carry": 5, "lidbox_gemm_nt_tn_carry": 6,
              "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13,
-             "lidbox_gemm_bf16s_tn": 14}
+             "lidbox_gemm_bf16s_tn": 14, "lidbox_gemm_bf16s_nt_carry": 15, "lidbox_gemm_bf16s_tn_partial": 16}
 
     def __init__(self, nv, feature_bytes=BYTES_PER_UTT_FEATURE):
         self.nv = nv
@@ -117,6 +118,14 @@ class KernelTimer:
     def _classify(self, name, args):
         import ctypes
         kind = self.ENTRY[name]
+        if kind == 4:          # (A, Bd, C, ldc, K1, N, accumulate, bias_grad, ws, ws_bytes, job, stream): lidbox_gemm_tn's arguments + job
+            kind = 2
+        elif kind == 5:        # (A, B, ldb, C, K, N, epi, aux, ws, ws_bytes, job, stream): lidbox_gemm_nt's arguments + job
+            kind = 1
+        elif kind == 15:       # lidbox_gemm_bf16s_nt's arguments + jobs
+            kind = 13
+        elif kind == 16:       # lidbox_gemm_bf16s_tn's arguments + job
+            kind = 14
         if kind < 0:
             return "fused_feat512_kernel", float(args[3]) * self.feature_bytes
         if kind == 13:                                        # bf16-storage kernel: (A16, B16, ldb, C, C16, K, N, ...)
@@ -149,16 +158,26 @@ class KernelTimer:
 
             def wrapper(*args, _n=name, _o=orig):
                 import ctypes
-                if self.ENTRY[_n] == 3:
-                    # (dY, W, ldb, dX, Co, N, epi, aux, ws_nt, ws_nt_bytes, X, dW, ldc, K1, accumulate, bias_grad, ws_tn, ws_tn_bytes, stream)
+                if self.ENTRY[_n] in (3, 6):
+                    # (dY, W, ldb, dX, Co, N, epi, aux, ws_nt, ws_nt_bytes, X, dW, ldc, K1, accumulate, bias_grad, ws_tn, ws_tn_bytes,
+                    #  [jobs, njobs, job_out,] stream)
                     dY, Co, N, K1 = args[0], args[4], args[5], args[13]
+                    stream = args[-1]
+                    jobs, njobs = (args[18], args[19]) if self.ENTRY[_n] == 6 else (None, 0)
                     M = dY.batch * dY.rows_per_batch
                     if not self.nv.lib.lidbox_gemm_plan_is_pair(M, Co, N, K1, int(args[9] or 0), int(args[17] or 0)):
-                        # the library would issue exactly these two calls: bracket them one by one
-                        rc = self.nv.lib.lidbox_gemm_tn(args[10], dY, args[11], args[12], K1, Co, args[14], args[15], args[16], args[17], args[18])
+                        # the library would issue exactly these two calls (the wgrad GEMM, then the dgrad launch that carries the
+                        # pending reduces and the wgrad's own in its leading workgroups): bracket them one by one
+                        both = (self.nv.ReduceJob * 2)()
+                        for q in range(njobs):
+                            both[q] = jobs[q]
+                        rc = self.nv.lib.lidbox_gemm_tn_partial(args[10], dY, args[11], args[12], K1, Co, args[14], args[15], args[16], args[17],
+                                                                ctypes.cast(ctypes.addressof(both) + njobs * ctypes.sizeof(self.nv.ReduceJob),
+                                                                            ctypes.POINTER(self.nv.ReduceJob)), stream)
                         if rc:
                             return rc
-                        return self.nv.lib.lidbox_gemm_nt(dY, args[1], args[2], args[3], Co, N, args[6], args[7], args[8], args[9], args[18])
+                        return self.nv.lib.lidbox_gemm_nt_carry(dY, args[1], args[2], args[3], Co, N, args[6], args[7], args[8], args[9],
+                                                                ctypes.cast(both, ctypes.POINTER(self.nv.ReduceJob)), njobs + 1, stream)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = _o(*args)
@@ -171,13 +190,13 @@ class KernelTimer:
                 rc = _o(*args)
                 e1.record()
                 nk = 1
-                if self.ENTRY[_n] in (0, 1, 2):           # kernels of the named instantiation this call launched
+                if self.ENTRY[_n] in (0, 1, 2, 4, 5):     # kernels of the named instantiation this call launched
                     out3 = (ctypes.c_int * 3)()
                     self.nv.check(self.nv.lib.lidbox_gemm_last_launches(out3))
                     nk = max(1, out3[0])
                     if self.nv.lib.lidbox_gemm_last_family() == 1:     # the LDS-DMA instantiation of the same tile shape
                         key = key.replace("gemm_rows_kernel<", "gemm_rows_dma_kernel<").replace("gemm_tn_kernel<", "gemm_tn_dma_kernel<")
-                elif self.ENTRY[_n] == 13:
+                elif self.ENTRY[_n] in (13, 15):
                     out3 = (ctypes.c_int * 3)()
                     self.nv.check(self.nv.lib.lidbox_gemm_bf16s_last_variant(out3))
                     if out3[0]:

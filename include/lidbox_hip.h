@@ -218,12 +218,54 @@ int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1
                    int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                    lidbox_stream_t stream);
 
+/* ---- carried reduce: a wgrad's fixed-order slice sum inside a LATER GEMM launch -----------------------------------------
+ * lidbox_gemm_tn = a GEMM over M slices + a bandwidth-bound reduce launch that sums the slices in order.  The two halves
+ * are also callable on their own, so that the reduce can run in the LEADING WORKGROUPS of the next MFMA-bound launch on the
+ * same stream (the layer's dgrad) instead of between two launches; every element still adds its slices in the order
+ * 0 .. splits-1, so the results are bit-identical to lidbox_gemm_tn whoever runs the job.
+ *   lidbox_gemm_tn_partial  the GEMM only; *job describes the pending reduce (the workspace holds the slices and must stay
+ *                           untouched until the job has run; job->nblocks == 0: nothing pending -- unaligned operands had
+ *                           their scalar reduce launched by this call)
+ *   lidbox_gemm_nt_carry    lidbox_gemm_nt + up to two pending `jobs` (NULL / empty ones: plain lidbox_gemm_nt): in the same
+ *                           launch when that is an LDS-DMA tile launch (16-byte aligned operands; one leading workgroup per
+ *                           CU, shared in proportion to the jobs' bytes), else as one launch of their own behind it;
+ *                           LIDBOX_GEMM_NO_CARRY=1 forces the latter (A/B aid); `workspace` must not hold a job's slices
+ *   lidbox_gemm_nt_tn_carry lidbox_gemm_nt_tn that carries one pending job of an EARLIER layer in its launch and, where
+ *                           its own wgrad reduce cannot run inside its launches (the one-launch pair), hands that out as
+ *                           *job_out for a later carry call (job_out == NULL: launched here)
+ *   lidbox_reduce_jobs_run  up to two jobs as one launch of their own
+ *   lidbox_gemm_last_carried  number of jobs the calling thread's most recent *_carry call ran inside its GEMM launch
+ * Reference: the wgrad / dgrad of Conv1D and Dense, lidbox/models/xvector.py:38-43,53-64 under Keras' fit (keras_utils.py:198-203). */
+typedef struct lidbox_reduce_job {
+    const float* partials;        /* [splits][n] */
+    const float* bias_partials;   /* [splits][N] or NULL */
+    float* C;
+    float* bias_grad;             /* or NULL */
+    long n, ldc;                  /* n = K1 * N elements of C, rows of N at stride ldc */
+    int splits, N, accumulate;
+    unsigned nblocks;             /* workgroups of a stand-alone launch; 0 = nothing to do */
+} lidbox_reduce_job_t;
+int lidbox_gemm_tn_partial(lidbox_rows_t A, lidbox_rows_t Bm, float* C, long ldc, int K1, int N, int accumulate,
+                           float* bias_grad, void* workspace, size_t workspace_bytes, lidbox_reduce_job_t* job,
+                           lidbox_stream_t stream);
+int lidbox_gemm_nt_carry(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N, int epilogue,
+                         const float* aux, void* workspace, size_t workspace_bytes, const lidbox_reduce_job_t* jobs, int njobs,
+                         lidbox_stream_t stream);
+int lidbox_gemm_nt_tn_carry(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
+                            const float* aux, void* ws_nt, size_t ws_nt_bytes, lidbox_rows_t X, float* dW, long ldc, int K1,
+                            int accumulate, float* bias_grad, void* ws_tn, size_t ws_tn_bytes,
+                            const lidbox_reduce_job_t* jobs, int njobs, lidbox_reduce_job_t* job_out, lidbox_stream_t stream);
+int lidbox_reduce_jobs_run(const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream);
+int lidbox_gemm_last_carried(void);
+
 /* A layer's dgrad and wgrad in one call -- both read the output gradient dY [M, Co]:
  *     dX rows = epilogue(dY . W^T)        exactly lidbox_gemm_nt(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ...)
  *     dW [K1, Co] (ldc) (+)= X^T . dY     exactly lidbox_gemm_tn(X, dY, dW, ldc, K1, Co, accumulate, bias_grad, ws_tn, ...)
  * Small problems (the dense head: M = batch rows, both planned as 64 x 64 tiles that fit the chip at once) go out as ONE
- * kernel launch followed by their reduces; everything else is the two calls, wgrad first.  Bit-identical to the two calls
- * either way.  The two workspaces must not overlap (the two GEMMs run concurrently). */
+ * kernel launch followed by their reduces; everything else is lidbox_gemm_tn_partial + lidbox_gemm_nt_carry: the wgrad GEMM,
+ * then the dgrad launch with the wgrad's reduce in its leading workgroups.  Bit-identical to the two plain calls either way.
+ * The two workspaces should not overlap (one launch: the two GEMMs run concurrently; two launches: the slices wait in
+ * ws_tn while the dgrad uses ws_nt -- a shared workspace falls back to the plain sequence). */
 /* 1 when lidbox_gemm_nt_tn would launch this pair (16-byte aligned operands) as one kernel (profiling tools). */
 int lidbox_gemm_plan_is_pair(long M, int Co, int N, int K1, size_t ws_nt_bytes, size_t ws_tn_bytes);
 int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
@@ -276,6 +318,18 @@ size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N);
 int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ldc, int K1, int N,
                          int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
                          lidbox_stream_t stream);
+/* The carried-reduce forms of the storage kernels (see lidbox_gemm_tn_partial / lidbox_gemm_nt_carry above: same contract,
+ * same bit-identical sums; jobs of either family may be carried -- the dense head's wgrads run on the fp32 family):
+ *   lidbox_gemm_bf16s_tn_partial   the wgrad GEMM only, *job = its pending fixed-order slice sum
+ *   lidbox_gemm_bf16s_nt_carry     lidbox_gemm_bf16s_nt whose (first) launch runs up to two pending jobs in its leading workgroups
+ *   lidbox_gemm_bf16s_last_carried jobs the calling thread's most recent lidbox_gemm_bf16s_nt_carry ran inside its launch */
+int lidbox_gemm_bf16s_tn_partial(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ldc, int K1, int N, int accumulate,
+                                 float* bias_grad, void* workspace, size_t workspace_bytes, lidbox_reduce_job_t* job,
+                                 lidbox_stream_t stream);
+int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16, int K, int N,
+                               int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                               const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream);
+int lidbox_gemm_bf16s_last_carried(void);
 /* All bf16 weight shadows of a model in ONE launch (once per train step, after the optimizer): flat16[i] = bf16(flat[i]) for
  * the n parameters, and for each listed row-major [rows][cols] matrix at flat + offset a bf16 image at dst with its own
  * leading dimension: transposed ([cols][rows]: a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand

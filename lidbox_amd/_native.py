@@ -32,6 +32,13 @@ class Rows(C.Structure):
                 ("batch", C.c_int), ("rows_per_batch", C.c_int)]
 
 
+class ReduceJob(C.Structure):
+    """lidbox_reduce_job_t: a wgrad's pending fixed-order slice sum (lidbox_gemm_tn_partial -> lidbox_gemm_nt_carry)"""
+    _fields_ = [("partials", C.c_void_p), ("bias_partials", C.c_void_p), ("C", C.c_void_p), ("bias_grad", C.c_void_p),
+                ("n", C.c_long), ("ldc", C.c_long), ("splits", C.c_int), ("N", C.c_int), ("accumulate", C.c_int),
+                ("nblocks", C.c_uint)]
+
+
 class WeightShadow(C.Structure):
     """lidbox_weight_shadow_t"""
     _fields_ = [("offset", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("dst", C.c_void_p), ("ld_dst", C.c_long),
@@ -87,6 +94,12 @@ _SIGS = {
     "lidbox_gemm_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_plan_is_pair": (_i, [_l, _i, _i, _i, _sz, _sz]),
     "lidbox_gemm_nt_tn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, Rows, _vp, _l, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_tn_partial": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),
+    "lidbox_gemm_nt_carry": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _i, _vp]),
+    "lidbox_gemm_nt_tn_carry": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, Rows, _vp, _l, _i, _i, _vp, _vp, _sz,
+                                     C.POINTER(ReduceJob), _i, C.POINTER(ReduceJob), _vp]),
+    "lidbox_reduce_jobs_run": (_i, [C.POINTER(ReduceJob), _i, _vp]),
+    "lidbox_gemm_last_carried": (_i, []),
     "lidbox_gemm_bf16_rows_workspace": (_sz, [_l, _i, _i]),
     "lidbox_gemm_bf16_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_bf16_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -130,6 +143,9 @@ _SIGS = {
     "lidbox_gemm_bf16s_tn_workspace": (_sz, [_i, _i, _i]),
     "lidbox_refresh_bf16_weights": (_i, [_vp, _vp, _l, C.POINTER(WeightShadow), _i, _vp]),
     "lidbox_gemm_bf16s_tn": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "lidbox_gemm_bf16s_tn_partial": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),
+    "lidbox_gemm_bf16s_nt_carry": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _i, _vp]),
+    "lidbox_gemm_bf16s_last_carried": (_i, []),
     "lidbox_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
     "lidbox_transpose_f32_to_bf16": (_i, [_vp, _i, _i, _l, _vp, _l, _vp]),
     "lidbox_scale": (_i, [_vp, _l, _f, _vp]),

@@ -44,6 +44,7 @@
 
 #include "gemm_shared.h"
 #include "gemm_sk.h"
+#include <string.h>
 #include "gemm_dma.h"
 #include "gemm_tuned.h"
 
@@ -808,6 +809,7 @@ struct RowsChoice {
 thread_local int g_last_launches[3] = {0, 0, 0};
 thread_local int g_last_family = 0;       // 0 register-staged kernels of this file, 1 LDS-DMA (gemm_dma.h), 2 stream-K (gemm_sk.h)
 thread_local int g_first_tile[2] = {0, 0};
+thread_local int g_last_carried = 0;      // whether the most recent lidbox_gemm_nt_carry ran its job inside the GEMM launch
 
 // Cost model in "K-steps of a 128x128 tile at the full fp32 MFMA rate" (~1 us each per CU).
 // A CU's resident workgroups share its four matrix pipes, so a CU's time is the SUM of its
@@ -921,10 +923,24 @@ inline int dma_mode() {
 
 template <int BM, int BN, bool B_KINNER>
 void launch_rows_dma_t(dim3 grid, hipStream_t st, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, float* P, long m_beg, long m_end,
-                       int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps, const DmaStream& sp) {
+                       int K, int N, int epi, const float* aux, int tiles_n, unsigned ntiles, int kps, const DmaStream& sp, const ReduceJobs& rj) {
     hipLaunchKernelGGL((gemm_rows_dma_kernel<BM, BN, B_KINNER>), grid, dim3(256), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi,
-                       aux, tiles_n, ntiles, kps, sp);
+                       aux, tiles_n, ntiles, kps, sp, rj);
 }
+
+// workgroups the carried reduces of a GEMM launch share (pack_carry).  Measured per launch at bs 256 (profiles/
+// r04_carry_blocks.txt): 64 .. 160 workgroups hide the sums beside the tiles (-6 .. -10 us per layer against reduce launches),
+// 256 and more delay the tiles by most of what the reduce takes -- their loads starve the tiles' operand DMA.
+// LIDBOX_GEMM_CARRY_BLOCKS overrides (A/B aid).
+inline long carry_cap() {
+    if (const char* e = getenv("LIDBOX_GEMM_CARRY_BLOCKS")) { const long v = atol(e); if (v >= 8) return v; }
+    return 96;
+}
+struct Carry {
+    const ReduceJob* jobs = nullptr;
+    int njobs = 0;
+    bool carried = false;           // set by the launch that took the jobs
+};
 
 // Streamed remainder of an unsplit decomposition (gemm_dma.h: DmaStream): g pieces per tile of the last partial round,
 // chosen for the fewest rounds of pieces (in tile times), pieces of at least DMA_STREAM_MIN_STEPS K steps.
@@ -964,7 +980,7 @@ inline DmaStreamPlan dma_stream_plan(int bm, int bn, long M, int N, int K) {
 template <bool B_KINNER>
 int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, long ldb, RowsOutD Co, long m_beg,
                       long m_end, int K, int N, int epi, const float* aux, float* P, hipStream_t st, bool dma_ok = false,
-                      const DmaStreamPlan* stream = nullptr, void* ws = nullptr) {
+                      const DmaStreamPlan* stream = nullptr, void* ws = nullptr, Carry* carry = nullptr) {
     const long Msub = m_end - m_beg;
     if (Msub <= 0) return LIDBOX_OK;
     const int tiles_n = (int)lbx_cdiv(N, ch.bn);
@@ -975,10 +991,15 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
     if (ch.splits > 1) ++g_last_launches[2];
 #define LBX_ROWS(BM_, BN_) launch_rows_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
 #define LBX_ROWS8(BM_, BN_) launch_rows8_t<BM_, BN_, B_KINNER>(al, grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, ch.k_per_split)
-#define LBX_ROWS_DMA(BM_, BN_) launch_rows_dma_t<BM_, BN_, B_KINNER>(grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, ntiles_k, ch.k_per_split, sp)
+#define LBX_ROWS_DMA(BM_, BN_) launch_rows_dma_t<BM_, BN_, B_KINNER>(grid, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n, ntiles_k, ch.k_per_split, sp, rj)
     if (dma_ok && al && dma_mode() != 0) {
         g_last_family = 1;
         DmaStream sp;
+        ReduceJobs rj;                              // total = 0: nothing carried
+        if (carry && !carry->carried && carry->njobs > 0) {
+            rj = pack_carry(carry->jobs, carry->njobs, carry_cap());
+            carry->carried = rj.total > 0;
+        }
         unsigned ntiles_k = (unsigned)ntiles;
         if (stream && stream->g > 1 && ch.splits == 1) {
             sp.pieces = (unsigned)(stream->rem * stream->g);
@@ -991,6 +1012,7 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
             ntiles_k = (unsigned)stream->whole;
             grid.x = sp.npad + ntiles_k;
         }
+        grid.x += rj.total;
         if (ch.bm == 128 && ch.bn == 128) LBX_ROWS_DMA(128, 128);
         else if (ch.bm == 128) LBX_ROWS_DMA(128, 64);
         else if (ch.bn == 128) LBX_ROWS_DMA(64, 128);
@@ -1022,7 +1044,7 @@ inline int cand_index(int bm, int bn) { return bm == 128 ? (bn == 128 ? 0 : 1) :
 
 template <bool B_KINNER>
 int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd, int K, int N, int epi,
-                const float* aux, void* ws, size_t ws_bytes, hipStream_t st) {
+                const float* aux, void* ws, size_t ws_bytes, hipStream_t st, Carry* carry = nullptr) {
     const long M = (long)A.batch * A.rows_per_batch;
     g_last_launches[0] = g_last_launches[1] = g_last_launches[2] = 0;
     g_last_family = 0;
@@ -1094,7 +1116,7 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
     if (dma_ok && dma_mode() != 0 && ch.splits == 1 && aligned16(ws)) {
         const DmaStreamPlan spl = dma_stream_plan(ch.bm, ch.bn, M, N, K);
         if (spl.g > 1 && wsb >= spl.ws_need)
-            return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st, dma_ok, &spl, ws);
+            return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st, dma_ok, &spl, ws, carry);
     }
     const bool no_tail_split = ch.no_tail_split || getenv("LIDBOX_GEMM_NO_TAIL_SPLIT") != nullptr;
     if (!no_tail_split && ch.splits == 1) {
@@ -1116,14 +1138,14 @@ int launch_rows(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t Cd
                                            (double)rem.k_per_split / BK);
                 if (rem.splits > 1) split += 5.0 + (double)m_rem * N * 4.0 * (rem.splits + 1) / 3.0e6;
                 if (split < 0.97 * whole) {
-                    int rc = launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, m_main, K, N, epi, aux, P, st, dma_ok);
+                    int rc = launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, m_main, K, N, epi, aux, P, st, dma_ok, nullptr, nullptr, carry);
                     if (rc) return rc;
                     return launch_rows_range<B_KINNER>(rem, al, Ad, Bm, ldb, Co, m_main, M, K, N, epi, aux, P, st, dma_ok);
                 }
             }
         }
     }
-    return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st, dma_ok);
+    return launch_rows_range<B_KINNER>(ch, al, Ad, Bm, ldb, Co, 0, M, K, N, epi, aux, P, st, dma_ok, nullptr, nullptr, carry);
 }
 
 struct TnPlan {
@@ -1282,16 +1304,24 @@ extern "C" size_t lidbox_gemm_tn_workspace(int M, int K1, int N) {
     return need;
 }
 
-extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N,
-                              int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
-                              lidbox_stream_t stream) {
-    if (check_rows(__func__, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
-    if (check_rows(__func__, Bd.base, Bd.batch_stride, Bd.row_stride, Bd.batch, Bd.rows_per_batch)) return LIDBOX_E_INVALID;
+namespace {
+
+// the wgrad GEMM of lidbox_gemm_tn without its reduce: the slices' partial sums land in the workspace and *job describes the
+// fixed-order reduce that finishes C / bias_grad (nblocks == 0: unaligned case, the scalar reduce was launched here)
+int tn_partial_launch(const char* fn, lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N, int accumulate,
+                      float* bias_grad, void* workspace, size_t workspace_bytes, hipStream_t st, ReduceJob* job) {
+    *job = ReduceJob{};
+    if (check_rows(fn, A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch)) return LIDBOX_E_INVALID;
+    if (check_rows(fn, Bd.base, Bd.batch_stride, Bd.row_stride, Bd.batch, Bd.rows_per_batch)) return LIDBOX_E_INVALID;
     LBX_ARG(Cm && K1 >= 1 && N >= 1 && ldc >= N, "C != NULL, K1, N >= 1, ldc >= N");
     const long M = (long)A.batch * A.rows_per_batch;
     LBX_ARG(M == (long)Bd.batch * Bd.rows_per_batch, "A and B row counts differ");
     LBX_ARG(M >= 1, "M >= 1");
-    hipStream_t st = (hipStream_t)stream;
+    auto finish = [&](const float* P, const float* Pc, int splits) {
+        const long n = (long)K1 * N;
+        if (reduce_job_vec_ok(P, Pc, splits, n, N, Cm, ldc, bias_grad)) *job = make_reduce_job(P, Pc, splits, n, N, Cm, ldc, accumulate, bias_grad);
+        else launch_splitk_reduce(P, Pc, splits, n, N, Cm, ldc, accumulate, bias_grad, st);
+    };
     {
         // persistent-body kernel (gemm_sk.h) over a regular split of the contraction rows
         const SkTn sk = sk_tn_plan(M, K1, N);
@@ -1305,7 +1335,7 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
             hipLaunchKernelGGL(gemm_sk_tn_kernel, dim3((unsigned)(sk.ntiles * sk.splits)), dim3(256), SK_LDS_BYTES, st, to_dev(A),
                                to_dev(Bd), P, Pc, M, K1, N, sk.tiles_n, sk.ntiles, sk.rows_per_split);
             LBX_LAUNCH_OK();
-            launch_splitk_reduce((const float*)P, (const float*)Pc, sk.splits, (long)K1 * N, N, Cm, ldc, accumulate, bias_grad, st);
+            finish(P, Pc, sk.splits);
             LBX_LAUNCH_OK();
             return LIDBOX_OK;
         }
@@ -1331,7 +1361,7 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
         else LBX_TN_DMA(64, 64);
 #undef LBX_TN_DMA
         LBX_LAUNCH_OK();
-        launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, (long)K1 * N, N, Cm, ldc, accumulate, bias_grad, st);
+        finish(P, Pc, pl.splits);
         LBX_LAUNCH_OK();
         return LIDBOX_OK;
     }
@@ -1345,11 +1375,95 @@ extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long
     else LBX_TN(64, 64);
 #undef LBX_TN
     LBX_LAUNCH_OK();
-    const long n = (long)K1 * N;
-    launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad, st);
+    finish(P, Pc, pl.splits);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }
+
+static_assert(sizeof(lidbox_reduce_job_t) == sizeof(ReduceJob), "lidbox_reduce_job_t mirrors ReduceJob");
+inline ReduceJob job_in(const lidbox_reduce_job_t* j) {
+    ReduceJob r;
+    if (j) memcpy(&r, j, sizeof r);
+    return r;
+}
+// the non-empty jobs of a caller's list (at most MAX_CARRY are kept; -1: too many)
+inline int jobs_in(const lidbox_reduce_job_t* jobs, int njobs, ReduceJob (&out)[MAX_CARRY]) {
+    int m = 0;
+    for (int i = 0; jobs && i < njobs; ++i) {
+        if (jobs[i].nblocks == 0) continue;
+        if (m == MAX_CARRY) return -1;
+        out[m++] = job_in(jobs + i);
+    }
+    return m;
+}
+
+// the jobs as one launch of their own
+int run_reduce_jobs(const ReduceJob* jobs, int njobs, hipStream_t st) {
+    ReduceJobs js;
+    for (int i = 0, m = 0; i < njobs && m < MAX_CARRY; ++i) {
+        if (jobs[i].nblocks == 0) continue;
+        js.j[m++] = jobs[i];
+        js.total += jobs[i].nblocks;
+    }
+    if (js.total == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(js.total), dim3(256), 0, st, js);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+}  // namespace
+
+extern "C" int lidbox_gemm_tn(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N,
+                              int accumulate, float* bias_grad, void* workspace, size_t workspace_bytes,
+                              lidbox_stream_t stream) {
+    ReduceJob job;
+    int rc = tn_partial_launch(__func__, A, Bd, Cm, ldc, K1, N, accumulate, bias_grad, workspace, workspace_bytes, (hipStream_t)stream, &job);
+    if (rc) return rc;
+    return run_reduce_jobs(&job, 1, (hipStream_t)stream);
+}
+
+// The two halves of lidbox_gemm_tn as separate calls, so that the reduce can be CARRIED by a later GEMM launch on the same
+// stream (lidbox_gemm_nt_carry): the workspace holds the slices until the job has run.
+extern "C" int lidbox_gemm_tn_partial(lidbox_rows_t A, lidbox_rows_t Bd, float* Cm, long ldc, int K1, int N, int accumulate,
+                                      float* bias_grad, void* workspace, size_t workspace_bytes, lidbox_reduce_job_t* job,
+                                      lidbox_stream_t stream) {
+    LBX_ARG(job, "job != NULL");
+    ReduceJob j;
+    int rc = tn_partial_launch(__func__, A, Bd, Cm, ldc, K1, N, accumulate, bias_grad, workspace, workspace_bytes, (hipStream_t)stream, &j);
+    memcpy(job, &j, sizeof j);
+    return rc;
+}
+
+extern "C" int lidbox_reduce_jobs_run(const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream) {
+    LBX_ARG(njobs >= 0 && (jobs || njobs == 0), "jobs != NULL");
+    ReduceJob js[MAX_CARRY];
+    const int m = jobs_in(jobs, njobs, js);
+    LBX_ARG(m >= 0, "at most 2 non-empty jobs per call");
+    return run_reduce_jobs(js, m, (hipStream_t)stream);
+}
+
+// lidbox_gemm_nt whose launch also runs the pending `jobs` (NULL / 0 / empty ones: plain lidbox_gemm_nt): in its leading
+// workgroups when the launch is an LDS-DMA tile launch (gemm_dma.h), else as a launch of their own behind it.  Results of
+// both are bit-identical to the separate calls.
+extern "C" int lidbox_gemm_nt_carry(lidbox_rows_t A, const float* Bm, long ldb, lidbox_rows_out_t C, int K, int N, int epilogue,
+                                    const float* aux, void* workspace, size_t workspace_bytes, const lidbox_reduce_job_t* jobs,
+                                    int njobs, lidbox_stream_t stream) {
+    if (validate_rows_call(__func__, A, Bm, ldb, C, K, N, epilogue, aux, K)) return LIDBOX_E_INVALID;
+    ReduceJob js[MAX_CARRY];
+    const int m = jobs_in(jobs, njobs, js);
+    LBX_ARG(m >= 0, "at most 2 non-empty jobs per call");
+    for (int i = 0; i < m; ++i) LBX_ARG((const void*)js[i].P != workspace, "a job's slices live in this call's workspace");
+    Carry carry;
+    carry.jobs = js;
+    carry.njobs = (m > 0 && getenv("LIDBOX_GEMM_NO_CARRY") == nullptr) ? m : 0;
+    int rc = launch_rows<true>(A, Bm, ldb, C, K, N, epilogue, aux, workspace, workspace_bytes, (hipStream_t)stream, &carry);
+    if (rc) return rc;
+    g_last_carried = carry.carried ? m : 0;
+    if (!carry.carried) return run_reduce_jobs(js, m, (hipStream_t)stream);
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_gemm_last_carried(void) { return g_last_carried; }
 
 inline long pair_max_blocks() {
     if (const char* e = getenv("LIDBOX_GEMM_PAIR_MAX_BLOCKS")) return atol(e);     // A/B aid
@@ -1382,10 +1496,21 @@ bool pair_plan(long M, int Co, int N, int K1, size_t ws_nt_bytes, size_t ws_tn_b
 // When both are small 64 x 64-tile launches of the LDS-DMA family (the dense head: M = batch rows) they go out as ONE launch
 // (gemm_nt_tn_pair_kernel, gemm_dma.h) followed by their reduces; otherwise this is exactly the two calls.  Results are
 // bit-identical to the two calls either way (same bodies, tiles and summation orders).
-extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
-                                 const float* aux, void* ws_nt, size_t ws_nt_bytes, lidbox_rows_t X, float* dW, long ldc, int K1,
-                                 int accumulate, float* bias_grad, void* ws_tn, size_t ws_tn_bytes, lidbox_stream_t stream) {
+// + jobs_in: pending reduces of EARLIER layers, carried by this call's launch (the pair kernel or the dgrad launch);
+// job_out (may be NULL): where this call's own wgrad reduce goes when it could not be placed inside this call's launches (the
+// one-launch pair: the slices are complete only when that launch ends) -- the caller hands it to a later carry call or to
+// lidbox_reduce_jobs_run; with job_out == NULL the reduce is launched here.  *job_out comes back empty otherwise.
+extern "C" int lidbox_gemm_nt_tn_carry(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
+                                       const float* aux, void* ws_nt, size_t ws_nt_bytes, lidbox_rows_t X, float* dW, long ldc, int K1,
+                                       int accumulate, float* bias_grad, void* ws_tn, size_t ws_tn_bytes,
+                                       const lidbox_reduce_job_t* jobs, int njobs, lidbox_reduce_job_t* job_out, lidbox_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (job_out) memset(job_out, 0, sizeof *job_out);
+    ReduceJob pend[MAX_CARRY];
+    const int npend = jobs_in(jobs, njobs, pend);
+    LBX_ARG(npend >= 0 && npend < MAX_CARRY, "at most 1 non-empty pending job per call");
+    for (int i = 0; i < npend; ++i)
+        LBX_ARG((const void*)pend[i].P != ws_nt && (const void*)pend[i].P != ws_tn, "a pending job's slices live in this call's workspaces");
     const long M = (long)dY.batch * dY.rows_per_batch;
     bool pair = dma_mode() != 0 && getenv("LIDBOX_GEMM_NO_PAIR") == nullptr && M >= 1 && N >= 1 && K1 >= 1 && Co >= 1 && W && dW && ws_tn &&
                 ws_nt != ws_tn;
@@ -1404,9 +1529,17 @@ extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lid
         pair = al_rows && al_tn && pair_plan(M, Co, N, K1, wsb, ws_tn_bytes, &ch, &pl);
     }
     if (!pair) {
-        int rc = lidbox_gemm_tn(X, dY, dW, ldc, K1, Co, accumulate, bias_grad, ws_tn, ws_tn_bytes, stream);
+        // wgrad GEMM first, then the dgrad launch carries the wgrad's reduce in its leading workgroups
+        lidbox_reduce_job_t all[MAX_CARRY];
+        for (int i = 0; i < npend; ++i) memcpy(&all[i], &pend[i], sizeof(ReduceJob));
+        int rc = lidbox_gemm_tn_partial(X, dY, dW, ldc, K1, Co, accumulate, bias_grad, ws_tn, ws_tn_bytes, &all[npend], stream);
         if (rc) return rc;
-        return lidbox_gemm_nt(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ws_nt_bytes, stream);
+        if (ws_nt == ws_tn) {               // one shared workspace: the slices must be consumed before the dgrad may use it
+            rc = lidbox_reduce_jobs_run(all, npend + 1, stream);
+            if (rc) return rc;
+            return lidbox_gemm_nt(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ws_nt_bytes, stream);
+        }
+        return lidbox_gemm_nt_carry(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ws_nt_bytes, all, npend + 1, stream);
     }
     PairRows r;
     r.A = to_dev(dY); r.Bm = W; r.ldb = ldb;
@@ -1436,11 +1569,18 @@ extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lid
     t.ntiles = (int)(lbx_cdiv((long)K1, 64L) * t.tiles_n);
     t.rows_per_split = pl.rows_per_split;
     const unsigned rows_blocks = r.nx * (unsigned)ch.splits;
-    const unsigned grid = rows_blocks + (unsigned)(t.ntiles * pl.splits);
-    g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = 1 + (ch.splits > 1 ? 1 : 0);
+    ReduceJobs rj;                                              // pending reduces of earlier layers ride in the leading blocks
+    if (npend > 0 && getenv("LIDBOX_GEMM_NO_CARRY") == nullptr) rj = pack_carry(pend, npend, carry_cap());
+    const unsigned grid = rj.total + rows_blocks + (unsigned)(t.ntiles * pl.splits);
+    g_last_launches[0] = 1; g_last_launches[1] = 0; g_last_launches[2] = (job_out ? 0 : 1) + (ch.splits > 1 ? 1 : 0);
     g_last_family = 1;
-    hipLaunchKernelGGL(gemm_nt_tn_pair_kernel, dim3(grid), dim3(256), 0, st, r, t, rows_blocks);
+    g_last_carried = rj.total > 0 ? npend : 0;
+    hipLaunchKernelGGL(gemm_nt_tn_pair_kernel, dim3(grid), dim3(256), 0, st, r, t, rows_blocks, rj);
     LBX_LAUNCH_OK();
+    if (npend > 0 && rj.total == 0) {
+        int rc = run_reduce_jobs(pend, npend, st);
+        if (rc) return rc;
+    }
     if (ch.splits > 1) {
         long g = lbx_cdiv(M * N, 256);
         if (g > 2048) g = 2048;
@@ -1448,9 +1588,21 @@ extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lid
                            aux);
         LBX_LAUNCH_OK();
     }
+    if (job_out && reduce_job_vec_ok(t.P, t.Pc, pl.splits, (long)K1 * Co, Co, dW, ldc, bias_grad)) {
+        const ReduceJob j = make_reduce_job(t.P, t.Pc, pl.splits, (long)K1 * Co, Co, dW, ldc, accumulate, bias_grad);
+        memcpy(job_out, &j, sizeof j);
+        return LIDBOX_OK;
+    }
     launch_splitk_reduce((const float*)t.P, (const float*)t.Pc, pl.splits, (long)K1 * Co, Co, dW, ldc, accumulate, bias_grad, st);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
+}
+
+extern "C" int lidbox_gemm_nt_tn(lidbox_rows_t dY, const float* W, long ldb, lidbox_rows_out_t dX, int Co, int N, int epilogue,
+                                 const float* aux, void* ws_nt, size_t ws_nt_bytes, lidbox_rows_t X, float* dW, long ldc, int K1,
+                                 int accumulate, float* bias_grad, void* ws_tn, size_t ws_tn_bytes, lidbox_stream_t stream) {
+    return lidbox_gemm_nt_tn_carry(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ws_nt_bytes, X, dW, ldc, K1, accumulate, bias_grad, ws_tn,
+                                   ws_tn_bytes, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int lidbox_gemm_plan_is_pair(long M, int Co, int N, int K1, size_t ws_nt_bytes, size_t ws_tn_bytes) {

@@ -69,7 +69,12 @@ template <int BM, int BN, int STAGES, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm16s_rows_dma_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
                                                                     float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
                                                                     const float* __restrict__ aux, int tiles_n, unsigned ntiles,
-                                                                    int k_per_split, const unsigned short* __restrict__ mask16) {
+                                                                    int k_per_split, const unsigned short* __restrict__ mask16, ReduceJobs rj) {
+    // carried reduces (gemm_shared.h: ReduceJobs): the leading rj.total workgroups sum pending wgrads' slices
+    if (blockIdx.x < rj.total) {
+        if (blockIdx.y == 0) reduce_jobs_run(rj, blockIdx.x);
+        return;
+    }
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int A_ST = BM * D16_ROW_BYTES, ST = (BM + BN) * D16_ROW_BYTES;      // bytes
     constexpr int PA = BM / 32, PB = BN / 32, NP = PA + PB;                       // DMA pieces per wave per step: 4 .. 8
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, OCC) void gemm16s_rows_dma_kernel(RowsH A, Row
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem16d);
-    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const unsigned chunk = xcd_chunk_id(blockIdx.x - rj.total, ntiles);
     const int tn = chunk % tiles_n;
     const long m0 = m_beg + (long)(chunk / tiles_n) * BM;
     const int n0 = tn * BN;

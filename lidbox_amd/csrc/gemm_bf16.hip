@@ -42,6 +42,7 @@
 // Requirements (checked, LIDBOX_E_INVALID otherwise): 16-byte aligned bases, K (K1) and N multiples
 // of 4, row/batch strides multiples of 4 -- true of every layer of the x-vector / CNN models.
 // Roofline: MFMA bf16 dense, 2.5 PFLOP/s (MI355X_MICROARCH.md); practical bound = L2->LDS traffic.
+#include <string.h>
 #include "gemm_shared.h"
 
 namespace {
@@ -511,14 +512,18 @@ __device__ __forceinline__ void mma_tile16s(const __bf16* As, const __bf16* Bs, 
 __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
                                                               float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
                                                               const float* __restrict__ aux, int tiles_n, unsigned ntiles,
-                                                              int k_per_split, const unsigned short* __restrict__ mask16) {
+                                                              int k_per_split, const unsigned short* __restrict__ mask16, ReduceJobs rj) {
     extern __shared__ __attribute__((aligned(16))) char smem16s[];      // 4 tiles: 40 KB (BKS 32) or 72 KB (BKS 64, above the static limit)
+    if (blockIdx.x < rj.total) {                                        // carried reduces (gemm_shared.h: ReduceJobs)
+        if (blockIdx.y == 0) reduce_jobs_run(rj, blockIdx.x);
+        return;
+    }
     __bf16 (*As)[TILE_S] = reinterpret_cast<__bf16 (*)[TILE_S]>(smem16s);
     __bf16 (*Bs)[TILE_S] = reinterpret_cast<__bf16 (*)[TILE_S]>(smem16s + 2 * TILE_S * sizeof(__bf16));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const unsigned chunk = xcd_chunk_id(blockIdx.x, ntiles);
+    const unsigned chunk = xcd_chunk_id(blockIdx.x - rj.total, ntiles);
     const int tn = chunk % tiles_n;
     const long m0 = m_beg + (long)(chunk / tiles_n) * BT;
     const int n0 = tn * BT;
@@ -702,8 +707,11 @@ __global__ __launch_bounds__(256, 2) void gemm16s_tn_kernel(RowsH A, RowsH Bd, f
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x % ntiles;                              // consecutive ids = the tiles of one M slice (L2 reuse)
-    const int split = blockIdx.x / ntiles;
+    // block -> (slice, tile) through the XCD-chunk remap: the tiles of one M slice run on ONE XCD (block % 8), so the slice's
+    // panels are fetched by one L2 (round 3: 168 MB at the fabric per launch against 44 MB algorithmic, every panel in 4-8 L2s)
+    const unsigned vb = xcd_chunk_id(blockIdx.x, gridDim.x);
+    const int tile = (int)(vb % (unsigned)ntiles);
+    const int split = (int)(vb / (unsigned)ntiles);
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int i0 = tk * BT, n0 = tn * BT;
     const long mbeg = (long)split * rows_per_split;
@@ -1012,7 +1020,7 @@ Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes) {
 
 template <int BM, int BN, int STAGES, int OCC>
 int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M,
-                         int K, int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st) {
+                         int K, int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
     constexpr size_t lds_bytes = (size_t)STAGES * (BM + BN) * D16_ROW_BYTES;
     static bool attr_set = false;
     if (lds_bytes > 65536 && !attr_set) {
@@ -1022,8 +1030,8 @@ int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh
     }
     const int tiles_n = (int)lbx_cdiv((long)N, (long)BN);
     const long ntiles = lbx_cdiv(M, (long)BM) * tiles_n;
-    hipLaunchKernelGGL((gemm16s_rows_dma_kernel<BM, BN, STAGES, OCC>), dim3((unsigned)ntiles, (unsigned)dc.splits), dim3(256), lds_bytes, st,
-                       Ah, Bh, Co, S, P, 0L, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, dc.k_per_split, mask16);
+    hipLaunchKernelGGL((gemm16s_rows_dma_kernel<BM, BN, STAGES, OCC>), dim3((unsigned)ntiles + rj.total, (unsigned)dc.splits), dim3(256), lds_bytes, st,
+                       Ah, Bh, Co, S, P, 0L, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, dc.k_per_split, mask16, rj);
     LBX_LAUNCH_OK();
     if (dc.splits > 1) {
         long g = lbx_cdiv(M * N, 256);
@@ -1035,12 +1043,13 @@ int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh
     return LIDBOX_OK;
 }
 
+thread_local int g16_last_carried = 0;                 // jobs the calling thread's last lidbox_gemm_bf16s_nt_carry ran inside its GEMM launch
 thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the calling thread's last lidbox_gemm_bf16s_nt (0: register-staged)
 
 int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
-                       int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st) {
+                       int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
 #define LBX_D16(BM_, BN_, ST_, OCC_) \
-    if (dc.bm == BM_ && dc.bn == BN_ && dc.stages == ST_) return launch_rows16s_dma_t<BM_, BN_, ST_, OCC_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st)
+    if (dc.bm == BM_ && dc.bn == BN_ && dc.stages == ST_) return launch_rows16s_dma_t<BM_, BN_, ST_, OCC_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj)
     LBX_D16(64, 64, 2, 5);
     LBX_D16(64, 64, 3, 3);
     LBX_D16(64, 64, 4, 2);
@@ -1055,10 +1064,23 @@ int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, 
     return LIDBOX_E_INVALID;
 }
 
+// workgroups the carried reduces of a storage-GEMM launch share (gemm.hip: carry_cap -- same measurement)
+inline long carry_cap16() {
+    if (const char* e = getenv("LIDBOX_GEMM_CARRY_BLOCKS")) { const long v = atol(e); if (v >= 8) return v; }
+    return 96;
+}
+
+// jobs / njobs: pending wgrad reduces this launch carries in its leading workgroups (the first kernel launched takes them)
 int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, lidbox_rows_out_t Cd, void* C16, int K, int N,
-                   int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t st, const unsigned short* mask16) {
+                   int epi, const float* aux, void* ws, size_t ws_bytes, hipStream_t st, const unsigned short* mask16,
+                   const ReduceJob* jobs = nullptr, int njobs = 0) {
     const long M = (long)A.batch * A.rows_per_batch;
-    if (M == 0 || N == 0) return LIDBOX_OK;
+    ReduceJobs rj;
+    if (njobs > 0) rj = pack_carry(jobs, njobs, carry_cap16());
+    if (M == 0 || N == 0) {
+        if (rj.total) hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(rj.total), dim3(256), 0, st, rj);
+        return LIDBOX_OK;
+    }
     const lidbox_rows_t Cin{Cd.base, Cd.batch_stride, Cd.row_stride, Cd.batch, Cd.rows_per_batch};
     const bool a_ok = aligned16(A.base) && A.row_stride % 8 == 0 && (A.batch == 1 || A.batch_stride % 8 == 0);
     if (!(a_ok && rows_aligned(Cin) && K % 8 == 0 && aligned16(B16) && ldb % 8 == 0 && aligned16(ws) &&
@@ -1080,7 +1102,7 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
             g16_last_variant[0] = dc.bm; g16_last_variant[1] = dc.bn; g16_last_variant[2] = dc.stages;
         }
         if (dc.bm != 0 && a_ext < 4.0e9 && b_ext < 4.0e9)
-            return launch_rows16s_dma(dc, Ah_, Bh_, Co_, (unsigned short*)C16, (float*)ws, M, K, N, epi, aux, mask16, st);
+            return launch_rows16s_dma(dc, Ah_, Bh_, Co_, (unsigned short*)C16, (float*)ws, M, K, N, epi, aux, mask16, st, rj);
     }
     const Rows16Plan pl = plan_rows16(M, N, K, ws ? ws_bytes : 0, BKS);
     const size_t lds_bytes = 4 * (size_t)TILE_S * sizeof(__bf16);
@@ -1098,9 +1120,10 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
     auto launch_range = [&](long m_beg, long m_end, const Rows16Plan& q) -> int {
         const long msub = m_end - m_beg;
         const long ntiles = lbx_cdiv(msub, BT) * tiles_n;
-        hipLaunchKernelGGL(gemm16s_rows_kernel, dim3((unsigned)ntiles, (unsigned)q.splits), dim3(256), lds_bytes, st, Ah, Bh, Co, S, P,
-                           m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, q.k_per_split, mask16);
+        hipLaunchKernelGGL(gemm16s_rows_kernel, dim3((unsigned)ntiles + rj.total, (unsigned)q.splits), dim3(256), lds_bytes, st, Ah, Bh, Co, S, P,
+                           m_beg, m_end, K, N, epi, aux, tiles_n, (unsigned)ntiles, q.k_per_split, mask16, rj);
         LBX_LAUNCH_OK();
+        rj = ReduceJobs{};                           // carried by the first launch of the call
         if (q.splits > 1) {
             long g = lbx_cdiv(msub * N, 256);
             if (g > 2048) g = 2048;
@@ -1134,6 +1157,25 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
 extern "C" int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16, int K,
                                     int N, int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
                                     lidbox_stream_t stream) {
+    return lidbox_gemm_bf16s_nt_carry(A16, B16, ldb, C, C16, K, N, epilogue, aux, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// lidbox_gemm_bf16s_nt whose first launch also runs up to two pending wgrad reduces in its leading workgroups (lidbox_hip.h:
+// "carried reduce"; LIDBOX_GEMM_NO_CARRY=1: as one launch of their own behind the GEMM)
+extern "C" int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, long ldb, lidbox_rows_out_t C, void* C16, int K,
+                                          int N, int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
+                                          const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream) {
+    static_assert(sizeof(lidbox_reduce_job_t) == sizeof(ReduceJob), "lidbox_reduce_job_t mirrors ReduceJob");
+    ReduceJob js[MAX_CARRY];
+    int m = 0;
+    for (int i = 0; jobs && i < njobs; ++i) {
+        if (jobs[i].nblocks == 0) continue;
+        LBX_ARG(m < MAX_CARRY, "at most 2 non-empty jobs per call");
+        memcpy(&js[m], jobs + i, sizeof(ReduceJob));
+        LBX_ARG((const void*)js[m].P != workspace, "a job's slices live in this call's workspace");
+        ++m;
+    }
+    const bool carry = m > 0 && getenv("LIDBOX_GEMM_NO_CARRY") == nullptr;
     // LIDBOX_EPI_MASK_BF16: the ReLU mask source (aux) is bfloat16 data at C's element offsets; C.base == NULL: the result
     // exists only as the shadow C16 (no fp32 copy is written) -- not with the accumulating epilogues, which read C
     const bool mask16 = (epilogue & LIDBOX_EPI_MASK_BF16) != 0;
@@ -1146,9 +1188,20 @@ extern "C" int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb
     }
     LBX_ARG(!mask16 || epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK, "LIDBOX_EPI_MASK_BF16 goes with a ReLU-mask epilogue");
     if (validate_rows_call(__func__, A16, (const float*)B16, ldb, Cv, K, N, epi, aux, K)) return LIDBOX_E_INVALID;
-    return launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epi, mask16 ? nullptr : aux, workspace, workspace_bytes,
-                          (hipStream_t)stream, mask16 ? (const unsigned short*)aux : nullptr);
+    int rc = launch_rows16s(__func__, A16, B16, ldb, C, C16, K, N, epi, mask16 ? nullptr : aux, workspace, workspace_bytes,
+                            (hipStream_t)stream, mask16 ? (const unsigned short*)aux : nullptr, js, carry ? m : 0);
+    if (rc) return rc;
+    g16_last_carried = carry ? m : 0;
+    if (m > 0 && !carry) {
+        ReduceJobs all;
+        for (int i = 0; i < m; ++i) { all.j[i] = js[i]; all.total += js[i].nblocks; }
+        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(all.total), dim3(256), 0, (hipStream_t)stream, all);
+        LBX_LAUNCH_OK();
+    }
+    return LIDBOX_OK;
 }
+
+extern "C" int lidbox_gemm_bf16s_last_carried(void) { return g16_last_carried; }
 
 extern "C" int lidbox_gemm_bf16s_last_variant(int* out3) {
     LBX_ARG(out3, "out3 != NULL");
@@ -1164,6 +1217,24 @@ extern "C" size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N) {
 
 extern "C" int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* Cm, long ldc, int K1, int N, int accumulate,
                                     float* bias_grad, void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
+    lidbox_reduce_job_t job;
+    int rc = lidbox_gemm_bf16s_tn_partial(A16, B16, Cm, ldc, K1, N, accumulate, bias_grad, workspace, workspace_bytes, &job, stream);
+    if (rc || job.nblocks == 0) return rc;
+    ReduceJobs js;
+    memcpy(&js.j[0], &job, sizeof(ReduceJob));
+    js.total = js.j[0].nblocks;
+    hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(js.total), dim3(256), 0, (hipStream_t)stream, js);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+// the GEMM of lidbox_gemm_bf16s_tn without its reduce: *job describes the pending fixed-order slice sum (lidbox_hip.h:
+// "carried reduce"); job->nblocks == 0: nothing pending (the scalar reduce of an unaligned output was launched here)
+extern "C" int lidbox_gemm_bf16s_tn_partial(lidbox_rows_t A16, lidbox_rows_t B16, float* Cm, long ldc, int K1, int N, int accumulate,
+                                            float* bias_grad, void* workspace, size_t workspace_bytes, lidbox_reduce_job_t* job,
+                                            lidbox_stream_t stream) {
+    LBX_ARG(job, "job != NULL");
+    memset(job, 0, sizeof *job);
     if (check_rows(__func__, A16.base, A16.batch_stride, A16.row_stride, A16.batch, A16.rows_per_batch)) return LIDBOX_E_INVALID;
     if (check_rows(__func__, B16.base, B16.batch_stride, B16.row_stride, B16.batch, B16.rows_per_batch)) return LIDBOX_E_INVALID;
     LBX_ARG(Cm && K1 >= 1 && N >= 1 && ldc >= N, "C != NULL, K1, N >= 1, ldc >= N");
@@ -1199,6 +1270,11 @@ extern "C" int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float*
                        tiles_n, ntiles, pl.rows_per_split);
     LBX_LAUNCH_OK();
     const long n = (long)K1 * N;
+    if (reduce_job_vec_ok(P, Pc, pl.splits, n, N, Cm, ldc, bias_grad)) {
+        const ReduceJob j = make_reduce_job(P, Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad);
+        memcpy(job, &j, sizeof j);
+        return LIDBOX_OK;
+    }
     launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad, st);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;

@@ -380,10 +380,16 @@ constexpr int dma_stage_floats() { return (BM + BN) * SK_BK; }
 template <int BM, int BN, bool B_KINNER>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_rows_dma_kernel(
     RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd, float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
-    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split, DmaStream sp) {
+    const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split, DmaStream sp, ReduceJobs rj) {
     __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * dma_stage_floats<BM, BN>()];
-    rows_dma_body<BM, BN, B_KINNER>(A, Bm, ldb, Cd, P, m_beg, M, K, N, epi, aux, tiles_n, ntiles, k_per_split, sp, blockIdx.x, blockIdx.y,
-                                    gridDim.y > 1 ? 1 : 0, smem);
+    // carried reduces (gemm_shared.h: ReduceJobs): the first rj.total workgroups (a multiple of 8: block % 8 stays the XCD of
+    // the tiles behind them) sum pending wgrads' slices -- bandwidth-bound work beside this launch's MFMA-bound tiles
+    if (blockIdx.x < rj.total) {
+        if (blockIdx.y == 0) reduce_jobs_run(rj, blockIdx.x);
+        return;
+    }
+    rows_dma_body<BM, BN, B_KINNER>(A, Bm, ldb, Cd, P, m_beg, M, K, N, epi, aux, tiles_n, ntiles, k_per_split, sp, blockIdx.x - rj.total,
+                                    blockIdx.y, gridDim.y > 1 ? 1 : 0, smem);
 }
 
 // K-outer operand whose k index is an implicit activation row (tn: the contraction runs over the rows), 16 rows x COLS
@@ -442,10 +448,12 @@ struct DmaOuterRows {
 
 // wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N] (+ Pc[split][N] = column sums of B[Mslice] from the stages in
 // LDS), the decomposition of gemm_tn_kernel (gemm.hip) on the LDS-DMA operand path with the tile shape as a template
-// parameter; grid.x = tiles x splits (tile fastest: co-resident workgroups share a slice's rows in L2)
+// parameter; grid.x = nblk = tiles x splits.  Block -> (slice, tile) through the XCD-chunk remap: the tiles of one slice run on
+// ONE XCD (block % 8), so a slice's activation / gradient panels are fetched by one L2 instead of eight (round 3 measured
+// 2 x the input bytes at the fabric: every panel went to four or eight L2s)
 template <int BM, int BN>
 __device__ __forceinline__ void tn_dma_body(const RowsD& A, const RowsD& Bd, float* __restrict__ P, float* __restrict__ Pc, long M, int K1, int N,
-                                            int tiles_n, int ntiles, long rows_per_split, unsigned bx, float* smem) {
+                                            int tiles_n, int ntiles, long rows_per_split, unsigned bx, unsigned nblk, float* smem) {
     constexpr int MI = BM / 64, NJ = BN / 64;
     constexpr int A_ST = SK_BK * BM, B_ST = SK_BK * BN, ST = A_ST + B_ST;
     constexpr int PA = BM / 64, PB = BN / 64, NP = PA + PB;
@@ -454,8 +462,9 @@ __device__ __forceinline__ void tn_dma_body(const RowsD& A, const RowsD& Bd, flo
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
-    const int tile = (int)(bx % (unsigned)ntiles);
-    const int split = (int)(bx / (unsigned)ntiles);
+    const unsigned vb = xcd_chunk_id(bx, nblk);
+    const int tile = (int)(vb % (unsigned)ntiles);
+    const int split = (int)(vb / (unsigned)ntiles);
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int i0 = tk * BM, n0 = tn * BN;
     const long mbeg = (long)split * rows_per_split;
@@ -561,7 +570,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : (BM * BN >= 8192 ? 4 : 6))) void gemm_tn_dma_kernel(
     RowsD A, RowsD Bd, float* __restrict__ P, float* __restrict__ Pc, long M, int K1, int N, int tiles_n, int ntiles, long rows_per_split) {
     __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * dma_stage_floats<BM, BN>()];
-    tn_dma_body<BM, BN>(A, Bd, P, Pc, M, K1, N, tiles_n, ntiles, rows_per_split, blockIdx.x, smem);
+    tn_dma_body<BM, BN>(A, Bd, P, Pc, M, K1, N, tiles_n, ntiles, rows_per_split, blockIdx.x, gridDim.x, smem);
 }
 
 // Two independent GEMMs that read the same output gradient -- a layer's dgrad (nt) and its wgrad (tn) -- in ONE launch of
@@ -593,13 +602,18 @@ struct PairTn {
     int K1, N, tiles_n, ntiles;
     long rows_per_split;
 };
-__global__ __launch_bounds__(256, 6) void gemm_nt_tn_pair_kernel(PairRows r, PairTn t, unsigned rows_blocks) {
+__global__ __launch_bounds__(256, 6) void gemm_nt_tn_pair_kernel(PairRows r, PairTn t, unsigned rows_blocks, ReduceJobs rj) {
     __shared__ __attribute__((aligned(16))) float smem[DMA_STAGES * dma_stage_floats<64, 64>()];
-    if (blockIdx.x < rows_blocks) {
+    if (blockIdx.x < rj.total) {                        // carried reduces of earlier layers (gemm_rows_dma_kernel)
+        reduce_jobs_run(rj, blockIdx.x);
+        return;
+    }
+    const unsigned bx = blockIdx.x - rj.total, nb = gridDim.x - rj.total;
+    if (bx < rows_blocks) {
         rows_dma_body<64, 64, true>(r.A, r.Bm, r.ldb, r.Cd, r.P, 0, r.M, r.K, r.N, r.epi, r.aux, r.tiles_n, r.ntiles, r.k_per_split, r.sp,
-                                    blockIdx.x % r.nx, blockIdx.x / r.nx, r.partial, smem);
+                                    bx % r.nx, bx / r.nx, r.partial, smem);
     } else {
-        tn_dma_body<64, 64>(t.A, t.Bd, t.P, t.Pc, t.M, t.K1, t.N, t.tiles_n, t.ntiles, t.rows_per_split, blockIdx.x - rows_blocks, smem);
+        tn_dma_body<64, 64>(t.A, t.Bd, t.P, t.Pc, t.M, t.K1, t.N, t.tiles_n, t.ntiles, t.rows_per_split, bx - rows_blocks, nb - rows_blocks, smem);
     }
 }
 

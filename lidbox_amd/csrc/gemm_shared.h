@@ -239,49 +239,158 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, const float* _
     }
 }
 
-// the same sums, four consecutive elements per thread as 16-byte accesses (every element still adds its slices in the
-// order 0 .. splits-1: bit-identical to the scalar kernel); the slices of a quad are issued four at a time
-__global__ void splitk_reduce4_kernel(const float* __restrict__ P, const float* __restrict__ Pc, int splits, long n, int N,
-                                      float* __restrict__ Cm, long ldc, int accumulate, float* __restrict__ bias_grad) {
+// A pending fixed-order reduce of wgrad slices (what splitk_reduce4_kernel does), as a value that can travel: run by its own
+// launch, or by the LEADING `nblocks` workgroups of a later GEMM launch on the same stream ("carried" reduce, gemm_dma.h /
+// gemm16_dma.h: the bandwidth-bound sums then run beside that launch's MFMA-bound tiles instead of between two launches).
+// Same element -> thread map, same slice order 0 .. splits-1 for every element whoever runs it: bit-identical results.
+struct ReduceJob {
+    const float* P = nullptr;       // [splits][n]
+    const float* Pc = nullptr;      // [splits][N] (bias gradient slices) or NULL
+    float* Cm = nullptr;
+    float* bias_grad = nullptr;
+    long n = 0, ldc = 0;
+    int splits = 0, N = 0, accumulate = 0;
+    unsigned nblocks = 0;           // workgroups of 256 threads that share the job; 0 = no job
+};
+
+// one matrix of slices X[splits][n] -> C quads, two quads per pass (eight 16-byte loads in flight per thread)
+__device__ __forceinline__ void reduce_slices(const float* X, long n, int splits, long nquads, unsigned blk, unsigned nblocks, int N, float* Cm,
+                                              long ldc, int accumulate) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const long n4 = n >> 2, N4 = N >> 2;
-    const long total = n4 + (bias_grad ? N4 : 0);
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const bool body = q < n4;
-        const float* src = body ? P + 4 * q : Pc + 4 * (q - n4);
-        const long stride = body ? n : (long)N;
-        f4 s = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 4 <= splits; k += 4) {
-            const f4 a = *reinterpret_cast<const f4*>(src + (long)k * stride);
-            const f4 b = *reinterpret_cast<const f4*>(src + (long)(k + 1) * stride);
-            const f4 c = *reinterpret_cast<const f4*>(src + (long)(k + 2) * stride);
-            const f4 d = *reinterpret_cast<const f4*>(src + (long)(k + 3) * stride);
-            s = (((s + a) + b) + c) + d;
-        }
-        for (; k < splits; ++k) s += *reinterpret_cast<const f4*>(src + (long)k * stride);
-        float* dst;
-        if (body) {
-            const long i = 4 * q, row = i / N, col = i - row * N;
-            dst = Cm + row * ldc + col;
-        } else {
-            dst = bias_grad + 4 * (q - n4);
-        }
-        f4* d4 = reinterpret_cast<f4*>(dst);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    // buffer loads: one wave-uniform descriptor of the slices, the slice offset k * n * 4 as the scalar offset, a 32-bit byte
+    // offset per lane -- no per-load 64-bit addresses (the GEMM kernels that carry a job have 80 registers)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0xffffffffu, 0x00020000);
+    const unsigned slice = (unsigned)(n * 4);
+    const long stride_q = (long)nblocks * 256;
+    auto put = [&](long q, f4 s) {
+        const long i = 4 * q, row = i / N, col = i - row * N;
+        f4* d4 = reinterpret_cast<f4*>(Cm + row * ldc + col);
         *d4 = accumulate ? *d4 + s : s;
+    };
+#define LBX_RJ_LD(v, o) __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (v), (o), 0))
+    long q0 = (long)blk * 256 + threadIdx.x;
+    for (; q0 + stride_q < nquads; q0 += 2 * stride_q) {             // two quads per pass
+        const long q1 = q0 + stride_q;
+        const unsigned v0 = (unsigned)(16 * q0), v1 = (unsigned)(16 * q1);
+        f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        unsigned so = 0;
+        for (; k + 4 <= splits; k += 4, so += 4 * slice) {
+            const f4 a0 = LBX_RJ_LD(v0, so), b0 = LBX_RJ_LD(v0, so + slice), c0 = LBX_RJ_LD(v0, so + 2 * slice), d0 = LBX_RJ_LD(v0, so + 3 * slice);
+            const f4 a1 = LBX_RJ_LD(v1, so), b1 = LBX_RJ_LD(v1, so + slice), c1 = LBX_RJ_LD(v1, so + 2 * slice), d1 = LBX_RJ_LD(v1, so + 3 * slice);
+            s0 = (((s0 + a0) + b0) + c0) + d0;
+            s1 = (((s1 + a1) + b1) + c1) + d1;
+        }
+        for (; k < splits; ++k, so += slice) {
+            s0 += LBX_RJ_LD(v0, so);
+            s1 += LBX_RJ_LD(v1, so);
+        }
+        put(q0, s0);
+        put(q1, s1);
+    }
+    if (q0 < nquads) {                                                // a thread's last, single quad: eight slices in flight
+        const unsigned v0 = (unsigned)(16 * q0);
+        f4 s0 = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        unsigned so = 0;
+        for (; k + 8 <= splits; k += 8, so += 8 * slice) {
+            const f4 a0 = LBX_RJ_LD(v0, so), b0 = LBX_RJ_LD(v0, so + slice), c0 = LBX_RJ_LD(v0, so + 2 * slice), d0 = LBX_RJ_LD(v0, so + 3 * slice);
+            const f4 e0 = LBX_RJ_LD(v0, so + 4 * slice), f0 = LBX_RJ_LD(v0, so + 5 * slice), g0 = LBX_RJ_LD(v0, so + 6 * slice),
+                     h0 = LBX_RJ_LD(v0, so + 7 * slice);
+            s0 = (((((((s0 + a0) + b0) + c0) + d0) + e0) + f0) + g0) + h0;
+        }
+        for (; k + 4 <= splits; k += 4, so += 4 * slice) {
+            const f4 a0 = LBX_RJ_LD(v0, so), b0 = LBX_RJ_LD(v0, so + slice), c0 = LBX_RJ_LD(v0, so + 2 * slice), d0 = LBX_RJ_LD(v0, so + 3 * slice);
+            s0 = (((s0 + a0) + b0) + c0) + d0;
+        }
+        for (; k < splits; ++k, so += slice) s0 += LBX_RJ_LD(v0, so);
+        put(q0, s0);
+    }
+#undef LBX_RJ_LD
+}
+
+// C[i] (+)= sum_s P[s][i]; bias_grad[n] (+)= sum_s Pc[s][n], four consecutive elements per thread as 16-byte accesses (every
+// element adds its slices in the order 0 .. splits-1: bit-identical to the scalar kernel).  `blk` of `j.nblocks` workgroups.
+// A carried job runs on few workgroups beside a GEMM's tiles, and a pass is a memory round trip under load (microseconds),
+// so the dependent passes per thread are what counts (segment1's 1.5 M-element job on 96 workgroups, one quad per pass: 16
+// passes made those workgroups the launch's long pole) -- hence two quads per pass.
+__device__ __forceinline__ void reduce_job_run(const ReduceJob& j, unsigned blk) {
+    reduce_slices(j.P, j.n, j.splits, j.n >> 2, blk, j.nblocks, j.N, j.Cm, j.ldc, j.accumulate);
+    if (j.bias_grad) reduce_slices(j.Pc, (long)j.N, j.splits, (long)(j.N >> 2), blk, j.nblocks, j.N, j.bias_grad, (long)j.N, j.accumulate);
+}
+
+// up to two pending jobs sharing the leading workgroups of one launch (by-value kernel arguments live in SGPRs: a third job no longer leaves the LDS-DMA statements their scalar operands): job i owns j[i].nblocks consecutive blocks
+constexpr int MAX_CARRY = 2;
+struct ReduceJobs {
+    ReduceJob j[MAX_CARRY];
+    unsigned total = 0;             // sum of j[i].nblocks
+};
+__device__ __forceinline__ void reduce_jobs_run(const ReduceJobs& js, unsigned blk) {
+#pragma unroll
+    for (int i = 0; i < MAX_CARRY; ++i) {
+        if (blk < js.j[i].nblocks) {
+            reduce_job_run(js.j[i], blk);
+            return;
+        }
+        blk -= js.j[i].nblocks;
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(ReduceJobs js) { reduce_jobs_run(js, blockIdx.x); }
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// whether the 16-byte form applies: every quad aligned and inside one row
+inline bool reduce_job_vec_ok(const float* P, const float* Pc, int splits, long n, int N, const float* Cm, long ldc, const float* bias_grad) {
+    // (the 16-byte kernel addresses the slices with 32-bit byte offsets)
+    return N % 4 == 0 && ldc % 4 == 0 && n % 4 == 0 && aligned16(P) && aligned16(Cm) && (!bias_grad || (aligned16(Pc) && aligned16(bias_grad))) &&
+           (double)splits * (double)n * 4.0 < 4.0e9;
+}
+
+// the job of a wgrad's slices; nblocks as the stand-alone launch uses it
+inline ReduceJob make_reduce_job(const float* P, const float* Pc, int splits, long n, int N, float* Cm, long ldc, int accumulate, float* bias_grad) {
+    ReduceJob j;
+    j.P = P; j.Pc = bias_grad ? Pc : nullptr; j.Cm = Cm; j.bias_grad = bias_grad;
+    j.n = n; j.ldc = ldc; j.splits = splits; j.N = N; j.accumulate = accumulate;
+    long g = lbx_cdiv((n + N) / 4, 256);
+    if (g > 2048) g = 2048;
+    j.nblocks = (unsigned)(g < 1 ? 1 : g);
+    return j;
+}
+
+// `njobs` pending jobs as the leading workgroups of a GEMM launch: `cap` blocks (a multiple of 8: block % 8 stays the XCD of
+// the tiles behind them) dealt in proportion to the load batches of each job (quads x ceil(slices / 4)), at least 8 each.
+inline ReduceJobs pack_carry(const ReduceJob* jobs, int njobs, long cap) {
+    ReduceJobs js;
+    double bytes[MAX_CARRY], all = 0.0;
+    int m = 0;
+    for (int i = 0; i < njobs && m < MAX_CARRY; ++i) {
+        if (jobs[i].nblocks == 0) continue;
+        js.j[m] = jobs[i];
+        bytes[m] = (double)jobs[i].n * ((jobs[i].splits + 3) / 4);       // load batches: what a job's workgroups spend their time on
+        all += bytes[m];
+        ++m;
+    }
+    for (int i = 0; i < m; ++i) {
+        long quads = lbx_cdiv((js.j[i].n + (js.j[i].bias_grad ? js.j[i].N : 0)) / 4, 256);
+        long g = (long)((double)cap * bytes[i] / all + 0.5);
+        if (g > quads) g = quads;
+        if (g < 8) g = 8;
+        js.j[i].nblocks = (unsigned)((g + 7) & ~7L);
+        js.total += js.j[i].nblocks;
+    }
+    return js;
+}
 
 // C (+)= sum of the wgrad slices, bias gradient likewise: the 16-byte kernel when every quad is aligned and inside one row
 inline void launch_splitk_reduce(const float* P, const float* Pc, int splits, long n, int N, float* Cm, long ldc, int accumulate,
                                  float* bias_grad, hipStream_t st) {
-    const bool vec = N % 4 == 0 && ldc % 4 == 0 && n % 4 == 0 && aligned16(P) && aligned16(Cm) && (!bias_grad || (aligned16(Pc) && aligned16(bias_grad)));
-    if (vec) {
-        long g = lbx_cdiv((n + N) / 4, 256);
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)g), dim3(256), 0, st, P, Pc, splits, n, N, Cm, ldc, accumulate, bias_grad);
+    if (reduce_job_vec_ok(P, Pc, splits, n, N, Cm, ldc, bias_grad)) {
+        ReduceJobs js;
+        js.j[0] = make_reduce_job(P, Pc, splits, n, N, Cm, ldc, accumulate, bias_grad);
+        js.total = js.j[0].nblocks;
+        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(js.total), dim3(256), 0, st, js);
         return;
     }
     long g = lbx_cdiv(n + N, 256);

@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256, SKP_WGCU) void gemm_skp_rows_kernel(RowsD A, c
 
 // ------------------------------------------------------------------------------------------------
 // wgrad: P[split][K1][N] = A[Mslice, K1]^T . B[Mslice, N];  Pc[split][N] = column sums of B[Mslice]
-// grid = ntiles x splits (consecutive blocks = the tiles of one slice), rows_per_split a multiple of 16.
+// grid = ntiles x splits (the tiles of one slice share an XCD), rows_per_split a multiple of 16.
 // (Slabs in accumulator order with a matching reduce kernel were tried: 16-byte slab stores, but the reduce then scatters
 // four rows per thread -- 135 vs 124 us on frame1's wgrad, 59 vs 55 on frame4's; not kept.)
 // ------------------------------------------------------------------------------------------------
@@ -952,8 +952,11 @@ __global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_tn_kernel(RowsD A, RowsD
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)sk_smem);
-    const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;
+    // block -> (slice, tile) through the XCD-chunk remap: all tiles of a slice on ONE XCD (block % 8), so its panels are fetched
+    // by one L2 (round 3: 2 x the input bytes at the fabric with the tiles of a slice dealt over all eight)
+    const unsigned vb = xcd_chunk_id(blockIdx.x, gridDim.x);
+    const int tile = (int)(vb % (unsigned)ntiles);
+    const int split = (int)(vb / (unsigned)ntiles);
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int i0 = tk * SK_BM, n0 = tn * SK_BN;
     const long mbeg = (long)split * rows_per_split;

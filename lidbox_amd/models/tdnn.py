@@ -222,6 +222,10 @@ class _Workspace:
             din = d.units
         self.gemm_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.gemm_ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)     # wgrad side stream's own workspace
+        # carried reduces (lidbox_hip.h: lidbox_reduce_job_t): a wgrad's slices wait in their workspace until a later GEMM
+        # launch has summed them, so consecutive wgrads alternate between two regions
+        self.tn_regions = (self.gemm_ws2, torch.empty(ws_bytes, dtype=torch.uint8, device=dev))
+        self.pending = []                    # [(nv.ReduceJob, region index)], oldest first
 
     def input_view(self):
         """[B, T, C0] view of where the model input lives: act[0] behind its causal zero rows, or the 2-D front-end's
@@ -731,6 +735,51 @@ class SequentialTDNN:
         return ws.logp
 
     # ------------------------------------------------------------------ backward
+    # Carried reduces.  A wgrad leaves M-slices of partial sums; the fixed-order sum that finishes dW / db is bandwidth-bound
+    # work that used to sit between two MFMA-bound launches.  The library can run it in the leading workgroups of a later
+    # GEMM launch instead (lidbox_gemm_nt_carry / lidbox_gemm_nt_tn_carry; same sums, bit-identical), so the engine keeps
+    # the jobs that are still open in ws.pending and hands them to the next dgrad; whatever is left at the end of a
+    # backward stage goes out as one launch (flush_reduce_jobs).  LIDBOX_GEMM_NO_CARRY=1 keeps every reduce a launch.
+    def _tn_region(self, ws):
+        """index of a wgrad workspace no pending job still reads"""
+        busy = {r for _, r in ws.pending}
+        for r in (0, 1):
+            if r not in busy:
+                return r
+        self.flush_reduce_jobs(ws)
+        return 0
+
+    def _take_jobs(self, ws, limit):
+        """up to `limit` pending jobs as a ctypes array (oldest first; older extras are flushed), removed from the list"""
+        if len(ws.pending) > limit:
+            keep = ws.pending[len(ws.pending) - limit:] if limit > 0 else []
+            ws.pending = ws.pending[:len(ws.pending) - limit]
+            self.flush_reduce_jobs(ws)
+            ws.pending = keep
+        n = len(ws.pending)
+        arr = (nv.ReduceJob * max(1, n))(*[j for j, _ in ws.pending])
+        ws.pending = []
+        return arr, n
+
+    def flush_reduce_jobs(self, ws):
+        """run what is still pending as a launch of its own (end of a backward stage: the gradients must be final)"""
+        while ws.pending:
+            chunk, ws.pending = ws.pending[:2], ws.pending[2:]
+            arr = (nv.ReduceJob * len(chunk))(*[j for j, _ in chunk])
+            nv.check(nv.lib.lidbox_reduce_jobs_run(arr, len(chunk), nv.current_stream()))
+
+    def _dgrad_wgrad(self, ws, dy, W, ldb, dX, Co, N, epi, aux, X, dW, ldc, K1, db):
+        """a layer's dgrad + wgrad on the fp32 family (lidbox_gemm_nt_tn_carry): carries one pending job of an earlier
+        layer, leaves its own reduce pending when the library could not place it inside its launches"""
+        r = self._tn_region(ws)
+        jobs, n = self._take_jobs(ws, 1)
+        out = nv.ReduceJob()
+        tws = ws.tn_regions[r]
+        nv.check(nv.lib.lidbox_gemm_nt_tn_carry(dy, W, ldb, dX, Co, N, epi, aux, nv.ptr(ws.gemm_ws), ws.gemm_ws.numel(), X, dW, ldc, K1, 0, db,
+                                                nv.ptr(tws), tws.numel(), jobs, n, ctypes.byref(out), nv.current_stream()))
+        if out.nblocks:
+            ws.pending.append((out, r))
+
     def _launch_wgrad(self, ws, launch, head=False):
         """launch(workspace_ptr, workspace_bytes, stream): on the side stream (after everything enqueued so
         far on the current stream) when one is configured, else inline.  head: a dense-head wgrad -- those few-workgroup
@@ -758,6 +807,7 @@ class SequentialTDNN:
         self.backward_head_ws(ws)
         for i in range(len(self.convs) - 1, -1, -1):
             self.backward_conv_ws(ws, i)
+        self.flush_reduce_jobs(ws)
         self.join_wgrad()
 
     def backward_head_ws(self, ws):
@@ -785,9 +835,8 @@ class SequentialTDNN:
             if self.dense_gemm.name == "float32" and self.wgrad_stream is None and self.head_wgrad_stream is None:
                 # wgrad and dgrad of the layer read the same dy: one launch when both are small (lidbox_gemm_nt_tn), the
                 # wgrad's partial sums in the second workspace
-                nv.check(lib.lidbox_gemm_nt_tn(dy, self._p(d.name + ".W"), d.units, dst_rows, d.units, din, epi, aux, gws, gws_n,
-                                               A_rows, self._p(d.name + ".W", True), d.units, din, 0, self._p(d.name + ".b", True),
-                                               nv.ptr(ws.gemm_ws2), ws.gemm_ws2.numel(), st))
+                self._dgrad_wgrad(ws, dy, self._p(d.name + ".W"), d.units, dst_rows, d.units, din, epi, aux,
+                                  A_rows, self._p(d.name + ".W", True), d.units, din, self._p(d.name + ".b", True))
                 continue
             self._launch_wgrad(ws, lambda w, n, s_, A_rows=A_rows, dy=dy, d=d, din=din: nv.check(self.dense_gemm.tn(
                 A_rows, dy, self._p(d.name + ".W", True), d.units, din, d.units, 0, self._p(d.name + ".b", True), w, n, s_)),
@@ -864,11 +913,28 @@ class SequentialTDNN:
         if dy16 is not None and ws.act16[i] is not None and self.shadow_wgrad_ok(i):
             # wgrad on the shadows (transpose-read operands, half the bytes of the fp32-source kernel)
             A16, B16 = self._rows16(A_rows, ws.act[i], ws.act16[i]), self._rows16(dy, ws.dact[i + 1], dy16)
-            self._launch_wgrad(ws, lambda w, n, s_: nv.check(lib.lidbox_gemm_bf16s_tn(
-                A16, B16, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
+            if self.wgrad_stream is None:
+                # the GEMM now; its slice sum rides in this layer's first dgrad launch (or the stage's flush)
+                r = self._tn_region(ws)
+                job, tws = nv.ReduceJob(), ws.tn_regions[r]
+                nv.check(lib.lidbox_gemm_bf16s_tn_partial(A16, B16, self._p(c.name + ".W", True), c.filters, K, c.filters, 0,
+                                                          self._p(c.name + ".b", True), nv.ptr(tws), tws.numel(), ctypes.byref(job), st))
+                if job.nblocks:
+                    ws.pending.append((job, r))
+            else:
+                self._launch_wgrad(ws, lambda w, n, s_: nv.check(lib.lidbox_gemm_bf16s_tn(
+                    A16, B16, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
         elif (self.gemm.name == "float32" and self.wgrad_stream is None and not self.bf16_storage and
               not (i == 0 and not self.frontend)):
             pair_wgrad = True             # goes out with the first dgrad group below (lidbox_gemm_nt_tn: one launch when both are small)
+        elif self.gemm.name == "float32" and self.wgrad_stream is None and not self.bf16_storage:
+            # no dgrad behind it (the first layer): the GEMM now, its reduce with whatever the stage still has pending
+            r = self._tn_region(ws)
+            job, tws = nv.ReduceJob(), ws.tn_regions[r]
+            nv.check(lib.lidbox_gemm_tn_partial(A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0,
+                                                self._p(c.name + ".b", True), nv.ptr(tws), tws.numel(), ctypes.byref(job), st))
+            if job.nblocks:
+                ws.pending.append((job, r))
         else:
             self._launch_wgrad(ws, lambda w, n, s_: nv.check(self.gemm.tn(
                 A_rows, dy, self._p(c.name + ".W", True), c.filters, K, c.filters, 0, self._p(c.name + ".b", True), w, n, s_)))
@@ -900,7 +966,9 @@ class SequentialTDNN:
                 elif relu_prev:
                     epi, mask = nv.EPI_RELU_MASK, ctypes.c_void_p(aprev.data_ptr() + 4 * p0 * cin)
                 sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + 2 * p0 * cin)
-                nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin, epi, mask, gws, gws_n, st))
+                jobs, nj = self._take_jobs(ws, 2)
+                nv.check(lib.lidbox_gemm_bf16s_nt_carry(A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin, epi, mask, gws, gws_n,
+                                                        jobs, nj, st))
             if d16 is not None:
                 ws.d16_fresh.add(i)
             return
@@ -934,16 +1002,17 @@ class SequentialTDNN:
                     Cd = _rows(None, Tp * cin, c.s * cin, B, To)
                     if relu_prev:
                         epi, mask = epi | nv.EPI_MASK_BF16, ctypes.c_void_p(ws.act16[i].data_ptr() + base_off // 2)
+                jobs, nj = self._take_jobs(ws, 2)
                 if fused16 is not None:                          # padded channel rows on both operands (pad columns are zero)
                     cp = fused16.shape[1]
-                    nv.check(lib.lidbox_gemm_bf16s_nt(A16, nv.ptr(fused16), cp, Cd, sh, cp, ntaps * cin, epi, mask, gws, gws_n, st))
+                    nv.check(lib.lidbox_gemm_bf16s_nt_carry(A16, nv.ptr(fused16), cp, Cd, sh, cp, ntaps * cin, epi, mask, gws, gws_n, jobs, nj, st))
                 else:
                     Wg16 = ctypes.c_void_p(self._p16(c.name + ".W").value + 2 * g * c.s * cin * c.filters)
-                    nv.check(lib.lidbox_gemm_bf16s_nt(A16, Wg16, c.filters, Cd, sh, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
+                    nv.check(lib.lidbox_gemm_bf16s_nt_carry(A16, Wg16, c.filters, Cd, sh, c.filters, ntaps * cin, epi, mask, gws, gws_n,
+                                                            jobs, nj, st))
             elif pair_wgrad and g == 0:
-                nv.check(lib.lidbox_gemm_nt_tn(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n,
-                                               A_rows, self._p(c.name + ".W", True), c.filters, K, 0, self._p(c.name + ".b", True),
-                                               nv.ptr(ws.gemm_ws2), ws.gemm_ws2.numel(), st))
+                self._dgrad_wgrad(ws, dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask,
+                                  A_rows, self._p(c.name + ".W", True), c.filters, K, self._p(c.name + ".b", True))
             else:
                 nv.check(self.gemm.nt(dy, Wg, c.filters, Cd, c.filters, ntaps * cin, epi, mask, gws, gws_n, st))
         if i == 0:

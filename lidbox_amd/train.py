@@ -350,6 +350,7 @@ class Trainer:
             self.model.backward_head_ws(ws)
         for i in range(hi_edges[k] - 1, lo_edges[k] - 1, -1):
             self.model.backward_conv_ws(ws, i)
+        self.model.flush_reduce_jobs(ws)       # carried wgrad reduces still open: the stage's gradient bucket must be final
         self.model.join_wgrad()
 
     @property

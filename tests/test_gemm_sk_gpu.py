@@ -8,6 +8,8 @@ ragged M / N edges, implicit-row (conv layout) operands and outputs, every epilo
 configs[1], bs 256) run on the real 768-workgroup grid at the end.
 Tolerance: rel 2e-5 of the result scale vs float64 (fp32 round-off of a K-long fmaf chain), as in test_ops_gpu.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -443,3 +445,165 @@ def test_dgrad_wgrad_pair_shared_workspace_and_bad_arguments():
     rc = nv.lib.lidbox_gemm_nt_tn(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, nv.EPI_RELU_MASK, None, nv.ptr(ws),
                                   ws.numel(), _rows(x, 0, K1, 1, M), nv.ptr(dw), Co, K1, 0, nv.ptr(db), nv.ptr(ws), ws.numel(), st)
     assert rc != 0 and b"aux" in nv.lib.lidbox_hip_last_error()
+
+
+@pytest.mark.parametrize("M,Co,N,K1,epi,accumulate,bias", [
+    (8448, 512, 512, 1536, "mask", 0, True),       # frame3 at bs 256: whole rounds + a streamed remainder behind the carried blocks
+    (8448, 1500, 512, 512, "none", 0, True),       # frame5: K tail (1500), 64 x 64 tiles
+    (4100, 512, 1024, 512, "mask", 1, False),      # ragged rows, accumulate into dW, no bias gradient
+    (700, 256, 192, 200, "none", 0, True),         # fewer tiles than one round; K1 = 200 (frame1's width)
+])
+def test_carried_reduce_is_bit_identical_to_the_separate_launches(M, Co, N, K1, epi, accumulate, bias, monkeypatch):
+    """lidbox_gemm_tn_partial + lidbox_gemm_nt_carry (the wgrad's fixed-order slice sum in the leading workgroups of the dgrad
+    launch) == lidbox_gemm_tn + lidbox_gemm_nt bit for bit, == the job run on its own, == LIDBOX_GEMM_NO_CARRY=1; float64 to
+    round-off.  Reference shapes: lidbox/models/xvector.py:53-57 backward."""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(M + N + K1)
+    dY, W, X = rng.standard_normal((M, Co)), rng.standard_normal((N, Co)) * 0.1, rng.standard_normal((M, K1))
+    mask, dW0 = rng.standard_normal((M, N)), rng.standard_normal((K1, Co))
+    dy, w, x, mk = _dev(dY), _dev(W), _dev(X), _dev(mask)
+    st = nv.current_stream()
+    ws1 = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, Co), 16) + 1024)
+    ws2 = _garbage_ws(max(nv.lib.lidbox_gemm_tn_workspace(M, K1, Co), 16) + 1024)
+    e = nv.EPI_RELU_MASK if epi == "mask" else nv.EPI_NONE
+    aux = nv.ptr(mk) if epi == "mask" else None
+
+    def run(mode):
+        dx = torch.full((M, N), 9.0, device="cuda")
+        dw = _dev(dW0).clone()
+        db = torch.full((Co,), 9.0, device="cuda") if bias else None
+        A, Bd, Cx = _rows(x, 0, K1, 1, M), _rows(dy, 0, Co, 1, M), _rows(dx, 0, N, 1, M)
+        carried = None
+        if mode == "plain":
+            nv.check(nv.lib.lidbox_gemm_tn(A, Bd, nv.ptr(dw), Co, K1, Co, accumulate, nv.ptr(db), nv.ptr(ws2), ws2.numel(), st))
+            nv.check(nv.lib.lidbox_gemm_nt(Bd, nv.ptr(w), Co, Cx, Co, N, e, aux, nv.ptr(ws1), ws1.numel(), st))
+        else:
+            job = nv.ReduceJob()
+            nv.check(nv.lib.lidbox_gemm_tn_partial(A, Bd, nv.ptr(dw), Co, K1, Co, accumulate, nv.ptr(db), nv.ptr(ws2), ws2.numel(),
+                                                   nv.C.byref(job), st))
+            assert job.nblocks > 0 and job.splits >= 1 and job.n == K1 * Co
+            if mode == "job_alone":
+                nv.check(nv.lib.lidbox_reduce_jobs_run(nv.C.byref(job), 1, st))
+                nv.check(nv.lib.lidbox_gemm_nt_carry(Bd, nv.ptr(w), Co, Cx, Co, N, e, aux, nv.ptr(ws1), ws1.numel(), None, 0, st))
+            else:
+                nv.check(nv.lib.lidbox_gemm_nt_carry(Bd, nv.ptr(w), Co, Cx, Co, N, e, aux, nv.ptr(ws1), ws1.numel(), nv.C.byref(job), 1, st))
+                carried = nv.lib.lidbox_gemm_last_carried()
+        torch.cuda.synchronize()
+        return (dx, dw) + ((db,) if bias else ()), carried
+
+    ref, _ = run("plain")
+    got, carried = run("carry")
+    assert carried == 1, "16-byte aligned operands: the reduce must ride in the dgrad launch"
+    for u, v in zip(got, ref):
+        assert torch.equal(u, v)
+    alone, _ = run("job_alone")
+    for u, v in zip(alone, ref):
+        assert torch.equal(u, v)
+    monkeypatch.setenv("LIDBOX_GEMM_NO_CARRY", "1")
+    off, carried = run("carry")
+    assert carried == 0
+    for u, v in zip(off, ref):
+        assert torch.equal(u, v)
+    monkeypatch.delenv("LIDBOX_GEMM_NO_CARRY")
+    monkeypatch.setenv("LIDBOX_GEMM_CARRY_BLOCKS", "8")            # a handful of blocks walk the whole job
+    few, carried = run("carry")
+    assert carried == 1
+    for u, v in zip(few, ref):
+        assert torch.equal(u, v)
+    ref_dx = dY @ W.T
+    if epi == "mask":
+        ref_dx = ref_dx * (mask > 0)
+    _close(got[0].cpu().numpy(), ref_dx)
+    _close(got[1].cpu().numpy(), X.T @ dY + (dW0 if accumulate else 0.0))
+    if bias:
+        _close(got[2].cpu().numpy(), dY.sum(0), rel=1e-5)
+
+
+def test_carried_reduce_conv_layout_and_rejections():
+    """the dgrad writes a strided, batched activation-gradient buffer (frame3's layout: k 3, s 3) while it carries the reduce;
+    a job whose slices sit in the dgrad's own workspace is refused"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(5)
+    B, To, Co, cin, k, s = 64, 33, 512, 512, 3, 3
+    Tp = To * s + 2
+    M, N, K1 = B * To, k * cin, k * cin
+    dY, W = rng.standard_normal((M, Co)), rng.standard_normal((N, Co)) * 0.1
+    act = rng.standard_normal((B, Tp, cin))
+    dy, w, a = _dev(dY), _dev(W), _dev(act)
+    st = nv.current_stream()
+    ws1 = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, Co), 16) + 1024)
+    ws2 = _garbage_ws(max(nv.lib.lidbox_gemm_tn_workspace(M, K1, Co), 16) + 1024)
+    A = _rows(a, Tp * cin, s * cin, B, To)                      # implicit rows: window t = padded rows [t*s, t*s + k)
+    outs = []
+    for carry in (False, True):
+        dprev = torch.zeros((B, Tp, cin), device="cuda")
+        dw = torch.zeros((K1, Co), device="cuda"); db = torch.zeros((Co,), device="cuda")
+        Cd = _rows(dprev, Tp * cin, s * cin, B, To)
+        if carry:
+            job = nv.ReduceJob()
+            nv.check(nv.lib.lidbox_gemm_tn_partial(A, _rows(dy, 0, Co, 1, M), nv.ptr(dw), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws2), ws2.numel(),
+                                                   nv.C.byref(job), st))
+            rc = nv.lib.lidbox_gemm_nt_carry(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, Cd, Co, N, nv.EPI_RELU_MASK, nv.ptr(a), nv.ptr(ws2),
+                                             ws2.numel(), nv.C.byref(job), 1, st)
+            assert rc != 0 and b"workspace" in nv.lib.lidbox_hip_last_error()
+            nv.check(nv.lib.lidbox_gemm_nt_carry(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, Cd, Co, N, nv.EPI_RELU_MASK, nv.ptr(a), nv.ptr(ws1),
+                                                 ws1.numel(), nv.C.byref(job), 1, st))
+            assert nv.lib.lidbox_gemm_last_carried() == 1
+        else:
+            nv.check(nv.lib.lidbox_gemm_tn(A, _rows(dy, 0, Co, 1, M), nv.ptr(dw), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws2), ws2.numel(), st))
+            nv.check(nv.lib.lidbox_gemm_nt(_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, Cd, Co, N, nv.EPI_RELU_MASK, nv.ptr(a), nv.ptr(ws1),
+                                           ws1.numel(), st))
+        outs.append((dprev, dw, db))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    cols = np.stack([act[:, t * s:t * s + k, :].reshape(B, k * cin) for t in range(To)], axis=1).reshape(M, K1)
+    _close(outs[1][1].cpu().numpy(), cols.T @ dY)
+    ref = (dY @ W.T).reshape(B, To, k, cin)
+    full = np.zeros((B, Tp, cin))
+    for t in range(To):
+        full[:, t * s:t * s + k, :] = ref[:, t] * (act[:, t * s:t * s + k, :] > 0)
+    _close(outs[1][0].cpu().numpy(), full)
+
+
+def test_pair_launch_hands_its_reduce_on_and_carries_an_earlier_one(monkeypatch):
+    """the dense head under the engine: segment2's pair launch leaves its wgrad reduce as a job, segment1's pair launch
+    carries it in its leading workgroups and leaves its own, which a conv-size dgrad then carries together with that
+    layer's reduce (two jobs in one launch); everything equals the plain sequence of calls bit for bit"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(17)
+    st = nv.current_stream()
+    shapes = [(256, 512, 512, 512), (256, 512, 3000, 3000), (8448, 1500, 512, 512)]          # (M, Co, N, K1): segment2, segment1, frame5
+    data = []
+    for M, Co, N, K1 in shapes:
+        data.append(tuple(_dev(x) for x in (rng.standard_normal((M, Co)), rng.standard_normal((N, Co)) * 0.1, rng.standard_normal((M, K1)))))
+    ws_nt = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, Co) for M, Co, N, K1 in shapes) + 1024)
+    need_tn = max(nv.lib.lidbox_gemm_tn_workspace(M, K1, Co) for M, Co, N, K1 in shapes) + 1024
+    regions = [_garbage_ws(need_tn), _garbage_ws(need_tn)]
+
+    def run(carry):
+        outs, pending = [], []
+        for li, ((M, Co, N, K1), (dy, w, x)) in enumerate(zip(shapes, data)):
+            dx = torch.full((M, N), 9.0, device="cuda"); dw = torch.full((K1, Co), 9.0, device="cuda"); db = torch.full((Co,), 9.0, device="cuda")
+            args = (_rows(dy, 0, Co, 1, M), nv.ptr(w), Co, _rows(dx, 0, N, 1, M), Co, N, nv.EPI_NONE, None, nv.ptr(ws_nt), ws_nt.numel(),
+                    _rows(x, 0, K1, 1, M), nv.ptr(dw), Co, K1, 0, nv.ptr(db), nv.ptr(regions[li % 2]), regions[li % 2].numel())
+            if carry:
+                jobs = (nv.ReduceJob * 1)(*pending)
+                out = nv.ReduceJob()
+                nv.check(nv.lib.lidbox_gemm_nt_tn_carry(*args, jobs, len(pending), nv.C.byref(out), st))
+                if not os.environ.get("LIDBOX_GEMM_NO_CARRY"):
+                    assert nv.lib.lidbox_gemm_last_carried() == len(pending) + (0 if li < 2 else 1)
+                pending = [out] if out.nblocks else []
+                assert bool(out.nblocks) == (li < 2)          # the M = 256 pair launches hand their reduce on, the conv layer does not
+            else:
+                nv.check(nv.lib.lidbox_gemm_nt_tn(*args, st))
+            outs += [dx, dw, db]
+        assert not pending
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    monkeypatch.setenv("LIDBOX_GEMM_NO_CARRY", "1")
+    for u, v in zip(run(True), b):
+        assert torch.equal(u, v)
