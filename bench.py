@@ -76,6 +76,11 @@ def parse_args():
     ap.add_argument("--resident-batches", type=int, default=4,
                     help="different batches kept in HBM per rank; the timed loop rotates over them")
     ap.add_argument("--config", type=int, choices=[1, 3, 4], default=1, help="BASELINE.json configs[] index (see the module docstring)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="extract the NEXT batch's features during the running step on a second stream (Trainer.train_step next_inputs) "
+                         "instead of at the start of its own step.  Off by default: measured slower inside the captured step (fp32 "
+                         "2.243 vs 2.220 ms, bf16 0.785 vs 0.767 ms at bs 256, profiles/r04_feature_prefetch_ab.txt) -- the fork / "
+                         "join edges of the graph cost more than the 30 us kernel they hide")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default run (config 1, fp32, one GPU) only: do not append the configs[3] fp32 and configs[4] bf16-shard "
                          "measurements as `secondary` (profiling passes use this so that per-kernel counters are not mixed across workloads)")
@@ -395,20 +400,25 @@ def resident_batches(n, B, world, rank, num_langs, dev):
     return out
 
 
-def timed_steps(trainer, batches, warmup, steps, sync_all):
+def timed_steps(trainer, batches, warmup, steps, sync_all, prefetch=False):
     """one untimed pass over every resident batch captures its graph (so that no capture lands in the timed region
     whatever --warmup is), then the W warm-up steps, then exactly K timed steps between two barrier + synchronize pairs"""
+    # prefetch: the features of step i + 1's batch are extracted during step i on a second stream (Trainer.train_step
+    # next_inputs; every batch's features are still computed once per step it is used in, inside the timed region)
+    n = len(batches)
+    nxt = (lambda i: dict(next_inputs=batches[(i + 1) % n][0])) if prefetch else (lambda i: {})
     first_loss = None
-    for xb, yb in batches:
-        l0 = trainer.train_step(xb, yb)
-        if first_loss is None:
-            first_loss = float(l0)
+    for rep in range(2 if prefetch else 1):          # prefetch: the second pass captures the steady-state (features ready) graphs
+        for i, (xb, yb) in enumerate(batches):
+            l0 = trainer.train_step(xb, yb, **nxt(i))
+            if first_loss is None:
+                first_loss = float(l0)
     for i in range(warmup):
-        trainer.train_step(*batches[i % len(batches)])
+        trainer.train_step(*batches[i % n], **nxt(i))
     sync_all()
     t0 = time.perf_counter()
     for i in range(steps):
-        loss = trainer.train_step(*batches[i % len(batches)])
+        loss = trainer.train_step(*batches[(warmup + i) % n], **nxt(warmup + i))
     sync_all()
     return time.perf_counter() - t0, first_loss, float(loss)
 
@@ -470,7 +480,7 @@ def secondary_run(nv, config, compute_dtype, B, dev, args):
 
     def sync_all():
         torch.cuda.synchronize(dev)
-    elapsed, first_loss, final_loss = timed_steps(trainer, batches, args.warmup, args.steps, sync_all)
+    elapsed, first_loss, final_loss = timed_steps(trainer, batches, args.warmup, args.steps, sync_all, prefetch=args.prefetch)
     if not np.isfinite(final_loss):
         raise SystemExit("non-finite loss %r in secondary config %d" % (final_loss, config))
     ms = 1e3 * elapsed / args.steps
@@ -527,7 +537,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    elapsed_local, first_loss, final_loss = timed_steps(trainer, batches, args.warmup, args.steps, sync_all)
+    elapsed_local, first_loss, final_loss = timed_steps(trainer, batches, args.warmup, args.steps, sync_all, prefetch=args.prefetch)
     elapsed = elapsed_local
     rank_ms = None
     if world > 1:
@@ -546,8 +556,12 @@ def main():
     # per-step HIP events over K more steps (outside the timed region): the distribution behind the wall-clock mean
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for i, (e0, e1) in enumerate(evs):
+        j = args.warmup + args.steps + i                      # continue the rotation of the timed loop
         e0.record()
-        trainer.train_step(*batches[i % len(batches)])
+        if not args.prefetch:
+            trainer.train_step(*batches[j % len(batches)])
+        else:
+            trainer.train_step(*batches[j % len(batches)], next_inputs=batches[(j + 1) % len(batches)][0])
         e1.record()
     torch.cuda.synchronize(dev)
     step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
@@ -572,6 +586,7 @@ def main():
                    "grad_sync": trainer.grad_sync_mode,
                    "allreduce_bytes_per_step": 4 * int(w["model"].num_flat) if sync_active else 0,
                    "hip_graph": not args.no_graph, "resident_batches": len(batches),
+                   "feature_prefetch": bool(args.prefetch),
                    "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6),
                    "loss_note": "SURVEY 8d's synthetic languages (one sine frequency each) are separable: the loss reaches ~0 within a "
                                 "few dozen Adam steps; every step still runs the full dense forward / backward / optimizer work"},

@@ -227,6 +227,20 @@ class _Workspace:
         self.tn_regions = (self.gemm_ws2, torch.empty(ws_bytes, dtype=torch.uint8, device=dev))
         self.pending = []                    # [(nv.ReduceJob, region index)], oldest first
 
+    def select_input_buffer(self, parity):
+        """Double-buffered model input (Trainer's feature prefetch: the features of batch t + 1 are extracted beside the
+        GEMMs of step t, the counterpart of the tf.data prefetch around lidbox/data/steps.py:725-736): makes act[0] (and its
+        bf16 shadow) the buffer `parity`; the second one is allocated on first use.  Every descriptor of the first layer is
+        derived from act[0] when a step is issued / captured."""
+        if hasattr(self, "fe_in"):
+            raise ValueError("no double-buffered input behind a 2-D front-end")
+        if not hasattr(self, "_in_bufs"):
+            self._in_bufs = [(self.act[0], self.act16[0]), None]
+        if self._in_bufs[parity] is None:
+            a16 = self.act16[0]
+            self._in_bufs[parity] = (torch.zeros_like(self.act[0]), None if a16 is None else torch.zeros_like(a16))
+        self.act[0], self.act16[0] = self._in_bufs[parity]
+
     def input_view(self):
         """[B, T, C0] view of where the model input lives: act[0] behind its causal zero rows, or the 2-D front-end's
         input buffer."""

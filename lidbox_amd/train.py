@@ -203,6 +203,9 @@ class Trainer:
         self._step_global_batch = None   # what the caller of the running step passed (train_step(..., global_batch=))
         self.grad_sync_mode = "none"     # what the last built step does with the gradient exchange: none | in_graph | segmented | eager
         self._size_stream = None
+        self._feat_ready = {}            # id(workspace) -> (data_ptr, shape of the waveforms whose features a prefetch left, buffer parity)
+        self._prefetch_stream = None
+        self._step_feat = None           # (skip_inline_features, next_inputs or None, parity of the prefetch target) of the step being issued
 
     @property
     def adam_state(self):
@@ -225,17 +228,25 @@ class Trainer:
         # model -- bench.py's eager one -- must not re-key the first one's masks)
         model.dropout_step = self.adam_state
         model.dropout_seed_mix = self._rank_mix()
+        skip_inline, nxt, nxt_parity = self._step_feat or (False, None, 0)
+        if nxt is not None:
+            # feature prefetch: the NEXT batch's features, extracted on a second stream beside this step's MFMA-bound GEMMs into
+            # the other input buffer (vector-ALU-bound work under matrix-pipe-bound work; joined behind the forward pass)
+            if self._prefetch_stream is None:
+                self._prefetch_stream = torch.cuda.Stream(device=self.device)
+            cur_parity = 1 - nxt_parity
+            ws.select_input_buffer(nxt_parity)
+            side = self._prefetch_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._extract_features(ws, nxt, nv.current_stream())
+            ws.select_input_buffer(cur_parity)
+        elif hasattr(ws, "_in_bufs"):
+            ws.select_input_buffer(0)
         in_ptr, in_bs, _, C = ws.input_target()              # act[0] behind the first Conv1D's causal zero rows, or the 2-D front-end's input
         if self.feature is not None:
-            plan, kind = self.feature["plan"], self.feature["kind"]
-            Bn, N = inputs.shape
-            stride = inputs.stride(0) if Bn > 1 else N
-            # features land directly in the model's input buffer
-            nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(inputs), Bn, N, stride, in_ptr,
-                                                     in_bs, None, 0, st))
-            if self.feature.get("cmvn"):
-                # per-utterance CMVN over time (features/__init__.py:22-32), in place where the conv reads it
-                nv.check(lib.lidbox_cmvn_strided_fwd(in_ptr, Bn, ws.T, C, in_bs, 1, in_ptr, in_bs, st))
+            if not skip_inline:
+                self._extract_features(ws, inputs, st)
         else:
             if inputs.stride(2) != 1 or inputs.stride(1) != C:
                 inputs = inputs.contiguous()
@@ -281,6 +292,21 @@ class Trainer:
                 self.metric._update_sparse(labels, ws.ap_scores)
         if self.loss_kind == "nll" and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)
+        if nxt is not None:
+            torch.cuda.current_stream().wait_stream(self._prefetch_stream)      # the prefetch joins behind the forward pass
+
+    def _extract_features(self, ws, signals, st):
+        """waveforms -> the model's input buffer (ws.act[0] as currently selected): fused log-mel / MFCC kernel, CMVN in place"""
+        lib = nv.lib
+        in_ptr, in_bs, _, C = ws.input_target()
+        plan, kind = self.feature["plan"], self.feature["kind"]
+        Bn, N = signals.shape
+        stride = signals.stride(0) if Bn > 1 else N
+        # features land directly in the model's input buffer
+        nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(signals), Bn, N, stride, in_ptr, in_bs, None, 0, st))
+        if self.feature.get("cmvn"):
+            # per-utterance CMVN over time (features/__init__.py:22-32), in place where the conv reads it
+            nv.check(lib.lidbox_cmvn_strided_fwd(in_ptr, Bn, ws.T, C, in_bs, 1, in_ptr, in_bs, st))
 
     def _rank_mix(self):
         """per-rank offset of every dropout seed under data parallelism (0 for a single process)"""
@@ -488,12 +514,17 @@ class Trainer:
         return entry
 
     # ---------------------------------------------------------------- public API
-    def train_step(self, inputs, labels, global_batch=None):
+    def train_step(self, inputs, labels, global_batch=None, next_inputs=None):
         """One optimisation step on this rank's shard.  inputs: waveforms [B,N] (feature != None) or
         features [B,T,C]; labels int32 [B].  Both must stay alive and at the same address between
         calls that reuse the captured graph (pass the same tensors, refilled in place).
         global_batch (data parallelism): the number of utterances of this step over ALL ranks; pass it whenever the ranks'
         shard sizes do not all change together (see `_loss_scale`).
+        next_inputs (waveform input only): the waveforms of the NEXT step.  Their features are then extracted during this
+        step, on a second stream beside its GEMMs, into the other half of a double-buffered model input, and the next
+        call -- which must pass exactly that tensor as `inputs` -- skips its own extraction (the counterpart of the tf.data
+        prefetch around the reference's feature step, lidbox/data/steps.py:725-736).  Every batch's features are still
+        computed exactly once, one step early; a call whose `inputs` were not prefetched extracts them in line.
         Returns the device scalar holding this rank's mean loss."""
         inputs = nv.require_gpu_tensor(inputs, "inputs", torch.float32)
         labels = nv.require_gpu_tensor(labels, "labels", torch.int32)
@@ -502,10 +533,25 @@ class Trainer:
         key = (inputs.data_ptr(), labels.data_ptr(), tuple(inputs.shape), tuple(inputs.stride()),
                None if global_batch is None else int(global_batch))
         self._step_global_batch = None if global_batch is None else int(global_batch)
+        feat_mode, ws_key = None, None
+        if self.feature is not None and not self.model.frontend:
+            ws_key = (int(inputs.shape[0]), int(self.feature["plan"].num_frames(inputs.shape[1])))
+            if next_inputs is not None:
+                next_inputs = nv.require_gpu_tensor(next_inputs, "next_inputs", torch.float32)
+                if tuple(next_inputs.shape) != tuple(inputs.shape) or tuple(next_inputs.stride()) != tuple(inputs.stride()):
+                    raise ValueError("next_inputs must have the shape and strides of inputs")
+                ready = self._feat_ready.get(ws_key)
+                have = ready is not None and ready[0] == inputs.data_ptr()
+                parity = ready[1] if have else 0                  # the buffer this step's features are (or will be) in
+                feat_mode = (have, next_inputs, 1 - parity)
+                key = key + (next_inputs.data_ptr(), have, parity)
+        elif next_inputs is not None:
+            raise ValueError("next_inputs needs a Trainer with a waveform feature front-end (and no 2-D front-end)")
+        self._step_feat = feat_mode
         with torch.cuda.device(self.device):
             entry = self._graphs.get(key)
             if entry is None:
-                if len(self._graphs) >= 4:
+                if len(self._graphs) >= 16:
                     self._graphs.pop(next(iter(self._graphs)))
                 entry = self._build(inputs, labels)
                 self._graphs[key] = entry
@@ -523,6 +569,12 @@ class Trainer:
                 self.sync.wait()
                 run[-1]()                                         # Adam
             self._lr_advance()
+            if ws_key is not None:
+                if feat_mode is not None:
+                    self._feat_ready[ws_key] = (next_inputs.data_ptr(), feat_mode[2])
+                else:
+                    self._feat_ready.pop(ws_key, None)
+            self._step_feat = None
             if self.sync_state_every_step:
                 self.sync_state()
             return ws.loss[0]
@@ -548,6 +600,8 @@ class Trainer:
             B = inputs.shape[0]
             T = self.feature["plan"].num_frames(inputs.shape[1]) if self.feature is not None else inputs.shape[1]
             ws = self.model.workspace(B, T)
+            self._feat_ready.pop((int(B), int(T)), None)          # the probe may overwrite a prefetched input buffer
+            self._step_feat = None
             was = self._warming
             self._warming = True                 # a probe, not a step: BatchNormalization running statistics and streaming metrics stay put
             try:

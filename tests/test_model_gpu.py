@@ -196,6 +196,48 @@ def test_train_step_from_waveforms_writes_features_in_place():
     assert torch.equal(m1.flat, m2.flat)
 
 
+@pytest.mark.parametrize("use_graph,kind,dtype", [(True, "logmel", "float32"), (False, "logmel", "float32"), (True, "mfcc_cmvn", "float32"),
+                                                  (True, "logmel", "bfloat16")])
+def test_feature_prefetch_equals_in_line_extraction(use_graph, kind, dtype):
+    """Trainer.train_step(next_inputs=): the next batch's features are extracted during the running step on a second stream
+    into the other half of the double-buffered model input (the tf.data prefetch of lidbox/data/steps.py:725-736).  Rotating
+    over three batches, losses and weights equal the in-line path bit for bit; a batch that was NOT announced is extracted in
+    line (no stale buffer is ever consumed)."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import cnn, xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    plan = audio.get_plan(16000, 400, 160)
+    if kind == "logmel":
+        mk = lambda: xvector.create((98, 40), 4, seed=0, compute_dtype=dtype)
+        feature = dict(plan=plan, kind=nv.FEAT_LOGMEL)
+    else:
+        mk = lambda: cnn.create((98, 12), 4, seed=0)
+        feature = dict(plan=plan, kind=nv.FEAT_MFCC, cmvn=True)
+    batches = []
+    for i in range(3):
+        sig, y = synthetic_batch(6, num_labels=4, duration_s=1.0, seed=40 + i)
+        batches.append((_dev(sig), _dev(y, np.int32)))
+    m1, m2 = mk(), mk()
+    t1 = Trainer(m1, feature=dict(feature), use_graph=use_graph)
+    t2 = Trainer(m2, feature=dict(feature), use_graph=use_graph)
+    order = [0, 1, 2, 0, 1, 2, 2, 0, 1]                   # the repeated 2 was announced as 0: must fall back to in-line extraction
+    announced = [1, 2, 0, 1, 2, 0, 0, 1, 2]
+    for i, a in zip(order, announced):
+        la = float(t1.train_step(*batches[i], next_inputs=batches[a][0]))
+        lb = float(t2.train_step(*batches[i]))
+        assert la == lb, (i, la, lb)
+    assert torch.equal(m1.flat, m2.flat)
+    # a probe in between invalidates the prefetched buffer instead of consuming it
+    t1.loss_and_grads(*batches[1])
+    la, lb = float(t1.train_step(*batches[2], next_inputs=batches[0][0])), float(t2.train_step(*batches[2]))
+    assert la == lb and torch.equal(m1.flat, m2.flat)
+    with pytest.raises(ValueError):
+        Trainer(mk(), use_graph=False).train_step(torch.zeros((6, 98, 40 if kind == "logmel" else 12), device="cuda"), batches[0][1],
+                                                  next_inputs=batches[0][0])
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 7), (2, 5, 40), (4, 50, 13), (10, 400, 100), (2, 198, 40)])
 def test_models_valid_output_any_shape(shape):
     """reference tests/test_models.py:30-35,65-68,104-107: [B,num_outputs], no NaN, training in {F,T}"""
