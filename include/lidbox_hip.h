@@ -257,6 +257,10 @@ int lidbox_gemm_nt_tn_carry(lidbox_rows_t dY, const float* W, long ldb, lidbox_r
                             const lidbox_reduce_job_t* jobs, int njobs, lidbox_reduce_job_t* job_out, lidbox_stream_t stream);
 int lidbox_reduce_jobs_run(const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream);
 int lidbox_gemm_last_carried(void);
+/* A zero fill as a job (splits = 0): `batch` runs of row_floats zeros at base, batch_stride floats apart (16-byte aligned,
+ * multiples of 4).  Carried like a reduce -- the pad rows a strided Conv1D's accumulating dgrad groups do not all cover
+ * (Keras Conv1D(strides), xvector.py:53-57 backward) are cleared inside the group-0 launch instead of by a fill launch. */
+int lidbox_zero_job(float* base, long batch_stride, long row_floats, int batch, lidbox_reduce_job_t* job);
 
 /* A layer's dgrad and wgrad in one call -- both read the output gradient dY [M, Co]:
  *     dX rows = epilogue(dY . W^T)        exactly lidbox_gemm_nt(dY, W, ldb, dX, Co, N, epilogue, aux, ws_nt, ...)

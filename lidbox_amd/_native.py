@@ -100,6 +100,7 @@ _SIGS = {
                                      C.POINTER(ReduceJob), _i, C.POINTER(ReduceJob), _vp]),
     "lidbox_reduce_jobs_run": (_i, [C.POINTER(ReduceJob), _i, _vp]),
     "lidbox_gemm_last_carried": (_i, []),
+    "lidbox_zero_job": (_i, [_vp, _l, _l, _i, C.POINTER(ReduceJob)]),
     "lidbox_gemm_bf16_rows_workspace": (_sz, [_l, _i, _i]),
     "lidbox_gemm_bf16_nn": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "lidbox_gemm_bf16_nt": (_i, [Rows, _vp, _l, Rows, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -1434,6 +1434,22 @@ extern "C" int lidbox_gemm_tn_partial(lidbox_rows_t A, lidbox_rows_t Bd, float* 
     return rc;
 }
 
+// A zero fill in the shape of a job (splits = 0: the "sum" of no slices): `batch` runs of row_floats zeros, batch_stride floats
+// apart.  The engine carries it like a reduce: the rows a strided layer's accumulating dgrad groups do not all cover are
+// cleared in the leading workgroups of the group-0 launch instead of by a fill launch of their own.
+extern "C" int lidbox_zero_job(float* base, long batch_stride, long row_floats, int batch, lidbox_reduce_job_t* job) {
+    LBX_ARG(job && base && batch >= 1 && row_floats >= 4 && batch_stride >= row_floats, "base, job != NULL; batch >= 1; row_floats >= 4");
+    LBX_ARG(aligned16(base) && row_floats % 4 == 0 && batch_stride % 4 == 0 && row_floats <= 0x7fffffffL,
+            "16-byte aligned base, row_floats and batch_stride multiples of 4");
+    ReduceJob j;
+    j.Cm = base; j.n = (long)batch * row_floats; j.N = (int)row_floats; j.ldc = batch_stride; j.splits = 0; j.accumulate = 0;
+    long g = lbx_cdiv(j.n / 4, 256);
+    if (g > 2048) g = 2048;
+    j.nblocks = (unsigned)g;
+    memcpy(job, &j, sizeof j);
+    return LIDBOX_OK;
+}
+
 extern "C" int lidbox_reduce_jobs_run(const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream) {
     LBX_ARG(njobs >= 0 && (jobs || njobs == 0), "jobs != NULL");
     ReduceJob js[MAX_CARRY];

@@ -368,7 +368,8 @@ inline ReduceJobs pack_carry(const ReduceJob* jobs, int njobs, long cap) {
     for (int i = 0; i < njobs && m < MAX_CARRY; ++i) {
         if (jobs[i].nblocks == 0) continue;
         js.j[m] = jobs[i];
-        bytes[m] = (double)jobs[i].n * ((jobs[i].splits + 3) / 4);       // load batches: what a job's workgroups spend their time on
+        const int batches = (jobs[i].splits + 3) / 4;                     // load batches: what a job's workgroups spend their time on
+        bytes[m] = (double)jobs[i].n * (batches > 0 ? batches : 1);       // (a zero fill -- no slices -- counts its stores)
         all += bytes[m];
         ++m;
     }

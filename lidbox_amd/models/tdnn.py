@@ -991,8 +991,16 @@ class SequentialTDNN:
         # Rows no tap writes read as zero: they are zero since allocation and stay so when a single group writes (k <= s);
         # with several groups the later ones ACCUMULATE into rows group 0 does not cover, which are cleared first.
         if ngroups > 1 and To * c.s < Tp:
-            nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), 4 * Tp * cin,
-                                        4 * (Tp - To * c.s) * cin, B, st))
+            if pair_wgrad and ((Tp - To * c.s) * cin) % 4 == 0 and (Tp * cin) % 4 == 0 and dprev.data_ptr() % 16 == 0 and (To * c.s * cin) % 4 == 0:
+                # as a carried job: cleared in the leading workgroups of the group-0 launch below (group 0 does not touch these rows)
+                zj = nv.ReduceJob()
+                nv.check(lib.lidbox_zero_job(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), Tp * cin, (Tp - To * c.s) * cin, B,
+                                             ctypes.byref(zj)))
+                self.flush_reduce_jobs(ws)
+                ws.pending.append((zj, -1))
+            else:
+                nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(dprev.data_ptr() + 4 * To * c.s * cin), 4 * Tp * cin,
+                                            4 * (Tp - To * c.s) * cin, B, st))
             if d16 is not None:
                 nv.check(lib.lidbox_zero_2d(ctypes.c_void_p(d16.data_ptr() + 2 * To * c.s * cin), 2 * Tp * cin,
                                             2 * (Tp - To * c.s) * cin, B, st))

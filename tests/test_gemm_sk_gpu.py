@@ -607,3 +607,31 @@ def test_pair_launch_hands_its_reduce_on_and_carries_an_earlier_one(monkeypatch)
     monkeypatch.setenv("LIDBOX_GEMM_NO_CARRY", "1")
     for u, v in zip(run(True), b):
         assert torch.equal(u, v)
+
+
+def test_zero_fill_job_alone_and_carried():
+    """lidbox_zero_job: `batch` runs of zeros as a job without slices; run on its own and in the leading workgroups of a GEMM
+    launch it clears exactly its runs (the rows a strided Conv1D's accumulating dgrad groups do not all cover)"""
+    from lidbox_amd import _native as nv
+    st = nv.current_stream()
+    B, Tp, cin, rows = 37, 20, 64, 2
+    for carried in (False, True):
+        buf = torch.full((B, Tp, cin), 7.0, device="cuda")
+        job = nv.ReduceJob()
+        nv.check(nv.lib.lidbox_zero_job(nv.C.c_void_p(buf.data_ptr() + 4 * (Tp - rows) * cin), Tp * cin, rows * cin, B, nv.C.byref(job)))
+        if carried:
+            rng = np.random.default_rng(2)
+            M, K, N = 1024, 256, 256
+            a, w = _dev(rng.standard_normal((M, K))), _dev(rng.standard_normal((N, K)))
+            c = torch.zeros((M, N), device="cuda")
+            ws = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, K), 16) + 1024)
+            nv.check(nv.lib.lidbox_gemm_nt_carry(_rows(a, 0, K, 1, M), nv.ptr(w), K, _rows(c, 0, N, 1, M), K, N, nv.EPI_NONE, None, nv.ptr(ws),
+                                                 ws.numel(), nv.C.byref(job), 1, st))
+            assert nv.lib.lidbox_gemm_last_carried() == 1
+            _close(c.cpu().numpy(), a.cpu().numpy().astype(np.float64) @ w.cpu().numpy().astype(np.float64).T)
+        else:
+            nv.check(nv.lib.lidbox_reduce_jobs_run(nv.C.byref(job), 1, st))
+        out = buf.cpu().numpy()
+        assert (out[:, Tp - rows:, :] == 0).all() and (out[:, :Tp - rows, :] == 7.0).all()
+    rc = nv.lib.lidbox_zero_job(nv.C.c_void_p(buf.data_ptr() + 4), Tp * cin, rows * cin, B, nv.C.byref(job))
+    assert rc != 0 and b"aligned" in nv.lib.lidbox_hip_last_error()
