@@ -352,6 +352,7 @@ struct FusedArgs {
     int tiles_per_utt;          // ceil(T / 8)
     long ntiles;                // B * tiles_per_utt
     int iters;                  // tiles per wave
+    int tiles_per_wg;           // consecutive tiles one workgroup owns (its waves take them round-robin)
     unsigned nwg;
 #ifdef LBX_FEAT_TIMING
     long long* stamps;          // [nwg*4][12] s_memtime samples of each wave's first tile (debug builds only)
@@ -437,8 +438,15 @@ __host__ __device__ inline int mel_table_floats(bool segmel, int M, int nnz, int
     return segmel ? 3 * 64 + seg_len * 64 : 3 * M + nnz;
 }
 
-template <int KIND, bool VEC4, bool POW2, bool SEGMEL>
-__global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(const FusedArgs a) {
+// NW = waves per workgroup.  4: the round-1 shape, three workgroups per CU (every workgroup stages its own copy of the
+// tables: 3 x 9.7 KB).  14 ("wide", log-mel only): ONE persistent workgroup per CU whose 14 waves share one copy of the
+// tables -- 9.7 + 14 x 10.3 KB = 154 KB of the 160 -- i.e. 3.5 waves per SIMD instead of 3 at <= 128 registers, and every CU
+// gets the same number of consecutive tiles (+- 1).  Round 4's counters (profiles/r04_feature_census.txt) show the kernel
+// waiting, not issuing: a wave64 vector instruction costs ~2.3 cycles (tools/micro/valu_rate2), the 1 606 of a tile ~3.7 k
+// of the ~8 k cycles a SIMD spends per tile, and waves are parked 36 % of their cycles.
+template <int KIND, bool VEC4, bool POW2, bool SEGMEL, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_feat512_kernel(const FusedArgs a) {
+    constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS carve: tables, then one scratch block per wave
     float* s_win = reinterpret_cast<float*>(smem);                    // 2048 B
@@ -462,24 +470,26 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
     const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < 512; i += 256) s_win[i] = a.win512[i];
-    s_tw256[tid] = a.tw256[tid];
-    s_tw512[tid] = a.tw512[tid];
+    for (int i = tid; i < 512; i += NT) s_win[i] = a.win512[i];
+    if (tid < 256) {
+        s_tw256[tid] = a.tw256[tid];
+        s_tw512[tid] = a.tw512[tid];
+    }
     if (KIND != LIDBOX_FEAT_SPECTROGRAM) {
         if (SEGMEL) {
             if (tid < 192) s_segmeta[tid] = a.seg_meta[tid];
-            for (int i = tid; i < a.seg_len * 64; i += 256) s_segw[i] = a.seg_w[i];
+            for (int i = tid; i < a.seg_len * 64; i += NT) s_segw[i] = a.seg_w[i];
         } else {
-            for (int i = tid; i < a.M; i += 256) {
+            for (int i = tid; i < a.M; i += NT) {
                 s_mstart[i] = a.mel_start[i];
                 s_mcnt[i] = a.mel_cnt[i];
                 s_moff[i] = a.mel_off[i];
             }
-            for (int i = tid; i < a.nnz; i += 256) s_mw[i] = a.mel_w[i];
+            for (int i = tid; i < a.nnz; i += NT) s_mw[i] = a.mel_w[i];
         }
         if (KIND == LIDBOX_FEAT_MFCC)
             if (!dct_regs)
-                for (int i = tid; i < a.M * a.ncoef; i += 256) s_dct[i] = a.dct[i];
+                for (int i = tid; i < a.M * a.ncoef; i += NT) s_dct[i] = a.dct[i];
     }
     __syncthreads();
 
@@ -502,11 +512,12 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
     float* s_stage = reinterpret_cast<float*>(wbuf + WAVE_SCRATCH);      // [8][M] (+ [8][ncoef])
 
     const unsigned chunk = xcd_chunk_id(blockIdx.x, a.nwg);
-    const long tile0 = (long)chunk * 4 * a.iters;
+    const long tile0 = (long)chunk * a.tiles_per_wg;
 
     for (int it = 0; it < a.iters; ++it) {
-        const long tile = tile0 + (long)it * 4 + wave;
-        if (tile >= a.ntiles) break;                    // wave-uniform
+        const int local = it * NW + wave;
+        const long tile = tile0 + local;
+        if (local >= a.tiles_per_wg || tile >= a.ntiles) break;          // wave-uniform
         const int b = (int)(tile / a.tiles_per_utt);
         const int t0 = (int)(tile - (long)b * a.tiles_per_utt) * 8;
         const int t = t0 + f;
@@ -984,11 +995,25 @@ __global__ void generic_dct_kernel(const float* __restrict__ logmel, long nframe
     out[i] = acc;
 }
 
+constexpr int FEAT_WIDE_NW = 14;          // waves of the wide log-mel workgroup (see fused_feat512_kernel)
+
 template <int KIND>
-int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool segmel, size_t lds, hipStream_t st) {
+int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool segmel, size_t lds, hipStream_t st, int wide_nw = 4) {
     const bool pow2 = (p->power == 2.0f);
 #define LBX_FUSED(V, P2, SG)                                                                          \
     hipLaunchKernelGGL((fused_feat512_kernel<KIND, V, P2, SG>), dim3(a.nwg), dim3(256), lds, st, a)
+    if (wide_nw == FEAT_WIDE_NW && KIND == LIDBOX_FEAT_LOGMEL && segmel && vec4 && pow2) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            LBX_HIP(hipFuncSetAttribute((const void*)fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, FEAT_WIDE_NW>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, FEAT_WIDE_NW>), dim3(a.nwg), dim3(64 * FEAT_WIDE_NW), lds,
+                           st, a);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    }
     if (segmel && KIND != LIDBOX_FEAT_SPECTROGRAM) {
         if (vec4 && pow2) LBX_FUSED(true, true, (KIND != LIDBOX_FEAT_SPECTROGRAM));
         else if (vec4) LBX_FUSED(true, false, (KIND != LIDBOX_FEAT_SPECTROGRAM));
@@ -1066,7 +1091,10 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         const int stage_floats = (kind == LIDBOX_FEAT_SPECTROGRAM) ? 0
                                  : 8 * p->M + ((kind == LIDBOX_FEAT_MFCC && !segmel) ? 8 * p->ncoef : 0);
         const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
-        const size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
+        size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
+        // float4 loads need 16-byte aligned frames
+        const bool vec4 = (((uintptr_t)signals & 15) == 0) && (sig_stride % 4 == 0) &&
+                          (p->S % 4 == 0) && (p->L % 4 == 0);
         // grid: about four dispatch rounds of resident workgroups, equal tile counts per wave.  One tile per wave
         // while that holds (B <= ~490 at 2 s): the dispatcher then balances the tail; measured 35 vs 39 us at B = 256
         // against three tiles per wave on two thirds of the slots, and no difference at B = 2048.
@@ -1075,13 +1103,28 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.iters = (int)lbx_cdiv(wg_needed, 4 * max_wg);
         if (const char* e = getenv("LIDBOX_FEAT_ITERS")) { const int v = atoi(e); if (v >= 1) a.iters = v; }   // tuning aid
         a.nwg = (unsigned)lbx_cdiv(a.ntiles, 4L * a.iters);
-        // float4 loads need 16-byte aligned frames
-        const bool vec4 = (((uintptr_t)signals & 15) == 0) && (sig_stride % 4 == 0) &&
-                          (p->S % 4 == 0) && (p->L % 4 == 0);
+        a.tiles_per_wg = 4 * a.iters;
+        // wide workgroups (log-mel, the train step's kind): one persistent 14-wave workgroup per CU, every CU the same number
+        // of consecutive tiles (+- 1), its waves take them round-robin.  Measured against the 4-wave shape (round 4,
+        // profiles/r04_feature_wide_ab.txt).  LIDBOX_FEAT_WIDE=0 keeps the 4-wave shape (A/B aid).
+        int wide_nw = 4;
+        {
+            static const int wide_env = getenv("LIDBOX_FEAT_WIDE") ? atoi(getenv("LIDBOX_FEAT_WIDE")) : 1;
+            const size_t lds_wide = (size_t)table_bytes + FEAT_WIDE_NW * (size_t)wave_bytes;
+            // interleaved on one box (B x 2 s): 256 +10 %, 512 +12 %, 1024 equal, 2048 -3 % -> up to 100 tiles per CU
+            if (wide_env != 0 && kind == LIDBOX_FEAT_LOGMEL && segmel && vec4 && p->power == 2.0f && lds_wide <= 160 * 1024 &&
+                a.ntiles >= 4L * 256 && (a.ntiles <= 100L * 256 || wide_env > 1)) {
+                wide_nw = FEAT_WIDE_NW;
+                lds = lds_wide;
+                a.tiles_per_wg = (int)lbx_cdiv(a.ntiles, 256L);
+                a.nwg = (unsigned)lbx_cdiv(a.ntiles, (long)a.tiles_per_wg);
+                a.iters = (int)lbx_cdiv((long)a.tiles_per_wg, (long)FEAT_WIDE_NW);
+            }
+        }
         switch (kind) {
             case LIDBOX_FEAT_SPECTROGRAM: return launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, false, lds, st);
             case LIDBOX_FEAT_MEL: return launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, segmel, lds, st);
-            case LIDBOX_FEAT_LOGMEL: return launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st);
+            case LIDBOX_FEAT_LOGMEL: return launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st, wide_nw);
             default: return launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, segmel, lds, st);
         }
     }

@@ -16,7 +16,7 @@ if "--from" in rest:
     rest = rest[:i] + rest[i + 2:]
 flags = rest
 b.build(verbose=False)
-out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab")
+out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("LIDBOX_AB_DIR", "ab"))
 os.makedirs(out_dir, exist_ok=True)
 obj = os.path.join(out_dir, name + "_" + src[:-4] + ".o")
 subprocess.run([b.HIPCC] + b.FLAGS + flags + ["-x", "hip", "-c", path, "-o", obj], check=True)

@@ -7,7 +7,7 @@ from lidbox_amd.features import audio
 from lidbox_amd import _native as nv
 
 def main():
-    for B in (256, 1024, 2048):
+    for B in (256, 512, 1024, 2048):
         x = torch.randn(B, 32000, device="cuda") * 0.1
         plan = audio.get_plan(16000, 400, 160)
         for kind, name, ch in ((nv.FEAT_LOGMEL, "logmel", 40), (nv.FEAT_MFCC, "mfcc", 12), (nv.FEAT_SPECTROGRAM, "spec", 257)):
