@@ -46,6 +46,7 @@
 #include "gemm_sk.h"
 #include <string.h>
 #include "gemm_dma.h"
+#include "gemm_dma8.h"
 #include "gemm_tuned.h"
 
 namespace {
@@ -873,6 +874,12 @@ RowsChoice choose_rows(int kind, long M, int N, int K, size_t ws_bytes) {
 // the decomposition a launch uses: the planner's, or the tuning overrides LIDBOX_GEMM_PLAN / LIDBOX_GEMM_TILE
 RowsChoice choose_rows_env(int kind, long M, int N, int K, size_t wsb) {
     RowsChoice ch = choose_rows(kind, M, N, K, wsb);
+    if (kind == 1 && M >= 4096) {
+        if (const char* f = getenv("LIDBOX_GEMM_NT8")) {          // A/B aid: conv-size dgrads on the eight-wave 128 x bn tiles (gemm_dma8.h)
+            const int bn = atoi(f);
+            if (bn == 64 || bn == 128) return RowsChoice{128, bn, 1, K, false, 8};
+        }
+    }
     if (const char* f = getenv("LIDBOX_GEMM_PLAN")) {             // tuning aid (tools/gemm_sweep.py): "bm,bn,splits"
         int bm = 0, bn = 0, sp = 0, wv = 4;
         if (sscanf(f, "%d,%d,%d,%d", &bm, &bn, &sp, &wv) >= 3 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1 &&
@@ -995,6 +1002,8 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
     if (dma_ok && al && dma_mode() != 0) {
         g_last_family = 1;
         DmaStream sp;
+        // eight-wave tiles (gemm_dma8.h): nt launches planned as 128 x 64 / 128 x 128 with waves = 8
+        const bool dma8 = B_KINNER && ch.waves == 8 && ch.bm == 128;
         ReduceJobs rj;                              // total = 0: nothing carried
         if (carry && !carry->carried && carry->njobs > 0) {
             rj = pack_carry(carry->jobs, carry->njobs, carry_cap());
@@ -1013,6 +1022,15 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
             grid.x = sp.npad + ntiles_k;
         }
         grid.x += rj.total;
+        if (dma8) {
+            g_last_family = 3;
+            if (ch.bn == 128)
+                hipLaunchKernelGGL((gemm_rows_dma8_kernel<128>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n,
+                                   ntiles_k, ch.k_per_split, sp, rj);
+            else
+                hipLaunchKernelGGL((gemm_rows_dma8_kernel<64>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n,
+                                   ntiles_k, ch.k_per_split, sp, rj);
+        } else
         if (ch.bm == 128 && ch.bn == 128) LBX_ROWS_DMA(128, 128);
         else if (ch.bm == 128) LBX_ROWS_DMA(128, 64);
         else if (ch.bn == 128) LBX_ROWS_DMA(64, 128);
