@@ -199,8 +199,13 @@ class KernelTimer:
                     out3 = (ctypes.c_int * 3)()
                     self.nv.check(self.nv.lib.lidbox_gemm_last_launches(out3))
                     nk = max(1, out3[0])
-                    if self.nv.lib.lidbox_gemm_last_family() == 1:     # the LDS-DMA instantiation of the same tile shape
+                    fam = self.nv.lib.lidbox_gemm_last_family()
+                    if fam == 1:     # the LDS-DMA instantiation of the same tile shape
                         key = key.replace("gemm_rows_kernel<", "gemm_rows_dma_kernel<").replace("gemm_tn_kernel<", "gemm_tn_dma_kernel<")
+                    elif fam == 3:   # the eight-wave LDS-DMA tile (gemm_dma8.h): rocprofv3 lists it by its column count
+                        import re as _re
+                        mm = _re.match(r"gemm_rows8?_kernel<(\d+), (\d+), NT>", key)
+                        key = "gemm_rows_dma8_kernel<%s>" % (mm.group(2) if mm else "64")
                 elif self.ENTRY[_n] in (13, 15):
                     out3 = (ctypes.c_int * 3)()
                     self.nv.check(self.nv.lib.lidbox_gemm_bf16s_last_variant(out3))

@@ -182,7 +182,8 @@ int lidbox_gemm_plan_is_stream_k(int kind, long M, int N, int K, size_t workspac
  * planned on its own), reduce kernels}. */
 int lidbox_gemm_last_launches(int* out3);
 /* Kernel family of that same call: 0 = register-staged kernels (gemm_rows_kernel / gemm_tn_kernel), 1 = the same
- * decomposition on the LDS-DMA operand path (gemm_rows_dma_kernel: 16-byte aligned operands), 2 = stream-K. */
+ * decomposition on the LDS-DMA operand path (gemm_rows_dma_kernel: 16-byte aligned operands), 2 = stream-K, 3 = the LDS-DMA
+ * tile worked by eight waves (gemm_rows_dma8_kernel: nt launches planned as 128-row tiles with 8 waves). */
 int lidbox_gemm_last_family(void);
 /* Pieces per tile (2 .. 8) when lidbox_gemm_nn / _nt (kind 0 / 1) would stream the last partial round of tiles of this
  * shape along K inside the one launch (LDS-DMA family, 16-byte aligned operands, a workspace of workspace_bytes: 16 KiB of

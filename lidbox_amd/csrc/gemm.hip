@@ -874,8 +874,8 @@ RowsChoice choose_rows(int kind, long M, int N, int K, size_t ws_bytes) {
 // the decomposition a launch uses: the planner's, or the tuning overrides LIDBOX_GEMM_PLAN / LIDBOX_GEMM_TILE
 RowsChoice choose_rows_env(int kind, long M, int N, int K, size_t wsb) {
     RowsChoice ch = choose_rows(kind, M, N, K, wsb);
-    if (kind == 1 && M >= 4096) {
-        if (const char* f = getenv("LIDBOX_GEMM_NT8")) {          // A/B aid: conv-size dgrads on the eight-wave 128 x bn tiles (gemm_dma8.h)
+    if (M >= 4096) {                  // A/B aids: conv-size dgrads (LIDBOX_GEMM_NT8) / forward GEMMs (LIDBOX_GEMM_NN8) on the eight-wave 128 x bn tiles
+        if (const char* f = getenv(kind == 1 ? "LIDBOX_GEMM_NT8" : "LIDBOX_GEMM_NN8")) {
             const int bn = atoi(f);
             if (bn == 64 || bn == 128) return RowsChoice{128, bn, 1, K, false, 8};
         }
@@ -1003,7 +1003,7 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
         g_last_family = 1;
         DmaStream sp;
         // eight-wave tiles (gemm_dma8.h): nt launches planned as 128 x 64 / 128 x 128 with waves = 8
-        const bool dma8 = B_KINNER && ch.waves == 8 && ch.bm == 128;
+        const bool dma8 = ch.waves == 8 && ch.bm == 128;
         ReduceJobs rj;                              // total = 0: nothing carried
         if (carry && !carry->carried && carry->njobs > 0) {
             rj = pack_carry(carry->jobs, carry->njobs, carry_cap());
@@ -1025,10 +1025,10 @@ int launch_rows_range(const RowsChoice& ch, bool al, RowsD Ad, const float* Bm, 
         if (dma8) {
             g_last_family = 3;
             if (ch.bn == 128)
-                hipLaunchKernelGGL((gemm_rows_dma8_kernel<128>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n,
+                hipLaunchKernelGGL((gemm_rows_dma8_kernel<128, B_KINNER>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n,
                                    ntiles_k, ch.k_per_split, sp, rj);
             else
-                hipLaunchKernelGGL((gemm_rows_dma8_kernel<64>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n,
+                hipLaunchKernelGGL((gemm_rows_dma8_kernel<64, B_KINNER>), grid, dim3(512), 0, st, Ad, Bm, ldb, Co, P, m_beg, m_end, K, N, epi, aux, tiles_n,
                                    ntiles_k, ch.k_per_split, sp, rj);
         } else
         if (ch.bm == 128 && ch.bn == 128) LBX_ROWS_DMA(128, 128);

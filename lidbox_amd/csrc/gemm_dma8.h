@@ -6,7 +6,7 @@
 // tile moves 12 B/clk/CU, and with one accumulator block per wave it fits 64 registers: four workgroups of eight waves = 32
 // waves per CU.  Same operand path (saddr LDS-DMA ring of three stages, K-inner operands XOR-swizzled on the source side and
 // read with ds_read_b128), same epilogues (store_rows_tile), same streamed remainder and carried reduces as
-// gemm_rows_dma_kernel; nt only (both operands K-inner: the dgrads).  Reference: the backward of Conv1D / Dense,
+// gemm_rows_dma_kernel; nt (dgrads) and nn (forward: B K-outer, read with ds_read_b32).  Reference: the backward of Conv1D / Dense,
 // lidbox/models/xvector.py:38-43,53-64.
 #pragma once
 
@@ -48,6 +48,45 @@ struct DmaInner8 {
     }
 };
 
+// K-outer operand of a plain matrix X[k][ld] worked by 8 waves (B of nn): 16 k x COLS columns per step, LDS image [k][COLS],
+// a piece = 1 KB = RPP k rows; wave w issues piece w (COLS = 64: waves 0 .. 3 only)
+template <int COLS>
+struct DmaOuter8 {
+    static constexpr int NPIECE = COLS / 16;
+    static constexpr int LPR = COLS / 4;          // lanes per k row
+    static constexpr int RPP = 64 / LPR;          // k rows per piece: 4 (64 columns) or 2 (128)
+    const float* sb;
+    unsigned vo;
+    long step;
+    int rd;
+    int krow;                                     // this lane's k row inside a step
+    bool mine;
+    __device__ __forceinline__ void init(const float* base, long ld, int col0, int ncols, int k0, int lane, int wv, int wsub) {
+        sb = sk_uniform(base + (long)k0 * ld + col0);
+        int c = (lane % LPR) * 4;
+        if (col0 + c >= ncols) c = 0;
+        const int p = wv % NPIECE;
+        krow = RPP * p + lane / LPR;
+        vo = (unsigned)(((long)krow * ld + c) * 4);
+        step = (long)SK_BK * ld;
+        rd = (4 * (lane >> 5)) * COLS + wsub * (COLS / 2) + (lane & 31);
+        mine = wv < NPIECE;
+    }
+    __device__ __forceinline__ void issue(unsigned dst) const { sk_dma_s(sb, vo, dst); }
+    __device__ __forceinline__ void issue_tail(unsigned dst, int kvalid, int lane) const {
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo);
+        sk_dma_f(krow < kvalid ? p : g_sk_zero, dst);
+    }
+    __device__ __forceinline__ void advance() { sb += step; }
+    template <int NB>
+    __device__ __forceinline__ void read(const float* st, int lane, int s2, float (&v)[NB][4]) const {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b][j] = st[rd + (8 * s2 + j) * COLS + b * 32];
+    }
+};
+
 // slabs of the streamed remainder, accumulator order of EIGHT waves: [(wave * NJ + bj) * 4 + r4][lane][4]
 template <int NJ>
 __device__ __forceinline__ void dma8_slab_store(float* slab, const f32x16 (&acc)[1][NJ], int wv, int lane) {
@@ -76,8 +115,9 @@ __device__ __forceinline__ void dma8_slab_add(const float* slab, f32x16 (&acc)[1
     }
 }
 
-// C[M,N] = epi(A[M,K] . B[N,K]^T); BM = 128, BN = 64 NJ; grid.x = [carried reduce blocks] + [streamed pieces] + whole tiles
-template <int BN>
+// C[M,N] = epi(A[M,K] . B), B_KINNER: B[N][K] (nt) else B[K][N] (nn); BM = 128, BN = 64 NJ;
+// grid.x = [carried reduce blocks] + [streamed pieces] + whole tiles
+template <int BN, bool B_KINNER>
 __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(RowsD A, const float* __restrict__ Bm, long ldb, RowsOutD Cd,
                                                                               float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
                                                                               const float* __restrict__ aux, int tiles_n, unsigned ntiles,
@@ -123,13 +163,16 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
         if (r >= M) r = m0;
         oa.init(A.base, row_offset(A, (unsigned)r), kbeg, lane, wv, wm, 32);
     }
-    DmaInner8<BN> ob;
-    {
+    DmaInner8<BN> obi;
+    DmaOuter8<BN> obo;
+    if (B_KINNER) {
         long r = n0 + 16 * (wv % (BN / 16)) + (lane >> 2);
         if (r >= N) r = n0;
-        ob.init(Bm, r * ldb, kbeg, lane, wv, wn, 32 * NJ);
+        obi.init(Bm, r * ldb, kbeg, lane, wv, wn, 32 * NJ);
+    } else {
+        obo.init(Bm, ldb, n0, N, kbeg, lane, wv, wn);
     }
-    const bool has_b = ob.mine;                              // wave-uniform: this wave also moves a piece of B every step
+    const bool has_b = B_KINNER ? obi.mine : obo.mine;       // wave-uniform: this wave also moves a piece of B every step
     f32x16 acc[1][NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -143,8 +186,14 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
     };
     auto issue_b = [&](int step, int stage) {
         const unsigned d = lds0 + (unsigned)((stage * ST + A_ST + wv * 256) * 4);
-        if (step == n - 1 && ktail < SK_BK) ob.issue_tail(d, ktail, lane);
-        else ob.issue(d);
+        const bool tail = step == n - 1 && ktail < SK_BK;
+        if (B_KINNER) { if (tail) obi.issue_tail(d, ktail, lane); else obi.issue(d); }
+        else { if (tail) obo.issue_tail(d, ktail, lane); else obo.issue(d); }
+    };
+    auto adv_b = [&]() { if (B_KINNER) obi.advance(); else obo.advance(); };
+    auto rb = [&](const float* stg, int s2, float (&v)[NJ][4]) {
+        if (B_KINNER) obi.template read<NJ>(stg, lane, s2, v);
+        else obo.template read<NJ>(stg, lane, s2, v);
     };
 #pragma unroll
     for (int s = 0; s < DMA_STAGES - 1; ++s)
@@ -152,7 +201,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
             issue_a(s, s);
             if (has_b) issue_b(s, s);
             oa.advance();
-            ob.advance();
+            adv_b();
         }
     // stage 0 must have landed; stage 1's pieces (one or two per wave) may stay in flight
     if (n >= DMA_STAGES - 1) {
@@ -165,7 +214,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
     float a0[1][4], b0[NJ][4], a1[1][4], b1[NJ][4];
     if (n > 0) {
         oa.template read<1>(smem, lane, 0, a0);
-        ob.template read<NJ>(smem + A_ST, lane, 0, b0);
+        rb(smem + A_ST, 0, b0);
     }
     int cur = 0;
     for (int t = 0; t < n; ++t) {
@@ -180,7 +229,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
         dma_mma<1, NJ, 0, 1>(a0, b0, acc);
         __builtin_amdgcn_sched_barrier(0);
         oa.template read<1>(st, lane, 1, a1);
-        ob.template read<NJ>(st + A_ST, lane, 1, b1);
+        rb(st + A_ST, 1, b1);
         __builtin_amdgcn_sched_barrier(0);
         dma_mma<1, NJ, 1, 2>(a0, b0, acc);
         if (more) issue_a(t + DMA_STAGES - 1, tgt);
@@ -191,7 +240,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
         dma_mma<1, NJ, 3, 4>(a0, b0, acc);
         if (more) {
             oa.advance();
-            ob.advance();
+            adv_b();
         }
         __builtin_amdgcn_sched_barrier(0);
         dma_mma<1, NJ, 0, 1>(a1, b1, acc);
@@ -199,7 +248,7 @@ __global__ __launch_bounds__(512, BN == 64 ? 8 : 4) void gemm_rows_dma8_kernel(R
         if (t + 1 < n) {
             const float* sn = smem + nxt * ST;
             oa.template read<1>(sn, lane, 0, a0);
-            ob.template read<NJ>(sn + A_ST, lane, 0, b0);
+            rb(sn + A_ST, 0, b0);
         }
         __builtin_amdgcn_sched_barrier(0);
         dma_mma<1, NJ, 1, 4>(a1, b1, acc);

@@ -635,3 +635,66 @@ def test_zero_fill_job_alone_and_carried():
         assert (out[:, Tp - rows:, :] == 0).all() and (out[:, :Tp - rows, :] == 7.0).all()
     rc = nv.lib.lidbox_zero_job(nv.C.c_void_p(buf.data_ptr() + 4), Tp * cin, rows * cin, B, nv.C.byref(job))
     assert rc != 0 and b"aligned" in nv.lib.lidbox_hip_last_error()
+
+
+@pytest.mark.parametrize("bn", ["64", "128"])
+@pytest.mark.parametrize("M,K,N,epi", [(8448, 512, 512, "mask"), (8448, 1500, 512, "none"), (4100, 516, 200, "accmask"), (33 * 130, 512, 1536, "mask")])
+def test_eight_wave_dgrad_tiles_match_float64(M, K, N, epi, bn, monkeypatch):
+    """gemm_rows_dma8_kernel (128-row tiles worked by eight waves: gemm_dma8.h) through lidbox_gemm_nt / lidbox_gemm_nt_carry:
+    ragged row counts, K tails (1500, 516), N that is no multiple of the tile, mask / accumulate epilogues, the streamed
+    remainder and a carried reduce; equal to float64 at round-off, run-to-run bit-identical, and the carried job's result equal
+    to the plain reduce.  Reference: the dgrad of Conv1D, lidbox/models/xvector.py:38-43,53-57."""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM_NT8", bn)
+    rng = np.random.default_rng(M + K)
+    A, W = rng.standard_normal((M, K)), rng.standard_normal((N, K)) * 0.1
+    mask, old = rng.standard_normal((M, N)), rng.standard_normal((M, N)).astype(np.float32)
+    a, w, mk = _dev(A), _dev(W), _dev(mask)
+    st = nv.current_stream()
+    ws = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, K), 16) + 1024)
+    e = {"mask": nv.EPI_RELU_MASK, "none": nv.EPI_NONE, "accmask": nv.EPI_ACCUM_RELU_MASK}[epi]
+    ref = A @ W.T
+    if epi != "none":
+        ref = ref * (mask > 0)
+    if epi == "accmask":
+        ref = ref + old.astype(np.float64)
+    # a pending wgrad-style job to carry: 3 slices of a [64, 128] matrix
+    P = _dev(rng.standard_normal((3, 64 * 128)))
+    outs = []
+    for rep in range(2):
+        c = _dev(old).clone() if epi == "accmask" else torch.full((M, N), 9.0, device="cuda")
+        dw = torch.full((64, 128), 5.0, device="cuda")
+        job = nv.ReduceJob(P.data_ptr(), None, dw.data_ptr(), None, 64 * 128, 128, 3, 128, 0, 8)
+        nv.check(nv.lib.lidbox_gemm_nt_carry(_rows(a, 0, K, 1, M), nv.ptr(w), K, _rows(c, 0, N, 1, M), K, N, e, nv.ptr(mk) if epi != "none" else None,
+                                             nv.ptr(ws), ws.numel(), nv.C.byref(job), 1, st))
+        assert nv.lib.lidbox_gemm_last_family() == 3 and nv.lib.lidbox_gemm_last_carried() == 1
+        torch.cuda.synchronize()
+        outs.append((c, dw))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    _close(outs[0][0].cpu().numpy(), ref)
+    Pn = P.cpu().numpy().astype(np.float32)
+    assert np.array_equal(outs[0][1].cpu().numpy().ravel(), (Pn[0] + Pn[1]) + Pn[2])
+
+
+@pytest.mark.parametrize("bn", ["64", "128"])
+@pytest.mark.parametrize("M,K,N", [(50688 // 8, 200, 512), (8448, 512, 1500), (4100, 516, 200)])
+def test_eight_wave_forward_tiles_match_float64(M, K, N, bn, monkeypatch):
+    """the nn form of gemm_rows_dma8_kernel (B [K][N] K-outer, bias + ReLU epilogue): K tails (200, 516), N = 1500 / 200 (partial
+    column tiles), ragged rows; float64 at round-off and bit-identical from run to run.  Built and measured in round 4, not
+    adopted for the forward launches (profiles/r04_nt8_ab.txt); reachable through a tuned-table entry with waves = 8."""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM_NN8", bn)
+    rng = np.random.default_rng(M + N)
+    A, W, b = rng.standard_normal((M, K)), rng.standard_normal((K, N)) * 0.1, rng.standard_normal(N)
+    a, w, bias = _dev(A), _dev(W), _dev(b)
+    st = nv.current_stream()
+    ws = _garbage_ws(max(nv.lib.lidbox_gemm_rows_workspace(M, N, K), 16) + 1024)
+    outs = []
+    for rep in range(2):
+        c = torch.full((M, N), 9.0, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_nn(_rows(a, 0, K, 1, M), nv.ptr(w), N, _rows(c, 0, N, 1, M), K, N, nv.EPI_BIAS_RELU, nv.ptr(bias), nv.ptr(ws),
+                                       ws.numel(), st))
+        assert nv.lib.lidbox_gemm_last_family() == 3
+        outs.append(c)
+    assert torch.equal(outs[0], outs[1])
+    _close(outs[0].cpu().numpy(), np.maximum(A @ W + b, 0.0))
