@@ -1,6 +1,6 @@
 # usage (on the MI355X box): bash tools/profile_round.sh r02   -> gpurun_out/<tag>_* (copy what is to be judged into profiles/)
 set -x
-T=${1:-r03}
+T=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 python bench.py --compute-dtype bfloat16 > gpurun_out/${T}_bench_bf16.json 2>> gpurun_out/${T}_bench.err
@@ -17,13 +17,19 @@ python tools/traffic_from_pmc.py gpurun_out/p_fetch16 gpurun_out/p_write16 gpuru
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/p_mfma -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timing > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/p_mfma > gpurun_out/${T}_pmc_mfma_raw.txt
 python tools/mfma_util_from_pmc.py gpurun_out/${T}_pmc_mfma_raw.txt gpurun_out/${T}_mfma_util.json | head -8
+for C in 3 4; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/p_fetchc$C -- python bench.py --config $C --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/p_writec$C -- python bench.py --config $C --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+  python tools/traffic_from_pmc.py gpurun_out/p_fetchc$C gpurun_out/p_writec$C gpurun_out/${T}_traffic_config$C.json | head -4
+  rm -rf gpurun_out/p_fetchc$C gpurun_out/p_writec$C
+done
 python bench.py --config 3 > gpurun_out/${T}_bench_config3.json 2>> gpurun_out/${T}_bench.err
 python bench.py --config 4 > gpurun_out/${T}_bench_config4.json 2>> gpurun_out/${T}_bench.err
 python tools/bench_configs.py > gpurun_out/${T}_configs.jsonl 2>/dev/null
 python tools/step_calls.py float32 > gpurun_out/${T}_step_calls_fp32.txt 2>/dev/null
 python tools/step_calls.py bfloat16 > gpurun_out/${T}_step_calls_bf16.txt 2>/dev/null
 python tools/bench_bf16s.py 256 > gpurun_out/${T}_bf16_storage_gemm.txt 2>/dev/null
-tools/micro/valu_rate short > gpurun_out/${T}_valu_rate.txt 2>&1
+tools/micro/valu_rate2 > gpurun_out/${T}_valu_rate2.txt 2>&1
 tools/micro/l2_rate > gpurun_out/${T}_l2_rate.txt 2>&1
 rm -rf gpurun_out/p_stats gpurun_out/p_stats16 gpurun_out/p_fetch gpurun_out/p_write gpurun_out/p_fetch16 gpurun_out/p_write16 gpurun_out/p_mfma
 cut -c1-600 gpurun_out/${T}_bench.json; cut -c1-300 gpurun_out/${T}_bench_bf16.json
