@@ -498,6 +498,13 @@ int lidbox_cavg_result(const float* tp, const float* fn, const float* fp_pairs, 
 int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr,
                      float beta1, float beta2, float eps, float grad_scale, void* state,
                      lidbox_stream_t stream);
+/* The same step in two halves: lidbox_adam_prepare_job describes its scalar half (advance the counter, publish lr_t) as a
+ * job for lidbox_reduce_jobs_run -- the launch that finishes the step's last wgrad then prepares the optimizer too (GEMM
+ * launches do not carry this kind: *_carry calls reject it) -- and lidbox_adam_apply is the elementwise update with the lr_t
+ * found in `state`.  lidbox_adam_step == the job on its own + lidbox_adam_apply, bit for bit. */
+int lidbox_adam_prepare_job(void* state, float lr, float beta1, float beta2, lidbox_reduce_job_t* job);
+int lidbox_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                      float grad_scale, const void* state, lidbox_stream_t stream);
 
 /* ------------------------------------------------------------------ BatchNormalization (f1: xvector_2d.py:36,43)
  * tf.keras.layers.BatchNormalization(axis=-1) over x viewed as [R rows, C channels] (dense).  Training: batch mean and

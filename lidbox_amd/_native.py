@@ -137,6 +137,8 @@ _SIGS = {
     "lidbox_cavg_update": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "lidbox_cavg_result": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
+    "lidbox_adam_prepare_job": (_i, [_vp, _f, _f, _f, C.POINTER(ReduceJob)]),
+    "lidbox_adam_apply": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
     "lidbox_dropout_rows": (_i, [Rows, _i, _f, C.c_ulonglong, _vp, _vp]),
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),

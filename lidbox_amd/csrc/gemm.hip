@@ -1486,6 +1486,7 @@ extern "C" int lidbox_gemm_nt_carry(lidbox_rows_t A, const float* Bm, long ldb, 
     ReduceJob js[MAX_CARRY];
     const int m = jobs_in(jobs, njobs, js);
     LBX_ARG(m >= 0, "at most 2 non-empty jobs per call");
+    for (int i = 0; i < m; ++i) LBX_ARG(js[i].splits >= 0, "an optimizer-prepare job runs through lidbox_reduce_jobs_run only");
     for (int i = 0; i < m; ++i) LBX_ARG((const void*)js[i].P != workspace, "a job's slices live in this call's workspace");
     Carry carry;
     carry.jobs = js;
@@ -1545,6 +1546,7 @@ extern "C" int lidbox_gemm_nt_tn_carry(lidbox_rows_t dY, const float* W, long ld
     LBX_ARG(npend >= 0 && npend < MAX_CARRY, "at most 1 non-empty pending job per call");
     for (int i = 0; i < npend; ++i)
         LBX_ARG((const void*)pend[i].P != ws_nt && (const void*)pend[i].P != ws_tn, "a pending job's slices live in this call's workspaces");
+    for (int i = 0; i < npend; ++i) LBX_ARG(pend[i].splits >= 0, "an optimizer-prepare job runs through lidbox_reduce_jobs_run only");
     const long M = (long)dY.batch * dY.rows_per_batch;
     bool pair = dma_mode() != 0 && getenv("LIDBOX_GEMM_NO_PAIR") == nullptr && M >= 1 && N >= 1 && K1 >= 1 && Co >= 1 && W && dW && ws_tn &&
                 ws_nt != ws_tn;

@@ -1173,6 +1173,7 @@ extern "C" int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, lo
         LBX_ARG(m < MAX_CARRY, "at most 2 non-empty jobs per call");
         memcpy(&js[m], jobs + i, sizeof(ReduceJob));
         LBX_ARG((const void*)js[m].P != workspace, "a job's slices live in this call's workspace");
+        LBX_ARG(js[m].splits >= 0, "an optimizer-prepare job runs through lidbox_reduce_jobs_run only");
         ++m;
     }
     const bool carry = m > 0 && getenv("LIDBOX_GEMM_NO_CARRY") == nullptr;

@@ -337,7 +337,41 @@ __device__ __forceinline__ void reduce_jobs_run(const ReduceJobs& js, unsigned b
     }
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce4_kernel(ReduceJobs js) { reduce_jobs_run(js, blockIdx.x); }
+// A job with splits == -1 is not a sum but the optimizer's per-step scalar work (lidbox_adam_prepare_job, nnops.hip: advance the
+// device-side step counter, publish the bias-corrected learning rate): one thread of the stand-alone launch does it, so the
+// launch that finishes the step's last wgrad also prepares Adam (round 3 had a one-thread launch for that).  Cm = the 16-byte
+// state {int64 step, float lr_t, float lr_now}; n / ldc carry the bits of lr, beta_1 / beta_2.  GEMM launches never carry it
+// (float64 pow in their leading blocks would set their register count).
+struct AdamStateD {
+    long long step;
+    float lr_t;
+    float lr_now;
+};
+__device__ __forceinline__ void adam_prepare_run(const ReduceJob& j) {
+    AdamStateD* st = reinterpret_cast<AdamStateD*>(j.Cm);
+    const float lr = __uint_as_float((unsigned)(j.n & 0xffffffffL)), b1 = __uint_as_float((unsigned)((unsigned long)j.n >> 32));
+    const float b2 = __uint_as_float((unsigned)(j.ldc & 0xffffffffL));
+    const long long t = ++st->step;
+    const double c = sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+    const float base = __float_as_uint(st->lr_now) != 0u ? fabsf(st->lr_now) : lr;
+    st->lr_t = (float)((double)base * c);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(ReduceJobs js) {
+    unsigned blk = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < MAX_CARRY; ++i) {
+        if (blk < js.j[i].nblocks) {
+            if (js.j[i].splits == -1) {
+                if (blk == 0 && threadIdx.x == 0) adam_prepare_run(js.j[i]);
+            } else {
+                reduce_job_run(js.j[i], blk);
+            }
+            return;
+        }
+        blk -= js.j[i].nblocks;
+    }
+}
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -13,6 +13,7 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -1009,6 +1010,35 @@ extern "C" int lidbox_adam_step(float* param, const float* grad, float* m, float
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (AdamState*)state, lr,
                        beta1, beta2);
     LBX_LAUNCH_OK();
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       m, v, n, (const AdamState*)state, beta1, beta2, eps, grad_scale);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+// The optimizer step in two halves, so that its scalar half can ride in the launch that finishes the step's last wgrad
+// (lidbox_reduce_jobs_run): lidbox_adam_prepare_job describes "advance the step counter, publish lr_t" as a job (what
+// adam_prepare_kernel does), lidbox_adam_apply is the elementwise update with the lr_t it finds in the state.
+// lidbox_adam_step == the job run on its own + lidbox_adam_apply.
+extern "C" int lidbox_adam_prepare_job(void* state, float lr, float beta1, float beta2, lidbox_reduce_job_t* job) {
+    LBX_ARG(state && job && (((uintptr_t)state) & 15) == 0, "state, job != NULL; state 16-byte aligned");
+    memset(job, 0, sizeof *job);
+    unsigned ulr, ub1, ub2;
+    memcpy(&ulr, &lr, 4); memcpy(&ub1, &beta1, 4); memcpy(&ub2, &beta2, 4);
+    job->C = (float*)state;
+    job->n = (long)(((unsigned long)ub1 << 32) | ulr);
+    job->ldc = (long)ub2;
+    job->splits = -1;
+    job->nblocks = 1;
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                                 float grad_scale, const void* state, lidbox_stream_t stream) {
+    LBX_ARG(param && grad && m && v && state && n >= 0, "pointers != NULL");
+    LBX_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v | (uintptr_t)state) & 15) == 0,
+            "param/grad/m/v/state must be 16-byte aligned");
     if (n == 0) return LIDBOX_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        m, v, n, (const AdamState*)state, beta1, beta2, eps, grad_scale);

@@ -13,6 +13,7 @@ then Adam scales by 1/world.  The gradient buffer is reduced in contiguous bucke
 issued as an asynchronous collective as soon as its last wgrad has been enqueued and overlaps
 the remaining backward GEMMs.
 """
+import ctypes
 import gc
 import os
 
@@ -376,6 +377,14 @@ class Trainer:
             self.model.backward_head_ws(ws)
         for i in range(hi_edges[k] - 1, lo_edges[k] - 1, -1):
             self.model.backward_conv_ws(ws, i)
+        self._prepared = False
+        if k == self.num_stages - 1 and not self._warming and not os.environ.get("LIDBOX_ADAM_PREPARE_LAUNCH"):
+            # the optimizer's scalar half (step counter, bias-corrected rate) rides in the launch that finishes the last wgrad
+            job = nv.ReduceJob()
+            o = self.opt
+            nv.check(nv.lib.lidbox_adam_prepare_job(nv.ptr(self.adam_state), o["lr"], o["beta_1"], o["beta_2"], ctypes.byref(job)))
+            ws.pending.append((job, -1))
+            self._prepared = True
         self.model.flush_reduce_jobs(ws)       # carried wgrad reduces still open: the stage's gradient bucket must be final
         self.model.join_wgrad()
 
@@ -413,6 +422,10 @@ class Trainer:
     def _adam(self):
         o = self.opt
         m = self.model
+        if getattr(self, "_prepared", False):      # the last backward stage carried the prepare half (lidbox_adam_prepare_job)
+            nv.check(nv.lib.lidbox_adam_apply(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v), m.num_flat,
+                                              o["beta_1"], o["beta_2"], o["epsilon"], 1.0, nv.ptr(self.adam_state), nv.current_stream()))
+            return
         nv.check(nv.lib.lidbox_adam_step(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v),
                                          m.num_flat, o["lr"], o["beta_1"], o["beta_2"], o["epsilon"],
                                          1.0, nv.ptr(self.adam_state), nv.current_stream()))

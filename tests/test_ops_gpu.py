@@ -543,3 +543,48 @@ def test_softmax_head_limits():
     with pytest.raises(ValueError):                              # workspace too small
         nv.check(nv.lib.lidbox_softmax_head_fwd_bwd(nv.ptr(x), nv.ptr(x), nv.ptr(x), nv.ptr(x), 4, 8, 2, 1.0, 0, nv.ptr(x), nv.ptr(x),
                                                     nv.ptr(x), nv.ptr(x), None, nv.ptr(x), 16, nv.current_stream()))
+
+
+def test_adam_prepare_job_plus_apply_equals_adam_step():
+    """lidbox_adam_prepare_job run by lidbox_reduce_jobs_run (together with a wgrad-style slice sum in the same launch) +
+    lidbox_adam_apply == lidbox_adam_step bit for bit over three steps, with and without a scheduled rate; GEMM carriers
+    refuse the job kind.  Reference: tf.keras.optimizers.Adam under fit, lidbox/models/keras_utils.py:135-140,198-203."""
+    from lidbox_amd import _native as nv
+    import ctypes
+    rng = np.random.default_rng(4)
+    n = 4099
+    p0, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    st = nv.current_stream()
+    res = []
+    for split in (False, True):
+        pd, gd = torch.from_numpy(p0.copy()).cuda(), torch.from_numpy(g).cuda()
+        md, vd = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        state = torch.zeros(16, dtype=torch.uint8, device="cuda")
+        P = torch.from_numpy(rng.standard_normal((3, 512)).astype(np.float32)).cuda() if split else None
+        for step in range(3):
+            if step == 2:
+                state[12:16].view(torch.float32).fill_(5e-4)          # a scheduled rate for the third step
+            if split:
+                jobs = (nv.ReduceJob * 2)()
+                out = torch.zeros(512, device="cuda")
+                jobs[0] = nv.ReduceJob(P.data_ptr(), None, out.data_ptr(), None, 512, 512, 3, 512, 0, 2)
+                second = ctypes.cast(ctypes.addressof(jobs) + ctypes.sizeof(nv.ReduceJob), ctypes.POINTER(nv.ReduceJob))
+                nv.check(nv.lib.lidbox_adam_prepare_job(nv.ptr(state), 1e-3, 0.9, 0.999, second))
+                nv.check(nv.lib.lidbox_reduce_jobs_run(jobs, 2, st))
+                nv.check(nv.lib.lidbox_adam_apply(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 0.9, 0.999, 1e-7, 0.5, nv.ptr(state), st))
+                Pn = P.cpu().numpy()
+                assert np.array_equal(out.cpu().numpy(), (Pn[0] + Pn[1]) + Pn[2])
+            else:
+                nv.check(nv.lib.lidbox_adam_step(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 0.5, nv.ptr(state), st))
+        torch.cuda.synchronize()
+        assert int(state[:8].view(torch.int64).item()) == 3
+        res.append((pd.cpu(), md.cpu(), vd.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # a GEMM launch does not carry the optimizer's job
+    job = nv.ReduceJob()
+    nv.check(nv.lib.lidbox_adam_prepare_job(nv.ptr(state), 1e-3, 0.9, 0.999, ctypes.byref(job)))
+    a = torch.zeros((256, 64), device="cuda"); w = torch.zeros((64, 64), device="cuda"); c = torch.zeros((256, 64), device="cuda")
+    rc = nv.lib.lidbox_gemm_nt_carry(nv.Rows(a.data_ptr(), 0, 64, 1, 256), nv.ptr(w), 64, nv.Rows(c.data_ptr(), 0, 64, 1, 256), 64, 64, nv.EPI_NONE,
+                                     None, None, 0, ctypes.byref(job), 1, st)
+    assert rc != 0 and b"optimizer-prepare" in nv.lib.lidbox_hip_last_error()
