@@ -92,6 +92,13 @@ size_t lidbox_extract_features_workspace(const lidbox_feat_plan* plan, int kind,
 int lidbox_extract_features_fwd(const lidbox_feat_plan* plan, int kind, const float* signals,
                                 int B, int N, long sig_stride, float* out, long out_batch_stride,
                                 void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
+/* The same, and additionally out16 (may be NULL): a bfloat16 copy of the features (round-to-nearest-even) at the same element
+ * offsets as out (so the same batch stride, counted in elements) -- the shadow the bf16-storage Conv1D path reads
+ * (lidbox_gemm_bf16s_nt).  The fused log-mel kernel (the train step's) writes it from its own store stage when
+ * out_batch_stride is a multiple of 4; other kinds and shapes get one conversion pass after their kernel.  out16 8-byte aligned. */
+int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* plan, int kind, const float* signals,
+                                       int B, int N, long sig_stride, float* out, long out_batch_stride, void* out16,
+                                       void* workspace, size_t workspace_bytes, lidbox_stream_t stream);
 
 /* ------------------------------------------------------------------ normalisation (a7-a10) */
 

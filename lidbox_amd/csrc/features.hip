@@ -349,6 +349,7 @@ struct FusedArgs {
     const float* dct;
     float* out;
     long out_bs;                // floats between consecutive utterances in out
+    unsigned short* out16;      // SHADOW instantiations: bfloat16 copy of the output (round-to-nearest-even) at the same ELEMENT offsets as out
     int tiles_per_utt;          // ceil(T / 8)
     long ntiles;                // B * tiles_per_utt
     int iters;                  // tiles per wave
@@ -444,7 +445,7 @@ __host__ __device__ inline int mel_table_floats(bool segmel, int M, int nnz, int
 // gets the same number of consecutive tiles (+- 1).  Round 4's counters (profiles/r04_feature_census.txt) show the kernel
 // waiting, not issuing: a wave64 vector instruction costs ~2.3 cycles (tools/micro/valu_rate2), the 1 606 of a tile ~3.7 k
 // of the ~8 k cycles a SIMD spends per tile, and waves are parked 36 % of their cycles.
-template <int KIND, bool VEC4, bool POW2, bool SEGMEL, int NW = 4>
+template <int KIND, bool VEC4, bool POW2, bool SEGMEL, int NW = 4, bool SHADOW = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_feat512_kernel(const FusedArgs a) {
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -878,8 +879,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
                     if (i1 < total) v1 = *reinterpret_cast<const float4*>(s_stage + i1);
                     if (i0 < total) *reinterpret_cast<float4*>(dst + i0) = v0;
                     if (i1 < total) *reinterpret_cast<float4*>(dst + i1) = v1;
+                    if constexpr (SHADOW) {
+                        // the bf16 shadow the first Conv1D of the bf16-storage path reads (gemm_bf16.hip), written here instead of
+                        // by a conversion launch over the whole feature tensor
+                        typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                        unsigned short* d16 = a.out16 + (dst - a.out);
+                        const bf4 h0 = {(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w}, h1 = {(__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+                        if (i0 < total) *reinterpret_cast<bf4*>(d16 + i0) = h0;
+                        if (i1 < total) *reinterpret_cast<bf4*>(d16 + i1) = h1;
+                    }
                 } else {
-                    for (int i = lane; i < total; i += 64) dst[i] = s_stage[i];
+                    for (int i = lane; i < total; i += 64) {
+                        dst[i] = s_stage[i];
+                        if constexpr (SHADOW) a.out16[(dst - a.out) + i] = __builtin_bit_cast(unsigned short, (__bf16)s_stage[i]);
+                    }
                 }
             }
         }
@@ -995,6 +1008,12 @@ __global__ void generic_dct_kernel(const float* __restrict__ logmel, long nframe
     out[i] = acc;
 }
 
+// out16[b*bs + i] = bf16(out[b*bs + i]), i < per: the shadow of feature kinds whose kernel does not store it itself
+__global__ void shadow_rows_kernel(const float* __restrict__ in, unsigned short* __restrict__ out16, long bs, long per) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < per) out16[blockIdx.y * bs + i] = __builtin_bit_cast(unsigned short, (__bf16)in[blockIdx.y * bs + i]);
+}
+
 constexpr int FEAT_WIDE_NW = 14;          // waves of the wide log-mel workgroup (see fused_feat512_kernel)
 
 template <int KIND>
@@ -1002,15 +1021,22 @@ int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool 
     const bool pow2 = (p->power == 2.0f);
 #define LBX_FUSED(V, P2, SG)                                                                          \
     hipLaunchKernelGGL((fused_feat512_kernel<KIND, V, P2, SG>), dim3(a.nwg), dim3(256), lds, st, a)
-    if (wide_nw == FEAT_WIDE_NW && KIND == LIDBOX_FEAT_LOGMEL && segmel && vec4 && pow2) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            LBX_HIP(hipFuncSetAttribute((const void*)fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, FEAT_WIDE_NW>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, FEAT_WIDE_NW>), dim3(a.nwg), dim3(64 * FEAT_WIDE_NW), lds,
-                           st, a);
+    if (KIND == LIDBOX_FEAT_LOGMEL && segmel && vec4 && pow2 && (wide_nw == FEAT_WIDE_NW || a.out16)) {
+        // the log-mel instantiations with their own launch shape: the wide workgroup and / or the bf16 shadow store
+#define LBX_LOGMEL(NWV, SH)                                                                                                          \
+    do {                                                                                                                             \
+        static bool attr_set = false;                                                                                                \
+        if (!attr_set && NWV != 4) {                                                                                                 \
+            LBX_HIP(hipFuncSetAttribute((const void*)fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, NWV, SH>,            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                      \
+            attr_set = true;                                                                                                         \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, NWV, SH>), dim3(a.nwg), dim3(64 * NWV), lds,  \
+                           st, a);                                                                                                   \
+    } while (0)
+        if (wide_nw == FEAT_WIDE_NW) { if (a.out16) LBX_LOGMEL(FEAT_WIDE_NW, true); else LBX_LOGMEL(FEAT_WIDE_NW, false); }
+        else LBX_LOGMEL(4, true);
+#undef LBX_LOGMEL
         LBX_LAUNCH_OK();
         return LIDBOX_OK;
     }
@@ -1052,6 +1078,15 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                                            int B, int N, long sig_stride, float* out,
                                            long out_batch_stride, void* workspace,
                                            size_t workspace_bytes, lidbox_stream_t stream) {
+    return lidbox_extract_features_fwd_shadow(p, kind, signals, B, N, sig_stride, out, out_batch_stride, nullptr, workspace, workspace_bytes, stream);
+}
+
+// + out16: a bfloat16 copy of the features (round-to-nearest-even) at the same element offsets as out (same batch stride, in
+// elements) -- the shadow the bf16-storage Conv1D path reads, written by the feature kernel itself.  Fused path, kinds
+// log-mel / mel only (LIDBOX_E_INVALID otherwise).
+extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int kind, const float* signals,
+                                                  int B, int N, long sig_stride, float* out, long out_batch_stride, void* out16,
+                                                  void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
     LBX_ARG(p && signals && out, "plan, signals, out != NULL");
     LBX_ARG(kind >= LIDBOX_FEAT_SPECTROGRAM && kind <= LIDBOX_FEAT_MFCC, "kind");
     LBX_ARG(kind != LIDBOX_FEAT_MFCC || p->ncoef > 0, "the plan's MFCC slice [coef_begin, coef_end) is empty");
@@ -1062,6 +1097,14 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
     const long chan = lidbox_feat_plan_channels(p, kind);
     if (out_batch_stride == 0) out_batch_stride = (long)T * chan;
     LBX_ARG(out_batch_stride >= (long)T * chan, "out_batch_stride >= T * channels");
+    LBX_ARG(!out16 || (((uintptr_t)out16) & 7) == 0, "out16 must be 8-byte aligned");
+    // bf16 shadow of kinds / shapes whose kernel has no shadow store: one conversion pass over what was just written
+    auto shadow_after = [&]() -> int {
+        const long per = (long)T * chan;
+        shadow_rows_kernel<<<dim3((unsigned)lbx_cdiv(per, 256L), (unsigned)B), 256, 0, st>>>(out, (unsigned short*)out16, out_batch_stride, per);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    };
 
     if (lidbox_feat_plan_is_fused(p, kind, signals, sig_stride)) {
         FusedArgs a;
@@ -1078,6 +1121,7 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
         a.win512 = p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
         a.mel_start = p->d_mel_start; a.mel_cnt = p->d_mel_cnt; a.mel_off = p->d_mel_off;
         a.mel_w = p->d_mel_w; a.dct = p->d_dct; a.out = out; a.out_bs = out_batch_stride;
+        a.out16 = nullptr;
 #ifdef LBX_FEAT_TIMING
         a.stamps = (workspace && workspace_bytes >= (size_t)768 * 4 * 12 * 8) ? (long long*)workspace : nullptr;
 #endif
@@ -1121,12 +1165,18 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                 a.iters = (int)lbx_cdiv((long)a.tiles_per_wg, (long)FEAT_WIDE_NW);
             }
         }
+        // the log-mel instantiation the train step uses stores the shadow itself (SHADOW = true)
+        const bool shadow_in_kernel = out16 && kind == LIDBOX_FEAT_LOGMEL && segmel && vec4 && p->power == 2.0f && out_batch_stride % 4 == 0;
+        if (shadow_in_kernel) a.out16 = (unsigned short*)out16;
+        int rc;
         switch (kind) {
-            case LIDBOX_FEAT_SPECTROGRAM: return launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, false, lds, st);
-            case LIDBOX_FEAT_MEL: return launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, segmel, lds, st);
-            case LIDBOX_FEAT_LOGMEL: return launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st, wide_nw);
-            default: return launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, segmel, lds, st);
+            case LIDBOX_FEAT_SPECTROGRAM: rc = launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, false, lds, st); break;
+            case LIDBOX_FEAT_MEL: rc = launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, segmel, lds, st); break;
+            case LIDBOX_FEAT_LOGMEL: rc = launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st, wide_nw); break;
+            default: rc = launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, segmel, lds, st); break;
         }
+        if (rc != LIDBOX_OK || !out16 || shadow_in_kernel) return rc;
+        return shadow_after();
     }
 
     // ---- generic path (dense output only)
@@ -1151,7 +1201,7 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                            p->power, spec);
     }
     LBX_LAUNCH_OK();
-    if (kind == LIDBOX_FEAT_SPECTROGRAM) return LIDBOX_OK;
+    if (kind == LIDBOX_FEAT_SPECTROGRAM) return out16 ? shadow_after() : LIDBOX_OK;
     float* mel = (kind == LIDBOX_FEAT_MFCC) ? (float*)workspace + nframes * p->F : out;
     hipLaunchKernelGGL(generic_mel_kernel, dim3((unsigned)lbx_cdiv(nframes * p->M, 256)), dim3(256), 0, st,
                        spec, nframes, p->F, p->M, p->d_mel_start, p->d_mel_cnt, p->d_mel_off,
@@ -1162,5 +1212,5 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                            st, mel, nframes, p->M, p->ncoef, p->d_dct, out);
         LBX_LAUNCH_OK();
     }
-    return LIDBOX_OK;
+    return out16 ? shadow_after() : LIDBOX_OK;
 }

@@ -38,8 +38,9 @@ class FeaturePlan:
     def num_frames(self, num_samples):
         return nv.lib.lidbox_num_frames(int(num_samples), self.frame_length, self.frame_step)
 
-    def run(self, kind, signals, out=None, out_batch_stride=0):
-        """signals [B,N] float32 on the HIP device -> [B,T,C]."""
+    def run(self, kind, signals, out=None, out_batch_stride=0, out16=None):
+        """signals [B,N] float32 on the HIP device -> [B,T,C].  out16: optional bfloat16 tensor laid out like `out`, receives
+        bf16(out) from the same call (the shadow the bf16-storage Conv1D path reads)."""
         nv.require_gpu_tensor(signals, "signals", torch.float32)
         if signals.dim() != 2:
             raise ValueError("Input signals for feature extraction must be batches of mono signals "
@@ -56,9 +57,11 @@ class FeaturePlan:
         wbytes = nv.lib.lidbox_extract_features_workspace(self.handle, kind, B, N, nv.ptr(signals), stride)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=signals.device) if wbytes else None
         with torch.cuda.device(signals.device):
-            nv.check(nv.lib.lidbox_extract_features_fwd(self.handle, kind, nv.ptr(signals), B, N, stride,
-                                                        nv.ptr(out), int(out_batch_stride), nv.ptr(ws), wbytes,
-                                                        nv.current_stream()))
+            if out16 is not None:
+                nv.require_gpu_tensor(out16, "out16", torch.bfloat16)
+            nv.check(nv.lib.lidbox_extract_features_fwd_shadow(self.handle, kind, nv.ptr(signals), B, N, stride,
+                                                               nv.ptr(out), int(out_batch_stride), nv.ptr(out16), nv.ptr(ws), wbytes,
+                                                               nv.current_stream()))
         return out
 
 

@@ -674,7 +674,7 @@ class SequentialTDNN:
             self._forward_frontend(ws, training, update_moving)
         if self.bf16_storage:
             self._refresh_bf16_weights()
-            if ws.act16[0] is not None:
+            if ws.act16[0] is not None and not ws.__dict__.pop("input16_fresh", False):   # else: the feature kernel wrote it
                 nv.check(lib.lidbox_f32_to_bf16(nv.ptr(ws.act[0]), nv.ptr(ws.act16[0]), ws.act[0].numel(), st))
         cin = self.input_dim
         fresh16 = False                                              # act16[i] holds bf16(act[i]) (written by conv i-1's epilogue)

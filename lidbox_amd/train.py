@@ -258,6 +258,7 @@ class Trainer:
             # keys the mask, so every replay of the captured step draws a new one
             nv.check(lib.lidbox_spatial_dropout(in_ptr, ws.B, ws.T, C, in_bs, model.channel_dropout_rate,
                                                 self._dropout_seed(), nv.ptr(self.adam_state), None, st))
+        ws.input16_fresh = self._input_shadow_from_features(ws)
         # BatchNormalization layers: batch statistics; the running statistics move once per real step (not in warm-up passes)
         B = ws.B
         scale = self._loss_scale(B)
@@ -303,11 +304,26 @@ class Trainer:
         plan, kind = self.feature["plan"], self.feature["kind"]
         Bn, N = signals.shape
         stride = signals.stride(0) if Bn > 1 else N
-        # features land directly in the model's input buffer
-        nv.check(lib.lidbox_extract_features_fwd(plan.handle, kind, nv.ptr(signals), Bn, N, stride, in_ptr, in_bs, None, 0, st))
+        # features land directly in the model's input buffer -- and, on the bf16-storage path, in its bf16 shadow as well
+        sh = None
+        if self._input_shadow_from_features(ws):
+            sh = ctypes.c_void_p(ws.act16[0].data_ptr() + (in_ptr.value - ws.act[0].data_ptr()) // 2)
+        nv.check(lib.lidbox_extract_features_fwd_shadow(plan.handle, kind, nv.ptr(signals), Bn, N, stride, in_ptr, in_bs, sh, None, 0, st))
         if self.feature.get("cmvn"):
             # per-utterance CMVN over time (features/__init__.py:22-32), in place where the conv reads it
             nv.check(lib.lidbox_cmvn_strided_fwd(in_ptr, Bn, ws.T, C, in_bs, 1, in_ptr, in_bs, st))
+
+    def _input_shadow_from_features(self, ws):
+        """True when the feature call also writes bf16(act[0]) (lidbox_extract_features_fwd_shadow: the log-mel kernel's store
+        stage does it), so that forward_ws skips its conversion launch: bf16-storage model, 1-D input, and nothing rewriting
+        the features in place afterwards (CMVN, channel dropout)."""
+        m = self.model
+        if self.feature is None or not m.bf16_storage or m.frontend or ws.act16[0] is None:
+            return False
+        if self.feature.get("cmvn") or m.channel_dropout_rate > 0 or os.environ.get("LIDBOX_FEAT_NO_SHADOW"):    # env: A/B aid
+            return False
+        in_ptr, _, _, _ = ws.input_target()
+        return (in_ptr.value - ws.act[0].data_ptr()) % 16 == 0 and ws.act16[0].data_ptr() % 8 == 0
 
     def _rank_mix(self):
         """per-rank offset of every dropout seed under data parallelism (0 for a single process)"""

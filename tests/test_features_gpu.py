@@ -331,3 +331,31 @@ def test_concurrent_callers_on_one_plan_are_bit_identical():
     assert set(results) == set(expect)
     for key, ref in expect.items():
         assert torch.equal(results[key], ref), key
+
+
+@pytest.mark.parametrize("B,dur", [(6, 2.0), (300, 1.0), (3, 0.37)])
+def test_bf16_shadow_equals_rounded_features(B, dur):
+    """lidbox_extract_features_fwd_shadow: out16 == bf16(out) bit for bit (round-to-nearest-even), and `out` is what the call
+    without a shadow writes -- the log-mel kernel's own shadow store (4-wave and wide workgroup shapes), the conversion
+    pass of the other kinds, the generic (non-512 FFT) path, and a padded batch stride whose gap stays untouched."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.testutil import synthetic_batch
+    x = torch.from_numpy(synthetic_batch(B, num_labels=4, duration_s=dur, seed=B)[0]).cuda()
+    plans = [audio.get_plan(16000, 400, 160)] + ([audio.get_plan(16000, 400, 160, fft_length=1024)] if B == 6 else [])
+    for plan in plans:
+        for kind in (nv.FEAT_LOGMEL, nv.FEAT_MEL, nv.FEAT_MFCC, nv.FEAT_SPECTROGRAM):
+            ref = plan.run(kind, x)
+            out16 = torch.full(ref.shape, 7.0, dtype=torch.bfloat16, device="cuda")
+            got = plan.run(kind, x, out16=out16)
+            assert torch.equal(got, ref)
+            assert torch.equal(out16, ref.to(torch.bfloat16)), (kind, plan.fft_length)
+    # strided: utterances 3 rows apart more than dense; the gap rows keep their fill in both buffers
+    plan = plans[0]
+    T, C = plan.num_frames(x.shape[1]), 40
+    buf = torch.full((B, T + 3, C), -5.0, device="cuda")
+    buf16 = torch.full((B, T + 3, C), -5.0, dtype=torch.bfloat16, device="cuda")
+    plan.run(nv.FEAT_LOGMEL, x, out=buf, out_batch_stride=(T + 3) * C, out16=buf16)
+    ref = plan.run(nv.FEAT_LOGMEL, x)
+    assert torch.equal(buf[:, :T], ref) and torch.equal(buf16[:, :T], ref.to(torch.bfloat16))
+    assert (buf[:, T:] == -5.0).all() and (buf16[:, T:] == -5.0).all()
