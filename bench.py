@@ -102,6 +102,7 @@ class KernelTimer:
     i.e. by the names rocprofv3 --stats reports."""
 
     ENTRY = {"lidbox_gemm_nn": 0, "lidbox_gemm_nt": 1, "lidbox_gemm_tn": 2, "lidbox_gemm_nt_tn": 3, "lidbox_extract_features_fwd": -1,
+             "lidbox_extract_features_fwd_shadow": -1,
              "lidbox_gemm_tn_partial": 4, "lidbox_gemm_nt_carry": 5, "lidbox_gemm_nt_tn_carry": 6,
              "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13,
              "lidbox_gemm_bf16s_tn": 14, "lidbox_gemm_bf16s_nt_carry": 15, "lidbox_gemm_bf16s_tn_partial": 16}
