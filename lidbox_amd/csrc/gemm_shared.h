@@ -56,6 +56,13 @@ template <bool V>
 struct FarTag {
     static constexpr bool value = V;
 };
+template <int V>
+struct IntTag {
+    static constexpr int value = V;
+};
+#ifndef LBX_EPI_INNER
+#define LBX_EPI_INNER 1            // 0: A/B aid (every block through the predicated epilogue)
+#endif
 
 // Epilogue of one workgroup tile held as MI x NJ accumulator blocks per wave (waves 2 x 2).
 // Rows of this launch are [m_beg, M).  gridDim.y > 1 = split along K: raw partial sums go to
@@ -128,10 +135,13 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         return;
     }
     const bool far = batched && (unsigned)Cd.rpb < 28;          // wave-uniform
-    auto run = [&](auto far_tag) {
-    constexpr bool FAR = decltype(far_tag)::value;
-#pragma unroll
-    for (int bi = 0; bi < MI; ++bi) {
+    // INNER (wave-uniform, per 32-row block): every row of the block is inside the matrix and every column inside N -- the
+    // common case.  Neither the loads nor the stores are predicated then (an utterance boundary inside the block stays a
+    // select); measured: the predicated form costs the mask epilogues 6 % of a K = 512 launch.
+    auto block = [&](auto far_tag, auto inner_tag, auto bi_tag) {
+        constexpr bool FAR = decltype(far_tag)::value;
+        constexpr bool INNER = decltype(inner_tag)::value;
+        constexpr int bi = decltype(bi_tag)::value;
         const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
         // (b, t) of the block's first row; the other 15 rows are <= 27 below it
         unsigned b0 = 0, t0 = (unsigned)rbase;
@@ -143,6 +153,7 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         const unsigned t_wrap = batched ? (unsigned)Cd.rpb : 0xffffffffu;
         const long wrap = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
         auto row_off = [&](int dr) -> long {
+            if (INNER) return off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
             long o;
             if (FAR) o = rbase + dr < M ? row_offset(Cd, (unsigned)(rbase + dr)) : 0;
             else o = off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
@@ -150,7 +161,7 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         };
 #pragma unroll
         for (int bj = 0; bj < NJ; ++bj) {
-            const int c = colok[bj] ? col[bj] : 0;
+            const int c = (INNER || colok[bj]) ? col[bj] : 0;
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 float v[8], mv[8], ov[8];
@@ -182,14 +193,25 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int dr = ((r0 + i) & 3) + 8 * ((r0 + i) >> 2);
-                    if (rbase + dr < M && colok[bj]) {
+                    if (INNER || (rbase + dr < M && colok[bj])) {
                         if (!EXT || out_base) out_base[row_off(dr) + c] = v[i];
                         if (shadow) shadow[row_off(dr) + c] = __builtin_bit_cast(unsigned short, (__bf16)v[i]);
                     }
                 }
             }
         }
-    }
+    };
+    auto run = [&](auto far_tag) {
+        auto one = [&](auto bi_tag) {
+            constexpr int bi = decltype(bi_tag)::value;
+            const long rb0 = m0 + wm * (32 * MI) + bi * 32;                 // the block's first row (wave-uniform)
+            bool inner = LBX_EPI_INNER && !decltype(far_tag)::value && rb0 + 32 <= M && n0 + wn * (32 * NJ) + 32 * NJ <= N;
+            if (inner) block(far_tag, FarTag<true>{}, bi_tag);
+            else block(far_tag, FarTag<false>{}, bi_tag);
+        };
+        one(IntTag<0>{});
+        if constexpr (MI > 1) one(IntTag<1>{});
+        static_assert(MI <= 2, "store_rows_tile: MI <= 2");
     };
     if (far) run(FarTag<true>{});
     else run(FarTag<false>{});
