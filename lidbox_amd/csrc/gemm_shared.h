@@ -108,30 +108,49 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
     // read a safe address (offset 0) and only their store is predicated: no control flow between the loads.  Eight
     // rows at a time keeps the temporaries inside the registers the K loop no longer needs (occupancy unchanged).
     if (!has_mask && !accum) {
-        // store-only epilogues (forward: bias / bias + ReLU, partial sums): nothing to batch, rows go out as they come
-#pragma unroll
-        for (int bi = 0; bi < MI; ++bi) {
+        // store-only epilogues (forward: bias / bias + ReLU, partial sums): nothing to batch, rows go out as they come.
+        // INNER (wave-uniform, per 32-row block): all rows inside the matrix, all columns inside N, utterances of >= 28 rows
+        // (at most one boundary inside the block, a select): no per-lane branches around the stores.
+        auto fast_block = [&](auto inner_tag, auto bi_tag) {
+            constexpr bool INNER = decltype(inner_tag)::value;
+            constexpr int bi = decltype(bi_tag)::value;
             const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
             unsigned b0 = 0, t0 = (unsigned)rbase;
             if (batched) { b0 = (unsigned)rbase / (unsigned)Cd.rpb; t0 = (unsigned)rbase - b0 * (unsigned)Cd.rpb; }
             const long off0 = batched ? (long)b0 * Cd.bs + (long)t0 * Cd.rs : rbase * out_rs;
+            const unsigned t_wrap = batched ? (unsigned)Cd.rpb : 0xffffffffu;
+            const long wrap = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
                 const long row = rbase + dr;
-                if (row >= M) continue;
-                long off = off0 + dr * out_rs;
-                if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
+                long off;
+                if (INNER) {
+                    off = off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
+                } else {
+                    if (row >= M) continue;
+                    off = off0 + dr * out_rs;
+                    if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
+                }
 #pragma unroll
                 for (int bj = 0; bj < NJ; ++bj) {
-                    if (!colok[bj]) continue;
+                    if (!INNER && !colok[bj]) continue;
                     float x = acc[bi][bj][r] + bias[bj];
                     if (do_relu) x = fmaxf(x, 0.f);
                     if (!EXT || out_base) out_base[off + col[bj]] = x;
                     if (shadow && !partial) shadow[off + col[bj]] = __builtin_bit_cast(unsigned short, (__bf16)x);
                 }
             }
-        }
+        };
+        auto fast_one = [&](auto bi_tag) {
+            constexpr int bi = decltype(bi_tag)::value;
+            const long rb0 = m0 + wm * (32 * MI) + bi * 32;                 // the block's first row (wave-uniform)
+            const bool inner = LBX_EPI_INNER && rb0 + 32 <= M && n0 + wn * (32 * NJ) + 32 * NJ <= N && (!batched || (unsigned)Cd.rpb >= 28);
+            if (inner) fast_block(FarTag<true>{}, bi_tag);
+            else fast_block(FarTag<false>{}, bi_tag);
+        };
+        fast_one(IntTag<0>{});
+        if constexpr (MI > 1) fast_one(IntTag<1>{});
         return;
     }
     const bool far = batched && (unsigned)Cd.rpb < 28;          // wave-uniform
