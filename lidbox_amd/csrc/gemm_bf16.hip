@@ -369,19 +369,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tn_kernel(RowsD A, RowsD Bd, fl
     }
 #undef LBX16_STEP
     float* Pd = P + (long)split * K1 * N;
-    const int h = lane >> 5, l = lane & 31;
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-        const int col = n0 + wn * 64 + bj * 32 + l;
-        if (col >= N) continue;
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
-            }
-    }
+    store_partial_blocks<2, 2>(Pd, acc, i0, n0, wm, wn, lane, K1, N);
     if (do_csum) {
         // the 8 k-quad lanes of one column quad are lanes (lane & ~7) + 0..7: fixed-order butterfly
 #pragma unroll
@@ -758,19 +746,7 @@ __global__ __launch_bounds__(256, 2) void gemm16s_tn_kernel(RowsH A, RowsH Bd, f
     }
 #undef LBX16T_STEP
     float* Pd = P + (long)split * K1 * N;
-    const int h = lane >> 5, l = lane & 31;
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-        const int col = n0 + wn * 64 + bj * 32 + l;
-        if (col >= N) continue;
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
-            }
-    }
+    store_partial_blocks<2, 2>(Pd, acc, i0, n0, wm, wn, lane, K1, N);
     if (do_csum) {
         // threads with the same column piece: lanes pc + 16 {0..3} of every wave -- fixed-order butterfly, then the four
         // waves through LDS (free after the K loop's last barrier) in wave order

@@ -550,19 +550,7 @@ __device__ __forceinline__ void tn_dma_body(const RowsD& A, const RowsD& Bd, flo
         cur = nxt;
     }
     float* Pd = P + (long)split * K1 * N;
-    const int h = lane >> 5, l = lane & 31;
-#pragma unroll
-    for (int bj = 0; bj < NJ; ++bj) {
-        const int col = n0 + wn * (32 * NJ) + bj * 32 + l;
-        if (col >= N) continue;
-#pragma unroll
-        for (int bi = 0; bi < MI; ++bi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * (32 * MI) + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
-            }
-    }
+    store_partial_blocks<MI, NJ>(Pd, acc, i0, n0, wm, wn, lane, K1, N);
     if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
 }
 

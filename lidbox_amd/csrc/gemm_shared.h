@@ -236,6 +236,33 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
     else run(FarTag<false>{});
 }
 
+// wgrad tiles: the wave's MI x NJ accumulator blocks -> Pd[row][col] (one slice's partial sums, leading dimension N), rows
+// < K1, columns < N.  A 32 x 32 block wholly inside takes unpredicated stores (wave-uniform test).
+template <int MI, int NJ>
+__device__ __forceinline__ void store_partial_blocks(float* __restrict__ Pd, const f32x16 (&acc)[MI][NJ], int i0, int n0, int wm, int wn, int lane,
+                                                     int K1, int N) {
+    const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+    for (int bj = 0; bj < NJ; ++bj) {
+        const int cb = n0 + wn * (32 * NJ) + bj * 32, col = cb + l;
+#pragma unroll
+        for (int bi = 0; bi < MI; ++bi) {
+            const int rb = i0 + wm * (32 * MI) + bi * 32;
+            if (LBX_EPI_INNER && rb + 32 <= K1 && cb + 32 <= N) {
+                float* p = Pd + (long)(rb + 4 * h) * N + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[(long)((r & 3) + 8 * (r >> 2)) * N] = acc[bi][bj][r];
+            } else if (col < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
+                }
+            }
+        }
+    }
+}
+
 // C rows [m_beg, m_beg + Msub) = epi( sum_s P[s][Msub][N] ), fixed order
 // (bf16-storage launches: Cd.base may be NULL, mask16 = the ReLU mask source as bfloat16 -- see store_rows_tile)
 __global__ void rows_reduce_kernel(const float* __restrict__ P, int splits, long m_beg, long Msub, int N, RowsOutD Cd,

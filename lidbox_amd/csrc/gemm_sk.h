@@ -995,19 +995,7 @@ __global__ __launch_bounds__(256, SK_WGCU) void gemm_sk_tn_kernel(RowsD A, RowsD
     sk_kloop<SK_STAGES, SK_WGCU>(sk_smem, lds0, wv, n, prio_slot, issue, next, ra, rb, acc, SkNoDrain{}, [] {}, SkNoEpiOps{});
 
     float* Pd = P + (long)split * K1 * N;
-    const int h = lane >> 5, l = lane & 31;
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-        const int col = n0 + wn * 64 + bj * 32 + l;
-        if (col >= N) continue;
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < K1) Pd[(long)row * N + col] = acc[bi][bj][r];
-            }
-    }
+    store_partial_blocks<2, 2>(Pd, acc, i0, n0, wm, wn, lane, K1, N);
     if (do_csum && n0 + tid < N) Pc[(long)split * N + n0 + tid] = csum;
 }
 
