@@ -346,7 +346,8 @@ int lidbox_gemm_bf16s_last_carried(void);
  * the n parameters, and for each listed row-major [rows][cols] matrix at flat + offset a bf16 image at dst with its own
  * leading dimension: transposed ([cols][rows]: a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand
  * the forward GEMM reads) or as it is (rows padded to 8 elements, or several taps' [C_in][C_out] blocks side by side: the
- * operand images dgrad reads).  More than 48 matrices take further launches. */
+ * operand images dgrad reads).  More than 48 matrices take further launches.  flat16 == NULL: only the listed matrices
+ * (a model whose GEMMs read images only; a kernel that IS read in place is then listed with dst inside the flat16 buffer). */
 typedef struct {
     long  offset;       /* of the matrix inside flat, in floats */
     int   rows, cols;

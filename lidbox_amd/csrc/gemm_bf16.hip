@@ -1270,7 +1270,8 @@ extern "C" int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_st
 
 extern "C" int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const lidbox_weight_shadow_t* mats, int nmats,
                                           lidbox_stream_t stream) {
-    LBX_ARG(flat && flat16 && n >= 0 && nmats >= 0 && (nmats == 0 || mats), "flat, flat16 != NULL; nmats >= 0");
+    // flat16 == NULL: only the listed matrices (a model refreshes just the images it reads)
+    LBX_ARG(flat && n >= 0 && nmats >= 0 && (nmats == 0 || mats), "flat != NULL; nmats >= 0");
     LBX_ARG(aligned16(flat) && (((uintptr_t)flat16) & 7) == 0, "flat 16-byte, flat16 8-byte aligned");
     for (int i = 0; i < nmats; ++i) {
         const lidbox_weight_shadow_t& m = mats[i];
@@ -1296,7 +1297,7 @@ extern "C" int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long
             w.tile_end[k] = tiles;
         }
         w.n = k;
-        const long conv = done == 0 ? (n > 0 ? cb : 0) : 0;
+        const long conv = done == 0 ? (n > 0 && flat16 ? cb : 0) : 0;
         if (conv + tiles > 0) {
             hipLaunchKernelGGL(refresh_bf16_weights_kernel, dim3((unsigned)(conv + tiles)), dim3(256), 0, (hipStream_t)stream, flat,
                                (unsigned short*)flat16, n, (int)conv, w);

@@ -476,7 +476,9 @@ class SequentialTDNN:
         return max(0, max(u_max for _, _, _, u_max in self._dgrad_residues(i, T)) - (To - 1))
 
     def _refresh_bf16_weights(self):
-        """flat16 and the transposed conv kernels from the fp32 master copy, one launch"""
+        """the bf16 weight images from the fp32 master copy, one launch: the transposed conv kernels (forward), the dgrad
+        images, and -- of flat16 -- only the kernels a dgrad reads in place (k <= s, channels a multiple of 8: frame3 / frame4
+        of the x-vector); the rest of flat16 has no reader and is not refreshed (it stays zero)"""
         mats = getattr(self, "_w16t_descs", None)
         if mats is None:
             items = []
@@ -484,6 +486,8 @@ class SequentialTDNN:
                 off, cin, co = self.layout[c.name + ".W"][0], self._cin(i), c.filters
                 if self.w16t[i] is not None:
                     items.append((off, c.k * cin, co, self.w16t[i].data_ptr(), c.k * cin, 1))
+                if i >= 1 and self.shadow_dgrad_ok(i) and not self.wd16[i]:
+                    items.append((off, c.k * cin, co, self.flat16.data_ptr() + 2 * off, co, 0))       # read through _p16
                 for key, img in self.wd16[i].items():
                     if key == "fused":
                         items.append((off, c.k * cin, co, img.data_ptr(), img.shape[1], 0))
@@ -495,8 +499,7 @@ class SequentialTDNN:
                                       img.shape[1], 0))
             mats = (nv.WeightShadow * max(1, len(items)))(*[nv.WeightShadow(*it) for it in items])
             self._w16t_descs, self._w16t_n = mats, len(items)
-        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(self.flat), nv.ptr(self.flat16), self.num_flat, mats, self._w16t_n,
-                                                    nv.current_stream()))
+        nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(self.flat), None, self.num_flat, mats, self._w16t_n, nv.current_stream()))
 
     def _p16(self, name):
         off, _ = self.layout[name]

@@ -405,6 +405,18 @@ def test_refresh_bf16_weights_one_launch():
     for (r, c), o, d in zip(shapes, offs, dsts):
         assert torch.equal(d, flat[o:o + r * c].reshape(r, c).t().bfloat16())
     nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, None, 0, st))      # no matrices: convert only
+    # flat16 == NULL: only the listed matrices -- one of them an in-place image inside a flat16 buffer that is otherwise left alone
+    part16 = torch.full((n,), 3.0, dtype=torch.bfloat16, device="cuda")
+    for d in dsts:
+        d.zero_()
+    some = items[:4] + [(offs[1], shapes[1][0], shapes[1][1], part16.data_ptr() + 2 * offs[1], shapes[1][1], 0)]
+    some_c = (nv.WeightShadow * len(some))(*[nv.WeightShadow(*it) for it in some])
+    nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), None, n, some_c, len(some), st))
+    for (r, c), o, d in zip(shapes, offs, dsts):
+        assert torch.equal(d, flat[o:o + r * c].reshape(r, c).t().bfloat16())
+    r1, c1 = shapes[1]
+    assert torch.equal(part16[offs[1]:offs[1] + r1 * c1], flat[offs[1]:offs[1] + r1 * c1].bfloat16())
+    assert (part16[:offs[1]] == 3.0).all() and (part16[offs[1] + r1 * c1:] == 3.0).all()
     with pytest.raises(ValueError):                              # a matrix that sticks out of the vector
         mats[0] = nv.WeightShadow(n - 10, 200, 512, dsts[0].data_ptr(), 200, 1)
         nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(items), st))
