@@ -112,14 +112,21 @@ class KernelTimer:
         self.records = {}
         self._orig = {}
         self.feature_bytes = feature_bytes
-        # what an empty bracket measures: subtracted from every bracket (event record + the gap the host leaves)
+        # what a bracket adds to the launch inside it: brackets around a kernel of KNOWN duration (lidbox_calibration_spin: one
+        # wave timed by the device's constant-rate wall clock), minus that duration.  (An EMPTY bracket measures about twice
+        # as much -- two event records back to back -- and over-corrects: round 3's per-kernel times ran 6-8 us short of
+        # rocprofv3's.)
+        spin_us = 40.0
         e = [torch.cuda.Event(enable_timing=True) for _ in range(40)]
+        st = nv.current_stream()
+        nv.check(nv.lib.lidbox_calibration_spin(spin_us, st))
         torch.cuda.synchronize()
         for i in range(0, 40, 2):
             e[i].record()
+            nv.check(nv.lib.lidbox_calibration_spin(spin_us, st))
             e[i + 1].record()
         torch.cuda.synchronize()
-        self.bracket_overhead_ms = float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(0, 40, 2)]))
+        self.bracket_overhead_ms = max(0.0, float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(0, 40, 2)])) - spin_us * 1e-3)
 
     def _classify(self, name, args):
         import ctypes
@@ -454,8 +461,8 @@ def kernel_pass(nv, w, trainer, batch, nsteps):
                 "hbm_floor_us": round(1e6 * (traffic or 0) / (PEAK_HBM_GBS * 1e9), 2) or None,
                 "mfma_floor_us": round(1e6 * d["work_per_launch"] / (peak_mfma * 1e12), 2),
                 "bracket_overhead_us": round(1e3 * kt.bracket_overhead_ms, 2),
-                "note": "HIP-event brackets around the C-ABI calls that launch this instantiation (minus what an "
-                        "empty bracket measures), divided by the kernel launches they made "
+                "note": "HIP-event brackets around the C-ABI calls that launch this instantiation (minus what a "
+                        "bracket adds to a kernel of known duration: bracket_overhead_us), divided by the kernel launches they made "
                         "(lidbox_gemm_last_launches; a bracket also covers the split-K reduce kernel where one "
                         "follows); rocprofv3 --stats lists the same instantiation by this name; the two floors "
                         "are PMC HBM bytes / 8 TB/s and flops / the MFMA peak per launch"}

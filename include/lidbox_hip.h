@@ -359,6 +359,9 @@ int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const l
                                 lidbox_stream_t stream);
 /* dst[i] = bf16(src[i]) (round-to-nearest-even), n elements; dst[c][r] = bf16(src[r][c]) for an R x C matrix */
 int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream);
+/* Measurement aid (no reference counterpart): one wave that runs for `microseconds` by the device's constant-rate wall clock.
+ * A kernel of known duration -- bench.py brackets it with HIP events to measure what a bracket adds to a launch. */
+int lidbox_calibration_spin(double microseconds, lidbox_stream_t stream);
 int lidbox_transpose_f32_to_bf16(const float* src, int R, int C, long ld_src, void* dst, long ld_dst,
                                  lidbox_stream_t stream);
 

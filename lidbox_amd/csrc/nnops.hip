@@ -1108,6 +1108,24 @@ extern "C" int lidbox_zero_2d(void* dst, size_t pitch, size_t width_bytes, size_
     return LIDBOX_OK;
 }
 
+// one wave that runs for a given time by the constant-rate wall clock: a kernel of KNOWN duration, for calibrating what a
+// HIP-event bracket adds to a launch (bench.py: KernelTimer)
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+}
+
+extern "C" int lidbox_calibration_spin(double microseconds, lidbox_stream_t stream) {
+    LBX_ARG(microseconds >= 0.0 && microseconds <= 1.0e6, "0 <= microseconds <= 1e6");
+    int dev = 0, khz = 0;
+    LBX_HIP(hipGetDevice(&dev));
+    LBX_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    LBX_ARG(khz > 0, "the device reports no wall-clock rate");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(microseconds * 1e-3 * khz));
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
 extern "C" int lidbox_scale(float* x, long n, float alpha, lidbox_stream_t stream) {
     LBX_ARG(x && n >= 0, "x != NULL");
     if (n == 0) return LIDBOX_OK;

@@ -4,9 +4,9 @@ T=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 python bench.py --compute-dtype bfloat16 > gpurun_out/${T}_bench_bf16.json 2>> gpurun_out/${T}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_stats -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-timing > /dev/null 2>&1
 cp $(ls gpurun_out/p_stats/*/*kernel_stats.csv | head -1) gpurun_out/${T}_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_stats16 -- python bench.py --compute-dtype bfloat16 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_stats16 -- python bench.py --compute-dtype bfloat16 --steps 100 --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-timing > /dev/null 2>&1
 cp $(ls gpurun_out/p_stats16/*/*kernel_stats.csv | head -1) gpurun_out/${T}_kernel_stats_bf16.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/p_fetch -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/p_write -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > /dev/null 2>&1
