@@ -110,9 +110,10 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
     if (!has_mask && !accum) {
         // store-only epilogues (forward: bias / bias + ReLU, partial sums): nothing to batch, rows go out as they come.
         // INNER (wave-uniform, per 32-row block): all rows inside the matrix, all columns inside N, utterances of >= 28 rows
-        // (at most one boundary inside the block, a select): no per-lane branches around the stores.
-        auto fast_block = [&](auto inner_tag, auto bi_tag) {
+        // (at most one boundary inside the block, a select): no per-lane branches around the stores, 32-bit offsets.
+        auto fast_block = [&](auto inner_tag, auto nowrap_tag, auto bi_tag) {
             constexpr bool INNER = decltype(inner_tag)::value;
+            constexpr bool NOWRAP = decltype(nowrap_tag)::value;      // INNER only: no utterance boundary inside the block
             constexpr int bi = decltype(bi_tag)::value;
             const long rbase = m0 + wm * (32 * MI) + bi * 32 + 4 * h;
             unsigned b0 = 0, t0 = (unsigned)rbase;
@@ -120,21 +121,44 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
             const long off0 = batched ? (long)b0 * Cd.bs + (long)t0 * Cd.rs : rbase * out_rs;
             const unsigned t_wrap = batched ? (unsigned)Cd.rpb : 0xffffffffu;
             const long wrap = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
+            if constexpr (INNER) {
+                // one 64-bit base per lane and column block, 32-bit row offsets (the inner test bounds them): per row a
+                // compare + select + add where an utterance boundary may fall inside the block, a scalar otherwise
+                float* pj[NJ];
+                unsigned short* sj[NJ];
+#pragma unroll
+                for (int bj = 0; bj < NJ; ++bj) {
+                    pj[bj] = out_base + off0 + col[bj];
+                    sj[bj] = shadow + off0 + col[bj];
+                }
+                const unsigned rs32 = (unsigned)out_rs, wrap32 = (unsigned)wrap;
+                const bool st32 = !EXT || out_base, st16 = shadow && !partial;
+                const unsigned wfrom = t_wrap - t0;                      // rows from this lane's first row to the boundary
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    const unsigned drs = (unsigned)dr * rs32;                                         // uniform: a scalar product
+                    const unsigned sel = NOWRAP ? 0u : ((unsigned)dr >= wfrom ? wrap32 : 0u);           // per lane: behind the boundary
+#pragma unroll
+                    for (int bj = 0; bj < NJ; ++bj) {
+                        float x = acc[bi][bj][r] + bias[bj];
+                        if (do_relu) x = fmaxf(x, 0.f);
+                        if (st32) (pj[bj] + drs)[sel] = x;
+                        if (st16) (sj[bj] + drs)[sel] = __builtin_bit_cast(unsigned short, (__bf16)x);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = (r & 3) + 8 * (r >> 2);
                 const long row = rbase + dr;
-                long off;
-                if (INNER) {
-                    off = off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
-                } else {
-                    if (row >= M) continue;
-                    off = off0 + dr * out_rs;
-                    if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
-                }
+                if (row >= M) continue;
+                long off = off0 + dr * out_rs;
+                if (batched && t0 + dr >= (unsigned)Cd.rpb) off = row_offset(Cd, (unsigned)row);   // crossed an utterance
 #pragma unroll
                 for (int bj = 0; bj < NJ; ++bj) {
-                    if (!INNER && !colok[bj]) continue;
+                    if (!colok[bj]) continue;
                     float x = acc[bi][bj][r] + bias[bj];
                     if (do_relu) x = fmaxf(x, 0.f);
                     if (!EXT || out_base) out_base[off + col[bj]] = x;
@@ -145,9 +169,13 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         auto fast_one = [&](auto bi_tag) {
             constexpr int bi = decltype(bi_tag)::value;
             const long rb0 = m0 + wm * (32 * MI) + bi * 32;                 // the block's first row (wave-uniform)
-            const bool inner = LBX_EPI_INNER && rb0 + 32 <= M && n0 + wn * (32 * NJ) + 32 * NJ <= N && (!batched || (unsigned)Cd.rpb >= 28);
-            if (inner) fast_block(FarTag<true>{}, bi_tag);
-            else fast_block(FarTag<false>{}, bi_tag);
+            const long wrap_u = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
+            const bool inner = LBX_EPI_INNER && rb0 + 32 <= M && n0 + wn * (32 * NJ) + 32 * NJ <= N && (!batched || (unsigned)Cd.rpb >= 28) &&
+                               out_rs > 0 && out_rs < (1L << 25) && wrap_u >= 0 && wrap_u < (1L << 30);
+            if (!inner) { fast_block(FarTag<false>{}, FarTag<false>{}, bi_tag); return; }
+            const bool nowrap = !batched || (unsigned)rb0 % (unsigned)Cd.rpb + 32u <= (unsigned)Cd.rpb;
+            if (nowrap) fast_block(FarTag<true>{}, FarTag<true>{}, bi_tag);
+            else fast_block(FarTag<true>{}, FarTag<false>{}, bi_tag);
         };
         fast_one(IntTag<0>{});
         if constexpr (MI > 1) fast_one(IntTag<1>{});
@@ -171,8 +199,10 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         // shorter utterances (wave-uniform test) take the general formula.
         const unsigned t_wrap = batched ? (unsigned)Cd.rpb : 0xffffffffu;
         const long wrap = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
+        // element `dr` rows below the lane's first row, column c, of an array laid out like C: INNER blocks use one 64-bit base
+        // per array, a scalar row product and a 32-bit select behind an utterance boundary (the inner test bounds them)
+        const unsigned rs32 = (unsigned)out_rs, wrap32 = (unsigned)wrap, wfrom = t_wrap - t0;
         auto row_off = [&](int dr) -> long {
-            if (INNER) return off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
             long o;
             if (FAR) o = rbase + dr < M ? row_offset(Cd, (unsigned)(rbase + dr)) : 0;
             else o = off0 + dr * out_rs + (t0 + dr >= t_wrap ? wrap : 0);
@@ -181,20 +211,24 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
 #pragma unroll
         for (int bj = 0; bj < NJ; ++bj) {
             const int c = (INNER || colok[bj]) ? col[bj] : 0;
+            auto at = [&](auto* base, int dr) {
+                if constexpr (INNER) return (base + off0 + c + (unsigned)dr * rs32) + ((unsigned)dr >= wfrom ? wrap32 : 0u);
+                else return base + row_off(dr) + c;
+            };
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 float v[8], mv[8], ov[8];
                 if (EXT && has_mask && mask16) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)                  // sign and zero-ness are all that is looked at: bits << 16 is the value
-                        mv[i] = __builtin_bit_cast(float, (unsigned)mask16[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c] << 16);
+                        mv[i] = __builtin_bit_cast(float, (unsigned)*at(mask16, ((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) << 16);
                 } else if (has_mask && !have_mask_bits) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) mv[i] = aux[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c];
+                    for (int i = 0; i < 8; ++i) mv[i] = *at(aux, ((r0 + i) & 3) + 8 * ((r0 + i) >> 2));
                 }
                 if (accum) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) ov[i] = out_base[row_off(((r0 + i) & 3) + 8 * ((r0 + i) >> 2)) + c];
+                    for (int i = 0; i < 8; ++i) ov[i] = *at(out_base, ((r0 + i) & 3) + 8 * ((r0 + i) >> 2));
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -213,8 +247,8 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
                 for (int i = 0; i < 8; ++i) {
                     const int dr = ((r0 + i) & 3) + 8 * ((r0 + i) >> 2);
                     if (INNER || (rbase + dr < M && colok[bj])) {
-                        if (!EXT || out_base) out_base[row_off(dr) + c] = v[i];
-                        if (shadow) shadow[row_off(dr) + c] = __builtin_bit_cast(unsigned short, (__bf16)v[i]);
+                        if (!EXT || out_base) *at(out_base, dr) = v[i];
+                        if (shadow) *at(shadow, dr) = __builtin_bit_cast(unsigned short, (__bf16)v[i]);
                     }
                 }
             }
@@ -224,7 +258,9 @@ __device__ __forceinline__ void store_rows_tile(const f32x16 (&acc)[MI][NJ], lon
         auto one = [&](auto bi_tag) {
             constexpr int bi = decltype(bi_tag)::value;
             const long rb0 = m0 + wm * (32 * MI) + bi * 32;                 // the block's first row (wave-uniform)
-            bool inner = LBX_EPI_INNER && !decltype(far_tag)::value && rb0 + 32 <= M && n0 + wn * (32 * NJ) + 32 * NJ <= N;
+            const long wrap_u = batched ? Cd.bs - (long)Cd.rpb * Cd.rs : 0;
+            const bool inner = LBX_EPI_INNER && !decltype(far_tag)::value && rb0 + 32 <= M && n0 + wn * (32 * NJ) + 32 * NJ <= N &&
+                               out_rs > 0 && out_rs < (1L << 25) && wrap_u >= 0 && wrap_u < (1L << 30);
             if (inner) block(far_tag, FarTag<true>{}, bi_tag);
             else block(far_tag, FarTag<false>{}, bi_tag);
         };
