@@ -289,9 +289,12 @@ def pmc_traffic(kernel_key, bf16=False, tag=None):
     elif kernel_key.startswith("gemm16s_rows_dma_kernel<"):          # rocprofv3 lists the fourth template argument (occupancy) too
         cands = [k for k in kern if k.startswith(kernel_key[:-1] + ",")]
         name = cands[0] if cands else None
-    elif kernel_key == "fused_feat512_kernel":
-        cands = [k for k in kern if k.startswith("fused_feat512_kernel<2,")]
+    elif kernel_key == "fused_feat512_kernel":                         # whichever instantiation this workload ran (log-mel: <2, ..>, MFCC: <3, ..>)
+        cands = [k for k in kern if k.startswith("fused_feat512_kernel<")]
         name = cands[0] if cands else None
+    elif kernel_key.startswith("gemm_rows_dma8_kernel<"):              # rocprofv3 lists the operand-order argument too
+        cands = [k for k in kern if k.startswith(kernel_key[:-1] + ",")]
+        name = max(cands, key=lambda k: kern[k].get("launches", 0)) if cands else None
     else:
         name = kernel_key if kernel_key in kern else None      # other families: exact name or nothing
     v = kern.get(name) if name else None
