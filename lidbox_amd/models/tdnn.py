@@ -833,6 +833,7 @@ class SequentialTDNN:
         lib = nv.lib
         B = ws.B
         ws.d16_fresh = set()                 # indices j whose dact16[j] holds bf16(dact[j]) (written by a dgrad epilogue)
+        ws.pending = []                      # jobs a pass that raised half-way left behind belong to that pass: never carried over
         gws, gws_n = nv.ptr(ws.gemm_ws), ws.gemm_ws.numel()
         # ---- dense chain (the output layer's share is already there when the train step fused it with the loss)
         top = len(self.denses) - 1

@@ -539,3 +539,32 @@ def test_learning_rate_schedule_reaches_the_captured_optimizer():
     w1 = m.flat.clone()
     t2.train_step(xd, yd)                      # device step 1 -> the schedule's second value (0), not its first
     assert torch.equal(m.flat, w1)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_jobs_left_by_an_interrupted_pass_are_dropped(dtype):
+    """A backward pass that raised half-way leaves carried-reduce jobs in the workspace's list.  The next pass must not run
+    them: here the left-over is a zero-fill job over frame5's weight gradient, which would wipe that layer's update.  Two
+    eager steps with the injection equal two steps of an untouched twin bit for bit."""
+    import ctypes
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    sig, y = synthetic_batch(6, num_labels=4, duration_s=1.0, seed=11)
+    x, lab = _dev(sig), _dev(y, np.int32)
+    plan = audio.get_plan(16000, 400, 160)
+    ms = [xvector.create((98, 40), 4, seed=0, compute_dtype=dtype) for _ in range(2)]
+    ts = [Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=False) for m in ms]
+    for t in ts:
+        t.train_step(x, lab)
+    ws = ms[0].workspace(6, 98)
+    off, shape = ms[0].layout["frame5.W"]
+    n = int(np.prod(shape))
+    stale = nv.ReduceJob()
+    nv.check(nv.lib.lidbox_zero_job(ctypes.c_void_p(ms[0].flat_grad.data_ptr() + 4 * off), n, n, 1, ctypes.byref(stale)))
+    ws.pending.append((stale, -1))
+    la, lb = float(ts[0].train_step(x, lab)), float(ts[1].train_step(x, lab))
+    assert la == lb and torch.equal(ms[0].flat, ms[1].flat)
+    assert not ws.pending
