@@ -125,6 +125,12 @@ int lidbox_minmax(const float* x, long n, float* out2, float* scratch, lidbox_st
 /* lidbox/features/__init__.py:5-9, axis=None: lo + (hi-lo)*divide_no_nan(x-min, max-min) */
 int lidbox_feature_scaling_fwd(const float* x, long n, const float* minmax2, float lo, float hi,
                                float* out, lidbox_stream_t stream);
+/* feature_scaling over ONE axis (reference lidbox/features/__init__.py:5-9 with axis = k): x viewed as [outer][R][inner],
+ * out = lo + (hi - lo) * divide_no_nan(x - min_R, max_R - min_R) with the min / max over R per (outer, inner).  outer <= 65535. */
+int lidbox_feature_scaling_axis_fwd(const float* x, long outer, long R, long inner, float lo, float hi, float* out,
+                                    lidbox_stream_t stream);
+/* audio.log10 (reference lidbox/features/audio.py:162-164): out = ln(x) / ln(10), elementwise, float32 op order. */
+int lidbox_log10_fwd(const float* x, long n, float* out, lidbox_stream_t stream);
 
 /* lidbox/features/audio.py:167-174 power_to_db: 20*(log10(max(amin,S)) - log10(max(amin,Smax))),
  * floored at (its own max) - top_db.  minmax2 = lidbox_minmax(S).  scratch as lidbox_minmax. */

@@ -80,6 +80,8 @@ _SIGS = {
     "lidbox_window_norm_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lidbox_minmax": (_i, [_vp, _l, _vp, _vp, _vp]),
     "lidbox_feature_scaling_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
+    "lidbox_feature_scaling_axis_fwd": (_i, [_vp, _l, _l, _l, _f, _f, _vp, _vp]),
+    "lidbox_log10_fwd": (_i, [_vp, _l, _vp, _vp]),
     "lidbox_power_to_db_fwd": (_i, [_vp, _l, _vp, _f, _f, _vp, _vp]),
     "lidbox_gemm_plan_query": (_i, [_i, _l, _i, _i, _sz, _vp]),
     "lidbox_gemm_last_launches": (_i, [_vp]),

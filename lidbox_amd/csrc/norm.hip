@@ -177,6 +177,49 @@ __global__ void feature_scaling_kernel(const float* __restrict__ x, long n,
 
 __device__ __forceinline__ float log10_tf(float v) { return logf(v) / logf(10.0f); }   // audio.py:164
 
+// audio.log10 (audio.py:162-164) as its own op: ln(x) / ln(10), elementwise
+__global__ void log10_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = log10_tf(x[i]);
+}
+
+// feature_scaling over ONE axis (features/__init__.py:5-9 with axis = k): x viewed as [outer][R][inner], min / max over R for
+// every (outer, inner), out = lo + (hi - lo) * divide_no_nan(x - min, max - min).  The decomposition of cmvn_kernel: a
+// workgroup owns cw consecutive inner positions of one outer index, 256 / cw row groups share the R rows.
+__global__ __launch_bounds__(256) void axis_scaling_kernel(const float* __restrict__ x, long R, long inner, int cw, float lo, float hi,
+                                                           float* __restrict__ out) {
+    __shared__ float rmin[256], rmax[256];
+    const int tid = threadIdx.x;
+    const int col = tid % cw, g = tid / cw, ng = 256 / cw;
+    const long c = (long)blockIdx.x * cw + col;
+    const long o = blockIdx.y;
+    const bool active = c < inner;
+    const float* xp = x + o * R * inner + c;
+    float* op = out + o * R * inner + c;
+    float mn = INFINITY, mx = -INFINITY;
+    if (active)
+        for (long r = g; r < R; r += ng) {
+            const float v = xp[r * inner];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    rmin[tid] = mn;
+    rmax[tid] = mx;
+    __syncthreads();
+    for (int h = ng / 2; h > 0; h >>= 1) {
+        if (g < h) {
+            rmin[tid] = fminf(rmin[tid], rmin[tid + h * cw]);
+            rmax[tid] = fmaxf(rmax[tid], rmax[tid + h * cw]);
+        }
+        __syncthreads();
+    }
+    const float lo_x = rmin[col], range = rmax[col] - rmin[col];
+    if (active)
+        for (long r = g; r < R; r += ng) {
+            const float q = range != 0.f ? (xp[r * inner] - lo_x) / range : 0.f;      // divide_no_nan
+            op[r * inner] = lo + (hi - lo) * q;
+        }
+}
+
 __global__ void power_to_db_kernel(const float* __restrict__ S, long n, const float* __restrict__ mm,
                                    float amin, float top_db, float* __restrict__ out) {
     const float ref = log10_tf(fmaxf(amin, mm[1]));
@@ -247,6 +290,28 @@ extern "C" int lidbox_feature_scaling_fwd(const float* x, long n, const float* m
     if (n == 0) return LIDBOX_OK;
     hipLaunchKernelGGL(feature_scaling_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n,
                        minmax2, lo, hi, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_feature_scaling_axis_fwd(const float* x, long outer, long R, long inner, float lo, float hi, float* out,
+                                               lidbox_stream_t stream) {
+    LBX_ARG(x && out, "x, out != NULL");
+    LBX_ARG(outer >= 0 && R >= 0 && inner >= 0, "non-negative shape");
+    if (outer == 0 || R == 0 || inner == 0) return LIDBOX_OK;
+    LBX_ARG(outer <= 65535, "outer <= 65535");
+    int cw = 64;
+    while (cw > 1 && cw / 2 >= inner) cw /= 2;
+    hipLaunchKernelGGL(axis_scaling_kernel, dim3((unsigned)lbx_cdiv(inner, cw), (unsigned)outer), dim3(256), 0, (hipStream_t)stream, x, R, inner,
+                       cw, lo, hi, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_log10_fwd(const float* x, long n, float* out, lidbox_stream_t stream) {
+    LBX_ARG(x && out && n >= 0, "x, out != NULL");
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(log10_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

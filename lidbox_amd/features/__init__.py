@@ -32,16 +32,22 @@ def _cmvn(X, axis, normalize_variance):
 
 
 def feature_scaling(X, min, max, axis=None):
-    """reference lidbox/features/__init__.py:5-9.  axis=None (the only form the pipeline uses,
-    tf_utils.py:189-190) runs the fused min/max + rescale kernels; an explicit axis is plain
-    tensor plumbing."""
+    """reference lidbox/features/__init__.py:5-9.  axis=None (the form the pipeline uses, tf_utils.py:189-190): the fused
+    min/max + rescale kernels over the whole tensor; an explicit axis: one kernel that takes min / max over that axis
+    (lidbox_feature_scaling_axis_fwd); a tuple of axes is not in the reference's callers and raises."""
     X = nv.require_gpu_tensor(X, "X", torch.float32)
     if axis is not None:
-        X_min = torch.amin(X, dim=axis, keepdim=True)
-        X_max = torch.amax(X, dim=axis, keepdim=True)
-        rng = X_max - X_min
-        q = torch.where(rng != 0, (X - X_min) / torch.where(rng != 0, rng, torch.ones_like(rng)), torch.zeros_like(X))
-        return min + (max - min) * q
+        if not isinstance(axis, int):
+            raise NotImplementedError("feature_scaling: axis must be None or one int")
+        X = X.contiguous()
+        out = torch.empty_like(X)
+        if X.numel() == 0:
+            return out
+        outer, R, inner = _as_outer_r_inner(X, axis)
+        with torch.cuda.device(X.device):
+            nv.check(nv.lib.lidbox_feature_scaling_axis_fwd(nv.ptr(X), outer, R, inner, float(min), float(max), nv.ptr(out),
+                                                            nv.current_stream()))
+        return out
     X = X.contiguous()
     out = torch.empty_like(X)
     if X.numel() == 0:

@@ -128,8 +128,13 @@ def _minmax(x):
 
 
 def log10(x):
-    """reference lidbox/features/audio.py:162-164: ln(x)/ln(10) (plain elementwise; torch holds the tensor)."""
-    return torch.log(x) / math.log(10.0)
+    """reference lidbox/features/audio.py:162-164: ln(x) / ln(10), float32 (lidbox_log10_fwd)."""
+    x = nv.require_gpu_tensor(x, "x", torch.float32).contiguous()
+    out = torch.empty_like(x)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            nv.check(nv.lib.lidbox_log10_fwd(nv.ptr(x), x.numel(), nv.ptr(out), nv.current_stream()))
+    return out
 
 
 def power_to_db(S, amin=1e-10, top_db=80.0):

@@ -38,18 +38,37 @@ class SparseAngularProximity:
 
     def __call__(self, y_true_sparse, y_pred):
         """Keras Loss.__call__: mean over the batch (SUM_OVER_BATCH_SIZE)."""
-        return self.call(y_true_sparse, y_pred).mean()
+        return self._mean(self.call(y_true_sparse, y_pred))
 
     def loss_and_grad(self, y_true_sparse, y_pred, scale=None):
         """(mean loss, d mean loss / d y_pred); scale defaults to 1/batch."""
         B = y_pred.shape[0]
         loss, dz = self._run(y_true_sparse, y_pred, True, (1.0 / B) if scale is None else scale)
-        return loss.mean(), dz
+        return self._mean(loss), dz
+
+    @staticmethod
+    def _mean(per_example):
+        """Keras' SUM_OVER_BATCH_SIZE reduction: lidbox_mean (one workgroup, fixed order)"""
+        out = torch.zeros((), dtype=torch.float32, device=per_example.device)
+        if per_example.numel():
+            with torch.cuda.device(per_example.device):
+                nv.check(nv.lib.lidbox_mean(nv.ptr(per_example), per_example.numel(), nv.ptr(out), nv.current_stream()))
+        return out
 
     def theta(self, z):
-        """reference losses.py:42-49 (elementwise acos of the first N coordinates)."""
-        return torch.acos(z[:, :self.N])
+        """reference losses.py:42-49 (elementwise acos of the first N coordinates): -predict, on the same kernel."""
+        out = self.predict(z)
+        if out.numel():
+            with torch.cuda.device(out.device):
+                nv.check(nv.lib.lidbox_scale(nv.ptr(out), out.numel(), -1.0, nv.current_stream()))
+        return out
 
     def predict(self, z):
-        """reference losses.py:51-52"""
-        return -self.theta(z)
+        """reference losses.py:51-52: -acos(z[:, :N]) (lidbox_neg_acos, the kernel the scoring path uses)"""
+        z = nv.require_gpu_tensor(z, "z", torch.float32).contiguous()
+        B, D = z.shape
+        out = torch.empty((B, self.N), dtype=torch.float32, device=z.device)
+        if out.numel():
+            with torch.cuda.device(z.device):
+                nv.check(nv.lib.lidbox_neg_acos(nv.ptr(z), B, D, self.N, nv.ptr(out), nv.current_stream()))
+        return out

@@ -222,9 +222,25 @@ def test_feature_scaling_and_power_to_db():
     y = F.feature_scaling(_dev(x), -1.0, 1.0).cpu().numpy()
     assert abs(y.min() + 1) < 1e-6 and abs(y.max() - 1) < 1e-6
     assert np.abs(y - fo.feature_scaling(x, -1.0, 1.0)).max() < 1e-5
-    for axis in (0, 1, 2):
+    for axis in (0, 1, 2, -1):
         y = F.feature_scaling(_dev(x), 0.0, 5.0, axis=axis).cpu().numpy()
         assert np.abs(y.min(axis=axis)).max() < 1e-5 and np.abs(y.max(axis=axis) - 5).max() < 1e-5
+        assert np.abs(y - fo.feature_scaling(x, 0.0, 5.0, axis=axis)).max() < 1e-5            # lidbox_feature_scaling_axis_fwd vs the oracle
+    # a constant slice: divide_no_nan -> the lower bound; wide and tall shapes (inner > 64, R not a multiple of the row groups)
+    xc = x.copy(); xc[:, :, 3] = 7.0
+    y = F.feature_scaling(_dev(xc), -2.0, 2.0, axis=1).cpu().numpy()
+    assert (y[:, :, 3] == -2.0).all() and np.abs(y - fo.feature_scaling(xc, -2.0, 2.0, axis=1)).max() < 1e-5
+    xw = rng.normal(0, 3, size=(3, 257, 130)).astype(np.float32)
+    for axis in (1, 2):
+        assert np.abs(F.feature_scaling(_dev(xw), 0.0, 1.0, axis=axis).cpu().numpy() - fo.feature_scaling(xw, 0.0, 1.0, axis=axis)).max() < 1e-5
+    assert F.feature_scaling(torch.zeros(0, 5, 3, device="cuda"), 0.0, 1.0, axis=1).shape == (0, 5, 3)
+    with pytest.raises(NotImplementedError):
+        F.feature_scaling(_dev(x), 0.0, 1.0, axis=(1, 2))
+    # audio.log10 (audio.py:162-164) on its own kernel
+    p = np.abs(rng.standard_normal((5, 1000)).astype(np.float32)) + 1e-3
+    got = audio.log10(_dev(p)).cpu().numpy()
+    assert np.abs(got - fo.log10(p)).max() < 1e-6 and np.abs(got - np.log10(p.astype(np.float64))).max() < 1e-6
+    assert torch.isneginf(audio.log10(torch.zeros(3, device="cuda"))).all() and torch.isnan(audio.log10(-torch.ones(2, device="cuda"))).all()
     S = np.abs(rng.standard_normal((2, 20, 33)).astype(np.float32)) ** 2
     for top_db in (10.0, 80.0):
         db = audio.power_to_db(_dev(S), top_db=top_db).cpu().numpy()

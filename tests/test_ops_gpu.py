@@ -281,6 +281,10 @@ def test_ap_loss_known_answers_and_grad():
     assert abs(float(loss) - mo.ap_loss(y, z, 17, 1.7)) < 1e-5
     _close(dz.cpu().numpy(), mo.ap_loss_grad(y, z, 17, 1.7), 1e-4)
     assert np.abs(ap.call(_dev(y, np.int32), _dev(z)).cpu().numpy() - mo.ap_loss_per_example(y, z, 17, 1.7)).max() < 1e-5
+    # theta / predict (losses.py:42-52) on the library's kernels: acos of the first N coordinates, and its negation
+    th, pr = ap.theta(_dev(z)).cpu().numpy(), ap.predict(_dev(z)).cpu().numpy()
+    assert th.shape == pr.shape == (64, 17)
+    assert np.abs(th - np.arccos(z[:, :17])).max() < 2e-6 and np.array_equal(pr, -th)
     with pytest.raises(ValueError):
         SparseAngularProximity(5, 4)
     with pytest.raises(ValueError):
