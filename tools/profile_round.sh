@@ -2,8 +2,6 @@
 set -x
 T=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
-python bench.py --compute-dtype bfloat16 > gpurun_out/${T}_bench_bf16.json 2>> gpurun_out/${T}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_stats -- python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-timing > /dev/null 2>&1
 cp $(ls gpurun_out/p_stats/*/*kernel_stats.csv | head -1) gpurun_out/${T}_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_stats16 -- python bench.py --compute-dtype bfloat16 --steps 100 --warmup 5 --no-cpu-baseline --no-secondary --no-kernel-timing > /dev/null 2>&1
@@ -23,13 +21,22 @@ for C in 3 4; do
   python tools/traffic_from_pmc.py gpurun_out/p_fetchc$C gpurun_out/p_writec$C gpurun_out/${T}_traffic_config$C.json | head -4
   rm -rf gpurun_out/p_fetchc$C gpurun_out/p_writec$C
 done
-python bench.py --config 3 > gpurun_out/${T}_bench_config3.json 2>> gpurun_out/${T}_bench.err
-python bench.py --config 4 > gpurun_out/${T}_bench_config4.json 2>> gpurun_out/${T}_bench.err
 python tools/bench_configs.py > gpurun_out/${T}_configs.jsonl 2>/dev/null
 python tools/step_calls.py float32 > gpurun_out/${T}_step_calls_fp32.txt 2>/dev/null
 python tools/step_calls.py bfloat16 > gpurun_out/${T}_step_calls_bf16.txt 2>/dev/null
 python tools/bench_bf16s.py 256 > gpurun_out/${T}_bf16_storage_gemm.txt 2>/dev/null
 tools/micro/valu_rate2 > gpurun_out/${T}_valu_rate2.txt 2>&1
 tools/micro/l2_rate > gpurun_out/${T}_l2_rate.txt 2>&1
+# the bench lines last: their `roofline.traffic` quotes the PMC summaries of THIS build (matched by source hash), which have to
+# sit in profiles/ when bench.py runs (on the box; the copies that are committed come from gpurun_out/)
+: > gpurun_out/${T}_bench.err
+cp gpurun_out/${T}_traffic.json gpurun_out/${T}_traffic_bf16.json gpurun_out/${T}_traffic_config3.json gpurun_out/${T}_traffic_config4.json profiles/
+python bench.py > gpurun_out/${T}_bench.json 2>> gpurun_out/${T}_bench.err
+python bench.py --compute-dtype bfloat16 > gpurun_out/${T}_bench_bf16.json 2>> gpurun_out/${T}_bench.err
+python bench.py --config 3 > gpurun_out/${T}_bench_config3.json 2>> gpurun_out/${T}_bench.err
+python bench.py --config 4 > gpurun_out/${T}_bench_config4.json 2>> gpurun_out/${T}_bench.err
+bash tools/prof_stats.sh ${T}s32 --steps 100 > /dev/null 2>&1; python tools/step_seq.py gpurun_out/${T}s32_kernel_trace.csv > gpurun_out/${T}_step_seq_fp32.txt
+bash tools/prof_stats.sh ${T}s16 --steps 100 --compute-dtype bfloat16 > /dev/null 2>&1; python tools/step_seq.py gpurun_out/${T}s16_kernel_trace.csv > gpurun_out/${T}_step_seq_bf16.txt
+rm -f gpurun_out/${T}s32_* gpurun_out/${T}s16_*
 rm -rf gpurun_out/p_stats gpurun_out/p_stats16 gpurun_out/p_fetch gpurun_out/p_write gpurun_out/p_fetch16 gpurun_out/p_write16 gpurun_out/p_mfma
 cut -c1-600 gpurun_out/${T}_bench.json; cut -c1-300 gpurun_out/${T}_bench_bf16.json
