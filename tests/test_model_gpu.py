@@ -568,3 +568,44 @@ def test_jobs_left_by_an_interrupted_pass_are_dropped(dtype):
     la, lb = float(ts[0].train_step(x, lab)), float(ts[1].train_step(x, lab))
     assert la == lb and torch.equal(ms[0].flat, ms[1].flat)
     assert not ws.pending
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_train_step_runs_one_standalone_slice_sum(dtype, monkeypatch):
+    """The wgrad slice sums of the x-vector step ride in the leading workgroups of later GEMM launches (carried reduces):
+    at the benchmark's batch size exactly ONE launch of their own is left per step -- frame1's (no dgrad behind it), together
+    with the optimizer's scalar job -- and the conv-layer dgrad calls carry the others."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.models import xvector
+    from lidbox_amd.testutil import synthetic_batch
+    from lidbox_amd.train import Trainer
+    sig, y = synthetic_batch(256, num_labels=4, duration_s=2.0, seed=5)     # BASELINE configs[1]'s per-GPU batch: the decompositions are per shape
+    x, lab = _dev(sig), _dev(y, np.int32)
+    m = xvector.create((198, 40), 4, seed=0, compute_dtype=dtype)
+    tr = Trainer(m, feature=dict(plan=audio.get_plan(16000, 400, 160), kind=nv.FEAT_LOGMEL), use_graph=False)
+    tr.train_step(x, lab)                                       # allocate, warm up
+    calls = {"standalone": 0, "jobs_in_standalone": 0, "carriers": 0, "carried": 0}
+    real_run = nv.lib.lidbox_reduce_jobs_run
+    carry_names = ["lidbox_gemm_nt_carry", "lidbox_gemm_nt_tn_carry"] if dtype == "float32" else ["lidbox_gemm_bf16s_nt_carry", "lidbox_gemm_nt_tn_carry"]
+    last = {"lidbox_gemm_nt_carry": nv.lib.lidbox_gemm_last_carried, "lidbox_gemm_nt_tn_carry": nv.lib.lidbox_gemm_last_carried,
+            "lidbox_gemm_bf16s_nt_carry": nv.lib.lidbox_gemm_bf16s_last_carried}
+
+    def run(jobs, n, stream):
+        calls["standalone"] += 1
+        calls["jobs_in_standalone"] += n
+        return real_run(jobs, n, stream)
+    monkeypatch.setattr(nv.lib, "lidbox_reduce_jobs_run", run)
+    for name in carry_names:
+        real = getattr(nv.lib, name)
+
+        def wrapped(*a, _real=real, _name=name):
+            rc = _real(*a)
+            calls["carriers"] += 1
+            calls["carried"] += int(last[_name]() > 0)
+            return rc
+        monkeypatch.setattr(nv.lib, name, wrapped)
+    loss = float(tr.train_step(x, lab))
+    assert np.isfinite(loss)
+    assert calls["standalone"] == 1 and calls["jobs_in_standalone"] == 2, calls       # frame1's slices + the optimizer's scalars
+    assert calls["carriers"] >= 5 and calls["carried"] >= 4, calls
