@@ -959,29 +959,24 @@ struct Dma16Choice {
 };
 
 // LIDBOX_GEMM16S_DMA: "0" off, "bm,bn,stages[,splits]" forces a variant (tuning aid, tools/gemm16_sweep.py); unset: policy
-Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes, bool has_mask = false) {
+Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes) {
     Dma16Choice c;
     int bm = 0, bn = 0, stg = 0, sp = 0;
     if (const char* e = getenv("LIDBOX_GEMM16S_DMA")) {
         if (sscanf(e, "%d,%d,%d,%d", &bm, &bn, &stg, &sp) < 3) return c;
         if (!((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && stg >= 2 && stg <= 4)) return c;
     } else {
-        // Measured per layer at bs 256 (profiles/r03_bf16_dma_variants.txt, us per call, register-staged 128 x 128 first):
-        // launches that put fewer than ~1.5 tiles of 128 x 128 on a CU finish sooner as 64 x 128 tiles, two stages
-        // (8448 x 512, K 512 / 1536: 22.0 -> 17.2, 39.1 -> 30.8), short-K launches (K <= 512: a tile is 8 steps, its
-        // epilogue half its life) as 64 x 64 (25344 x 512: 53.6 -> 49.0; 8448 x 1536: 54.0 -> 48.7); long-K launches that
-        // fill the chip stay on the 128 x 128 kernel (25344 x 512 x 1536: 71.8 vs 70.3-105).  Deeper rings lose: the
-        // launches are latency-, not bandwidth-bound, and every stage costs a resident workgroup.
-        // Round 4, after the epilogues lost their predication and 64-bit addressing (tools/bf16s_variants.py, bs 256, us per
-        // call: policy of round 3 -> now): the launches that fill the chip moved -- long K on 128 x 128 LDS-DMA tiles instead of
-        // the register-staged kernel (frame2 forward 69.8 -> 59.7, frame2's K = 1024 dgrad 60.4 -> 54.0), K <= 512 with a
-        // store-only epilogue on 64 x 128 (frame1 forward 39.8 -> 36.2, frame5 forward 33.6 -> 32.5); K <= 512 with a
-        // ReLU-mask epilogue stays on 64 x 64 (frame3's dgrad 37.2 vs 38.2).
+        // (round 3's table: profiles/r03_bf16_dma_variants.txt -- deeper rings lose: the launches are latency-, not bandwidth-bound,
+        // and every stage costs a resident workgroup)
+        // Round 4, after the epilogues lost their predication and 64-bit addressing, every variant on every rows launch of the
+        // step again (tools/bf16s_variants.py, us per call at bs 256 / 512, profiles/r04_bf16_variants.txt): 64 x 128 tiles on
+        // two stages are the best or within 1-2 us of it on every launch (sum 354.8 / 626.4 against 365.2 / 655.2 for round
+        // 3's table) except the longest one -- frame2's forward, K = 1536 on >= 3 tiles of 128 x 128 per CU -- which runs on
+        // 128 x 128 LDS-DMA tiles (69.8 -> 59.7 us at bs 256; the register-staged kernel it used is now the slowest choice).
         const long t128 = lbx_cdiv(M, 128L) * lbx_cdiv((long)N, 128L);
         if (t128 < NUM_CU / 2) return c;                       // split-K territory (dense head): register-staged kernel
-        if (t128 < 3 * NUM_CU / 2) { bm = 64; bn = 128; stg = 2; }
-        else if (K <= 512) { bm = 64; bn = has_mask ? 64 : 128; stg = 2; }
-        else { bm = 128; bn = 128; stg = 2; }
+        if (K >= 1536 && t128 >= 3 * NUM_CU) { bm = 128; bn = 128; stg = 2; }
+        else { bm = 64; bn = 128; stg = 2; }
     }
     c.bm = bm; c.bn = bn; c.stages = stg;
     const long tiles = lbx_cdiv(M, (long)bm) * lbx_cdiv((long)N, (long)bn);
@@ -1074,8 +1069,7 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
     const RowsH Ah_{(const __bf16*)A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch};
     const RowsH Bh_{(const __bf16*)B16, 0, ldb, 1, 0};
     {
-        const int epi_kind = epi & 0xff;
-        const Dma16Choice dc = choose_dma16(M, N, K, ws ? ws_bytes : 0, epi_kind == LIDBOX_EPI_RELU_MASK || epi_kind == LIDBOX_EPI_ACCUM_RELU_MASK);
+        const Dma16Choice dc = choose_dma16(M, N, K, ws ? ws_bytes : 0);
         // 32-bit byte offsets per lane inside the kernel: the operands' extents must fit
         const double a_ext = ((double)(A.batch - 1) * (double)A.batch_stride + (double)A.rows_per_batch * (double)A.row_stride + K) * 2.0;
         const double b_ext = ((double)N * (double)ldb + K) * 2.0;
