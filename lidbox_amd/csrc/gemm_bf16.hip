@@ -973,9 +973,16 @@ Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes) {
         // two stages are the best or within 1-2 us of it on every launch (sum 354.8 / 626.4 against 365.2 / 655.2 for round
         // 3's table) except the longest one -- frame2's forward, K = 1536 on >= 3 tiles of 128 x 128 per CU -- which runs on
         // 128 x 128 LDS-DMA tiles (69.8 -> 59.7 us at bs 256; the register-staged kernel it used is now the slowest choice).
+        // Smaller batches (same script at bs 128 / 64, r04_bf16_variants.txt): a launch whose 64 x 128 tiles fill the chip's
+        // 3 x 256 slots just over once (792 tiles: 1.03 rounds) runs a nearly empty second round -- 64 x 64 tiles win there by
+        // 10-15 % (128 x 128 for K >= 1536) -- and launches of less than half a round of 128 x 128 tiles, which round 3 left on
+        // the register-staged kernel, take 64 x 64 tiles split along K (bs 64: 14.7 / 7.5 / 16.5 / 9.4 us against 26 / 24 / 26 / 24).
         const long t128 = lbx_cdiv(M, 128L) * lbx_cdiv((long)N, 128L);
-        if (t128 < NUM_CU / 2) return c;                       // split-K territory (dense head): register-staged kernel
-        if (K >= 1536 && t128 >= 3 * NUM_CU) { bm = 128; bn = 128; stg = 2; }
+        const long t64x128 = lbx_cdiv(M, 64L) * lbx_cdiv((long)N, 128L);
+        const bool just_over_a_round = t64x128 > 3 * NUM_CU && 10 * t64x128 <= 12 * 3 * NUM_CU;
+        if (t128 < NUM_CU / 2) { bm = 64; bn = 64; stg = 2; }
+        else if (K >= 1536 && (t128 >= 3 * NUM_CU || just_over_a_round)) { bm = 128; bn = 128; stg = 2; }
+        else if (just_over_a_round) { bm = 64; bn = 64; stg = 2; }
         else { bm = 64; bn = 128; stg = 2; }
     }
     c.bm = bm; c.bn = bn; c.stages = stg;
