@@ -523,20 +523,6 @@ int lidbox_adam_prepare_job(void* state, float lr, float beta1, float beta2, lid
 int lidbox_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
                       float grad_scale, const void* state, lidbox_stream_t stream);
 
-/* The whole step as ONE launch, with the slice sums that are still pending at the end of the backward pass folded in (the
- * first layer's wgrad has no dgrad launch behind it to carry its job): the thread that updates a parameter whose gradient is a
- * pending sum adds the slices itself (order 0 .. splits-1: the same bits as lidbox_reduce_jobs_run), stores the gradient to
- * `grad` and uses it.  jobs: up to two pending jobs whose C / bias_grad lie inside [grad, grad + n) as dense rows at
- * 16-byte-aligned offsets; any other job list (zero fills, strided rows) is run as launches of its own first.  The counter
- * is advanced by the last workgroup to finish; the bias correction of step t + 1 is prepared during step t.  `aux`:
- * LIDBOX_ADAM_AUX_BYTES of device memory owned by the caller, zeroed once, 16-byte aligned, used by one stream at a time
- * (arrival tickets, the prepared bias correction tagged with its step and betas -- a state whose counter is set from
- * outside is detected and handled).  Result == lidbox_reduce_jobs_run(jobs) + lidbox_adam_step, bit for bit. */
-#define LIDBOX_ADAM_AUX_BYTES 8448
-int lidbox_adam_step_jobs(float* param, float* grad, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                          float grad_scale, void* state, const lidbox_reduce_job_t* jobs, int njobs, void* aux, size_t aux_bytes,
-                          lidbox_stream_t stream);
-
 /* ------------------------------------------------------------------ BatchNormalization (f1: xvector_2d.py:36,43)
  * tf.keras.layers.BatchNormalization(axis=-1) over x viewed as [R rows, C channels] (dense).  Training: batch mean and
  * population variance -> mean_out / invstd_out (kept for backward), scale = gamma * invstd, shift = beta - mean * scale,

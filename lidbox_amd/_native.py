@@ -39,9 +39,6 @@ class ReduceJob(C.Structure):
                 ("nblocks", C.c_uint)]
 
 
-ADAM_AUX_BYTES = 8448      # LIDBOX_ADAM_AUX_BYTES
-
-
 class WeightShadow(C.Structure):
     """lidbox_weight_shadow_t"""
     _fields_ = [("offset", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("dst", C.c_void_p), ("ld_dst", C.c_long),
@@ -145,7 +142,6 @@ _SIGS = {
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_adam_prepare_job": (_i, [_vp, _f, _f, _f, C.POINTER(ReduceJob)]),
     "lidbox_adam_apply": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp, _vp]),
-    "lidbox_adam_step_jobs": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, C.POINTER(ReduceJob), _i, _vp, _sz, _vp]),
     "lidbox_fill": (_i, [_vp, _l, _f, _vp]),
     "lidbox_dropout_rows": (_i, [Rows, _i, _f, C.c_ulonglong, _vp, _vp]),
     "lidbox_mean": (_i, [_vp, _l, _vp, _vp]),

@@ -742,164 +742,6 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-// ---- lidbox_adam_step_jobs: the optimizer step with the step's last wgrad slice sums folded in.
-// The backward's last wgrad (the first layer's: no dgrad launch behind it that could carry its fixed-order slice sum) used to
-// end in a launch of its own (splitk_reduce4_kernel, 11.7 us at bs 256) ahead of adam_kernel.  Here the thread that updates a
-// parameter whose gradient is such a pending sum adds the slices itself -- slice order 0 .. splits-1 from zero, one quad per
-// thread, eight 16-byte loads in flight: the sums and the update are bit-identical to lidbox_reduce_jobs_run + lidbox_adam_step
-// -- stores the gradient and uses it.  Those quads get workgroups of their own at the front of the grid (they are the launch's
-// long pole: `splits` dependent load batches), every other workgroup walks the rest of the vector as adam_kernel does.
-// The scalar half: every workgroup needs lr_t of step t = step + 1 at its start and nobody may advance the counter while
-// another workgroup can still read it.  (a) The bias correction c(t) = sqrt(1 - b2^t) / (1 - b1^t) (float64 pow: ~2 us of one
-// lane) is prepared one launch AHEAD by a workgroup that does nothing else, into slot t & 1 of the caller's scratch block,
-// tagged with (t, b1, b2); a launch that does not find its tag (the first one, or after the counter was set from outside)
-// derives c in the first wave of every workgroup.  (b) The last workgroup to FINISH publishes step = t and lr_t: found by
-// two-level arrival tickets (64 group counters on separate 128-byte lines, then one top counter: a single counter serialises
-// 2 048 arrivals at ~12 ns each, which is what round 4's first attempt at this measured), self-resetting.
-struct AdamRange {
-    const float* X;           // [splits][slice / 4] floats; quad q of the range is X[k][4 q .. 4 q + 3]
-    long lo, hi;              // quads [lo, hi) of the flat vector
-    long slice;               // floats between slices
-    int splits, accumulate;
-    unsigned first_block;
-};
-constexpr int ADAM_MAX_RANGES = 4;
-struct AdamRanges {
-    AdamRange r[ADAM_MAX_RANGES];
-    int count = 0;
-    unsigned job_blocks = 0;
-};
-struct AdamAux {              // LIDBOX_ADAM_AUX_BYTES, zeroed once by the caller
-    double c[2];
-    long long for_step[2];
-    float b1[2], b2[2];
-    unsigned pad[20];
-    unsigned tickets[65 * 32];
-};
-static_assert(sizeof(AdamAux) == 128 + 65 * 128, "LIDBOX_ADAM_AUX_BYTES");
-
-__device__ __forceinline__ double adam_bias_correction(float b1, float b2, long long t) {
-    return sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
-}
-
-__global__ __launch_bounds__(256) void adam_jobs_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, long n, AdamState* st, AdamAux* aux, float lr, float b1,
-                                                        float b2, float eps, float gscale, AdamRanges rs) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ double s_c;
-    const long long t = st->step + 1;
-    const int slot = (int)(t & 1);
-    const unsigned G = gridDim.x;
-    if (blockIdx.x == G - 1) {
-        // the preparing workgroup: c(t + 1) for the next launch (the other slot: nobody reads it in this launch)
-        if (threadIdx.x == 0) {
-            const int nslot = slot ^ 1;
-            aux->c[nslot] = adam_bias_correction(b1, b2, t + 1);
-            aux->b1[nslot] = b1;
-            aux->b2[nslot] = b2;
-            aux->for_step[nslot] = t + 1;
-        }
-    }
-    double c;
-    if (aux->for_step[slot] == t && aux->b1[slot] == b1 && aux->b2[slot] == b2) {
-        c = aux->c[slot];
-    } else {
-        if (threadIdx.x < 64) {
-            const double cc = adam_bias_correction(b1, b2, t);
-            if (threadIdx.x == 0) s_c = cc;
-        }
-        __syncthreads();
-        c = s_c;
-    }
-    const float base = __float_as_uint(st->lr_now) != 0u ? fabsf(st->lr_now) : lr;
-    const float lr_t = (float)((double)base * c);
-
-#define LBX_ADAM1(c)                                              \
-    {                                                             \
-        const float gr = gg.c * gscale;                           \
-        mm.c = b1 * mm.c + (1.f - b1) * gr;                       \
-        vv.c = b2 * vv.c + (1.f - b2) * gr * gr;                  \
-        pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps);          \
-    }
-#define LBX_ADAM_QUAD(i, gg)                                      \
-    {                                                             \
-        f4 pp = reinterpret_cast<f4*>(p)[i];                      \
-        f4 mm = reinterpret_cast<f4*>(m)[i];                      \
-        f4 vv = reinterpret_cast<f4*>(v)[i];                      \
-        LBX_ADAM1(x) LBX_ADAM1(y) LBX_ADAM1(z) LBX_ADAM1(w)       \
-        reinterpret_cast<f4*>(p)[i] = pp;                         \
-        reinterpret_cast<f4*>(m)[i] = mm;                         \
-        reinterpret_cast<f4*>(v)[i] = vv;                         \
-    }
-    if (blockIdx.x < rs.job_blocks) {
-        // a workgroup of pending sums: one quad per thread
-        int ri = 0;
-#pragma unroll
-        for (int i = 1; i < ADAM_MAX_RANGES; ++i)
-            if (i < rs.count && blockIdx.x >= rs.r[i].first_block) ri = i;
-        const AdamRange& r = rs.r[ri];
-        const long q = (long)(blockIdx.x - r.first_block) * 256 + threadIdx.x;
-        if (r.lo + q < r.hi) {
-            const f4* X = reinterpret_cast<const f4*>(r.X) + q;
-            const long sq = r.slice >> 2;
-            f4 s = {0.f, 0.f, 0.f, 0.f};
-            int k = 0;
-            for (; k + 8 <= r.splits; k += 8, X += 8 * sq) {
-                const f4 a = X[0], b = X[sq], cc = X[2 * sq], d = X[3 * sq], e = X[4 * sq], f = X[5 * sq], gq = X[6 * sq], h = X[7 * sq];
-                s = (((((((s + a) + b) + cc) + d) + e) + f) + gq) + h;
-            }
-            for (; k + 4 <= r.splits; k += 4, X += 4 * sq) {
-                const f4 a = X[0], b = X[sq], cc = X[2 * sq], d = X[3 * sq];
-                s = (((s + a) + b) + cc) + d;
-            }
-            for (; k < r.splits; ++k, X += sq) s += X[0];
-            const long i = r.lo + q;
-            f4* g4 = reinterpret_cast<f4*>(g) + i;
-            const f4 gg = r.accumulate ? *g4 + s : s;
-            *g4 = gg;
-            LBX_ADAM_QUAD(i, gg)
-        }
-    } else if (blockIdx.x < G - 1) {
-        const long n4 = n >> 2;
-        const long nb = (long)(G - 1 - rs.job_blocks);
-        const long first = (long)(blockIdx.x - rs.job_blocks) * 256 + threadIdx.x, stride = nb * 256;
-        for (long i = first; i < n4; i += stride) {
-            bool pending = false;
-#pragma unroll
-            for (int k = 0; k < ADAM_MAX_RANGES; ++k) pending |= k < rs.count && i >= rs.r[k].lo && i < rs.r[k].hi;
-            if (pending) continue;
-            const f4 gg = reinterpret_cast<const f4*>(g)[i];
-            LBX_ADAM_QUAD(i, gg)
-        }
-        for (long i = (n4 << 2) + first; i < n; i += stride) {         // tail
-            const float gr = g[i] * gscale;
-            const float mi = b1 * m[i] + (1.f - b1) * gr;
-            const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
-            m[i] = mi;
-            v[i] = vi;
-            p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
-        }
-    }
-#undef LBX_ADAM_QUAD
-#undef LBX_ADAM1
-    // arrival: every thread of this workgroup has read the state (its lr_t is computed); the last workgroup to get here
-    // advances the counter
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned grp = blockIdx.x & 63u, gsz = (G - grp + 63u) >> 6;
-        unsigned* tk = aux->tickets;
-        if (atomicAdd(&tk[grp * 32], 1u) == gsz - 1) {
-            tk[grp * 32] = 0u;
-            const unsigned ngrp = G < 64u ? G : 64u;
-            if (atomicAdd(&tk[64 * 32], 1u) == ngrp - 1) {
-                tk[64 * 32] = 0u;
-                st->step = t;
-                st->lr_t = lr_t;
-            }
-        }
-    }
-}
-
 // mean of n floats, one workgroup (fixed summation order: deterministic)
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     __shared__ float red[4];
@@ -1200,60 +1042,6 @@ extern "C" int lidbox_adam_apply(float* param, const float* grad, float* m, floa
     if (n == 0) return LIDBOX_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        m, v, n, (const AdamState*)state, beta1, beta2, eps, grad_scale);
-    LBX_LAUNCH_OK();
-    return LIDBOX_OK;
-}
-
-// one job's dW / db as ranges of the flat gradient; false: the job cannot be folded in (its sums go out as a launch)
-static bool adam_ranges_of(const lidbox_reduce_job_t& j, const float* grad, long n, AdamRanges* rs) {
-    if (j.splits < 1 || !j.partials || !j.C) return false;
-    auto add = [&](const float* X, const float* dst, long count, long slice) -> bool {
-        if (rs->count == ADAM_MAX_RANGES) return false;
-        const long off = dst - grad;
-        if (dst < grad || off + count > n || off % 4 != 0 || count % 4 != 0 || count < 4 || slice % 4 != 0 || (((uintptr_t)X) & 15) != 0) return false;
-        AdamRange& r = rs->r[rs->count++];
-        r.X = X; r.lo = off >> 2; r.hi = (off + count) >> 2; r.slice = slice; r.splits = j.splits; r.accumulate = j.accumulate;
-        r.first_block = rs->job_blocks;
-        rs->job_blocks += (unsigned)lbx_cdiv(count >> 2, 256L);
-        return true;
-    };
-    if (j.N < 1 || j.n % j.N != 0 || (j.ldc != j.N && j.n != j.N)) return false;       // dense rows only
-    if (!add(j.partials, j.C, j.n, j.n)) return false;
-    if (j.bias_grad && !add(j.bias_partials, j.bias_grad, (long)j.N, (long)j.N)) return false;
-    return true;
-}
-
-extern "C" int lidbox_adam_step_jobs(float* param, float* grad, float* m, float* v, long n, float lr, float beta1, float beta2,
-                                     float eps, float grad_scale, void* state, const lidbox_reduce_job_t* jobs, int njobs,
-                                     void* aux, size_t aux_bytes, lidbox_stream_t stream) {
-    LBX_ARG(param && grad && m && v && state && aux && n >= 0, "pointers != NULL");
-    LBX_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v | (uintptr_t)state | (uintptr_t)aux) & 15) == 0,
-            "param/grad/m/v/state/aux must be 16-byte aligned");
-    LBX_ARG(aux_bytes >= LIDBOX_ADAM_AUX_BYTES, "aux_bytes >= LIDBOX_ADAM_AUX_BYTES");
-    LBX_ARG(njobs >= 0 && (jobs || njobs == 0), "jobs != NULL");
-    AdamRanges rs;
-    bool fold = true;
-    for (int i = 0; i < njobs && fold; ++i) {
-        if (jobs[i].nblocks == 0) continue;
-        LBX_ARG(jobs[i].splits != -1, "an optimizer-prepare job has no place here: this call is the whole step");
-        const int before = rs.count;
-        fold = adam_ranges_of(jobs[i], grad, n, &rs);
-        // ranges must not overlap one another (two jobs on one matrix are ordered)
-        for (int a = before; a < rs.count && fold; ++a)
-            for (int b = 0; b < before; ++b) fold &= !(rs.r[a].lo < rs.r[b].hi && rs.r[b].lo < rs.r[a].hi);
-    }
-    if (!fold) {
-        // a job this kernel cannot take (a zero fill, strided rows, unaligned slices): all of them as launches, in order
-        rs = AdamRanges();
-        for (int i = 0; i < njobs; ++i) {
-            if (jobs[i].nblocks == 0) continue;
-            int rc = lidbox_reduce_jobs_run(jobs + i, 1, stream);
-            if (rc) return rc;
-        }
-    }
-    const long normal = ew_grid(n / 4 + 1);
-    hipLaunchKernelGGL(adam_jobs_kernel, dim3((unsigned)(rs.job_blocks + normal + 1)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n,
-                       (AdamState*)state, (AdamAux*)aux, lr, beta1, beta2, eps, grad_scale, rs);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

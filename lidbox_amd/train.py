@@ -394,15 +394,6 @@ class Trainer:
         for i in range(hi_edges[k] - 1, lo_edges[k] - 1, -1):
             self.model.backward_conv_ws(ws, i)
         self._prepared = False
-        self._adam_jobs = None
-        if (k == self.num_stages - 1 and not self._warming and not self.sync.active and not os.environ.get("LIDBOX_ADAM_PREPARE_LAUNCH")
-                and not os.environ.get("LIDBOX_ADAM_NO_FOLD")):
-            # one rank (no gradient exchange between the backward pass and the optimizer): the slice sums that are still open --
-            # the first layer's wgrad has no dgrad launch behind it to carry its job -- are added up by the optimizer launch
-            # itself (lidbox_adam_step_jobs; same sums, same update, one launch fewer), which also advances its own counter
-            self._adam_jobs = self.model._take_jobs(ws, 2)
-            self.model.join_wgrad()
-            return
         if k == self.num_stages - 1 and not self._warming and not os.environ.get("LIDBOX_ADAM_PREPARE_LAUNCH"):
             # the optimizer's scalar half (step counter, bias-corrected rate) rides in the launch that finishes the last wgrad
             job = nv.ReduceJob()
@@ -447,15 +438,6 @@ class Trainer:
     def _adam(self):
         o = self.opt
         m = self.model
-        if getattr(self, "_adam_jobs", None) is not None:      # the last backward stage left its open slice sums to this launch
-            jobs, n = self._adam_jobs
-            self._adam_jobs = None
-            if "_adam_aux" not in self.__dict__:
-                self._adam_aux = torch.zeros(nv.ADAM_AUX_BYTES, dtype=torch.uint8, device=self.device)
-            nv.check(nv.lib.lidbox_adam_step_jobs(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v), m.num_flat,
-                                                  o["lr"], o["beta_1"], o["beta_2"], o["epsilon"], 1.0, nv.ptr(self.adam_state),
-                                                  jobs, n, nv.ptr(self._adam_aux), self._adam_aux.numel(), nv.current_stream()))
-            return
         if getattr(self, "_prepared", False):      # the last backward stage carried the prepare half (lidbox_adam_prepare_job)
             nv.check(nv.lib.lidbox_adam_apply(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v), m.num_flat,
                                               o["beta_1"], o["beta_2"], o["epsilon"], 1.0, nv.ptr(self.adam_state), nv.current_stream()))

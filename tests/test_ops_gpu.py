@@ -549,97 +549,6 @@ def test_softmax_head_limits():
                                                     nv.ptr(x), nv.ptr(x), None, nv.ptr(x), 16, nv.current_stream()))
 
 
-def test_adam_step_jobs_equals_reduce_launch_plus_adam_step():
-    """lidbox_adam_step_jobs (the optimizer launch adds up the backward's last pending wgrad slices itself, prepares the next
-    step's bias correction and advances its own counter) == lidbox_reduce_jobs_run + lidbox_adam_step bit for bit: parameters,
-    moments, the stored gradient, the counter and the published lr_t, over five steps with a scheduled rate, a counter set from
-    outside (the prepared correction is then stale and must not be used), accumulate jobs, and job lists the kernel cannot fold
-    (strided rows, a zero fill: run as launches first).  Reference: tf.keras.optimizers.Adam under fit,
-    lidbox/models/keras_utils.py:135-140,198-203."""
-    from lidbox_amd import _native as nv
-    rng = np.random.default_rng(14)
-    n = 200 * 512 + 512 + 3 * 512 * 512 + 519                       # first layer's dW, db, a second matrix, an odd tail
-    K1, N, splits = 200, 512, 21
-    off_w, off_b, off_w2 = 0, K1 * N, K1 * N + N
-    p0 = rng.standard_normal(n).astype(np.float32)
-    g0 = rng.standard_normal(n).astype(np.float32)
-    P = torch.from_numpy(rng.standard_normal((splits, K1 * N)).astype(np.float32)).cuda()
-    Pc = torch.from_numpy(rng.standard_normal((splits, N)).astype(np.float32)).cuda()
-    P2 = torch.from_numpy(rng.standard_normal((5, 512 * 512)).astype(np.float32)).cuda()
-    st = nv.current_stream()
-
-    def jobs_for(gd, step):
-        jobs = (nv.ReduceJob * 2)()
-        base = gd.data_ptr()
-        jobs[0] = nv.ReduceJob(P.data_ptr(), Pc.data_ptr(), base + 4 * off_w, base + 4 * off_b, K1 * N, N, splits, N, 0, 101)
-        if step >= 1:      # a second job from step 1 on; it accumulates from step 3 on
-            jobs[1] = nv.ReduceJob(P2.data_ptr(), None, base + 4 * off_w2, None, 512 * 512, 512, 5, 512, 1 if step >= 3 else 0, 256)
-        return jobs
-
-    res = []
-    for fused in (False, True):
-        pd, gd = torch.from_numpy(p0.copy()).cuda(), torch.from_numpy(g0.copy()).cuda()
-        md, vd = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-        state = torch.zeros(16, dtype=torch.uint8, device="cuda")
-        aux = torch.zeros(nv.ADAM_AUX_BYTES, dtype=torch.uint8, device="cuda")
-        trace = []
-        for step in range(5):
-            if step == 2:
-                state[12:16].view(torch.float32).fill_(5e-4)          # a scheduled rate from the third step on
-            if step == 4:
-                state[:8].view(torch.int64).fill_(40)                 # the counter set from outside (a restored checkpoint)
-            jobs = jobs_for(gd, step)
-            if fused:
-                nv.check(nv.lib.lidbox_adam_step_jobs(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 0.5,
-                                                      nv.ptr(state), jobs, 2, nv.ptr(aux), aux.numel(), st))
-            else:
-                nv.check(nv.lib.lidbox_reduce_jobs_run(jobs, 2, st))
-                nv.check(nv.lib.lidbox_adam_step(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 0.5, nv.ptr(state), st))
-            torch.cuda.synchronize()
-            trace.append((pd.cpu().clone(), md.cpu().clone(), vd.cpu().clone(), gd.cpu().clone(), state.cpu().clone()))
-        assert int(state[:8].view(torch.int64).item()) == 41
-        if fused:
-            assert int(aux[128:].view(torch.int32).abs().sum().item()) == 0      # the tickets reset themselves
-        res.append(trace)
-    for step, (a, b) in enumerate(zip(*res)):
-        for k, (x, y) in enumerate(zip(a, b)):
-            assert torch.equal(x, y), (step, k)
-    Pn = P.cpu().numpy()
-    want = np.zeros(K1 * N, np.float32)
-    for k in range(splits):
-        want = want + Pn[k]
-    assert np.array_equal(res[1][0][3].numpy()[:K1 * N], want)
-
-    # job lists the kernel cannot fold run as launches of their own first: strided rows (ldc > N), a zero fill
-    for kind in ("strided", "zero"):
-        outs = []
-        for fused in (False, True):
-            pd, gd = torch.from_numpy(p0.copy()).cuda(), torch.from_numpy(g0.copy()).cuda()
-            md, vd = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-            state = torch.zeros(16, dtype=torch.uint8, device="cuda")
-            aux = torch.zeros(nv.ADAM_AUX_BYTES, dtype=torch.uint8, device="cuda")
-            jobs = (nv.ReduceJob * 2)()
-            if kind == "strided":
-                jobs[0] = nv.ReduceJob(P2.data_ptr(), None, gd.data_ptr(), None, 256 * 512, 1024, 5, 512, 0, 128)
-            else:
-                nv.check(nv.lib.lidbox_zero_job(gd.data_ptr() + 4 * 1024, 2048, 512, 8, jobs))
-            jobs[1] = nv.ReduceJob(P.data_ptr(), Pc.data_ptr(), gd.data_ptr() + 4 * 512 * 1024, gd.data_ptr() + 4 * (512 * 1024 + K1 * N),
-                                   K1 * N, N, splits, N, 0, 101)
-            if fused:
-                nv.check(nv.lib.lidbox_adam_step_jobs(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 1.0,
-                                                      nv.ptr(state), jobs, 2, nv.ptr(aux), aux.numel(), st))
-            else:
-                nv.check(nv.lib.lidbox_reduce_jobs_run(jobs, 2, st))
-                nv.check(nv.lib.lidbox_adam_step(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 1.0, nv.ptr(state), st))
-            torch.cuda.synchronize()
-            outs.append((pd.cpu(), gd.cpu(), md.cpu(), vd.cpu(), state.cpu()))
-        for x, y in zip(*outs):
-            assert torch.equal(x, y), kind
-    with pytest.raises(ValueError):                                  # scratch too small
-        nv.check(nv.lib.lidbox_adam_step_jobs(nv.ptr(pd), nv.ptr(gd), nv.ptr(md), nv.ptr(vd), n, 1e-3, 0.9, 0.999, 1e-7, 1.0,
-                                              nv.ptr(state), None, 0, nv.ptr(aux), 64, st))
-
-
 def test_adam_prepare_job_plus_apply_equals_adam_step():
     """lidbox_adam_prepare_job run by lidbox_reduce_jobs_run (together with a wgrad-style slice sum in the same launch) +
     lidbox_adam_apply == lidbox_adam_step bit for bit over three steps, with and without a scheduled rate; GEMM carriers
