@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--buckets", type=int, default=3,
                     help="gradient all-reduce buckets for N > 1 (3: frame1 | frame2 | rest -- only frame1's 0.4 MB is exposed)")
+    ap.add_argument("--grad-wire-dtype", choices=["float32", "bfloat16"], default="float32",
+                    help="wire format of the gradient all-reduce for N > 1 (Trainer(grad_wire_dtype=)): bfloat16 rounds every bucket "
+                         "once, exchanges half the bytes and widens the sum back to fp32 for Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -84,6 +87,16 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true",
                     help="default run (config 1, fp32, one GPU) only: do not append the configs[3] fp32 and configs[4] bf16-shard "
                          "measurements as `secondary` (profiling passes use this so that per-kernel counters are not mixed across workloads)")
+    ap.add_argument("--label-noise", type=float, default=None,
+                    help="probability with which a synthetic utterance's label is replaced by a uniformly drawn OTHER language "
+                         "(seeded, fixed per resident batch).  SURVEY 8d's languages are separable, so without it the loss reaches "
+                         "0.0 within a few dozen steps and the timed backward passes multiply near-zero gradients; the default "
+                         "(0.35 for the cross-entropy configurations, 0 for config 4 whose angular loss does not collapse) holds the "
+                         "loss well above 0.3 through the timed and sustained regions.  The work per step does not depend on it.")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="after the timed region: replay the same captured steps for at least this long and report the rate as "
+                         "`sustained` (0 disables).  The timed region of the driver's --steps 20 is ~45 ms; this block is long enough "
+                         "for a 5-second utilisation sampler to see the GPU busy and for clocks to settle")
     ap.add_argument("--compute-dtype", choices=["float32", "bfloat16"], default=None,
                     help="GEMM arithmetic; float32 is the BASELINE metric's configuration, bfloat16 = config 5's "
                          "bf16-compute / fp32-master variant of the same workload (default: what the configuration names)")
@@ -92,7 +105,13 @@ def parse_args():
         a.compute_dtype = "bfloat16" if a.config == 4 else "float32"
     if a.config == 4 and a.batch == PER_GPU_BATCH:
         a.batch = 512
+    if a.label_noise is None:
+        a.label_noise = default_label_noise(a.config)
     return a
+
+
+def default_label_noise(config):
+    return 0.0 if config == 4 else 0.35
 
 
 class KernelTimer:
@@ -403,14 +422,22 @@ def make_workload(config, compute_dtype, B, world, dev):
     return w
 
 
-def resident_batches(n, B, world, rank, num_langs, dev):
-    """SURVEY 8d recipe, seeds 1234, 1235, ...: this rank's contiguous shard of each global batch, resident in HBM"""
+def resident_batches(n, B, world, rank, num_langs, dev, label_noise=0.0):
+    """SURVEY 8d recipe, seeds 1234, 1235, ...: this rank's contiguous shard of each global batch, resident in HBM.
+    label_noise p: every label is replaced with probability p by a uniformly drawn other language (its own seeded stream,
+    the same on every rank), so that the separable synthetic task keeps a non-zero loss and the timed backward passes carry
+    real gradients; the waveforms are untouched."""
     from lidbox_amd.testutil import synthetic_batch
     from lidbox_amd.train import shard_bounds
     lo, hi = shard_bounds(B * world, rank, world)
     out = []
     for i in range(max(1, n)):
         sig, labels = synthetic_batch(B * world, num_langs, SAMPLE_RATE, DURATION_S, seed=1234 + i)
+        if label_noise > 0 and num_langs > 1:
+            rng = np.random.Generator(np.random.PCG64(99991 + i))
+            flip = rng.random(labels.shape[0]) < label_noise
+            other = (labels + rng.integers(1, num_langs, size=labels.shape[0])) % num_langs
+            labels = np.where(flip, other, labels).astype(labels.dtype)
         out.append((torch.from_numpy(sig[lo:hi]).to(dev), torch.from_numpy(labels[lo:hi].astype(np.int32)).to(dev)))
         del sig
     return out
@@ -437,6 +464,44 @@ def timed_steps(trainer, batches, warmup, steps, sync_all, prefetch=False):
         loss = trainer.train_step(*batches[(warmup + i) % n], **nxt(warmup + i))
     sync_all()
     return time.perf_counter() - t0, first_loss, float(loss)
+
+
+def sustained_steps(trainer, batches, start, seconds, est_ms, sync_all, prefetch=False):
+    """the same captured steps for >= `seconds` (step count fixed up front from the timed region's rate, so that every rank
+    runs the same number): (elapsed s, steps, last loss)"""
+    n = len(batches)
+    steps = max(20, int(np.ceil(1e3 * seconds / max(est_ms, 1e-3))))
+    nxt = (lambda i: dict(next_inputs=batches[(i + 1) % n][0])) if prefetch else (lambda i: {})
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = trainer.train_step(*batches[(start + i) % n], **nxt(start + i))
+    sync_all()
+    return time.perf_counter() - t0, steps, float(loss)
+
+
+def exposed_wait(w, trainer, batch, dev, world, nsteps=8):
+    """What the compute stream waits for the gradient exchange after the last backward launch (every rank runs this: the
+    steps contain collectives).  Eager steps on the trainer's own model / optimizer state with HIP events around
+    GradSync.wait(): the buckets of the upper layers overlap the remaining backward GEMMs, so this is the exposed part --
+    the last (smallest) bucket plus whatever of the earlier ones was not hidden.  Median / max over `nsteps`, max over ranks."""
+    from lidbox_amd.train import Trainer
+    import torch.distributed as dist
+    eager = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=False, num_buckets=trainer.sync.num_buckets,
+                    grad_wire_dtype="bfloat16" if trainer.sync.wire is not None else None)
+    eager.m, eager.v, eager.adam_state = trainer.m, trainer.v, trainer.adam_state
+    eager.train_step(*batch)
+    eager.sync.wait_events = []
+    for _ in range(nsteps):
+        eager.train_step(*batch)
+    torch.cuda.synchronize(dev)
+    us = sorted(1e3 * a.elapsed_time(b) for a, b in eager.sync.wait_events)
+    out = torch.tensor([us[len(us) // 2], us[-1]] if us else [0.0, 0.0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.MAX)
+    del eager
+    return {"median": round(float(out[0]), 1), "max": round(float(out[1]), 1), "steps": nsteps,
+            "note": "eager (un-captured) steps: HIP events on the compute stream around the join with the bucket all-reduces"}
 
 
 def kernel_pass(nv, w, trainer, batch, nsteps):
@@ -491,7 +556,8 @@ def secondary_run(nv, config, compute_dtype, B, dev, args):
     """one more BASELINE configuration on this GPU, same step count, same timing protocol: an entry of `secondary`"""
     from lidbox_amd.train import Trainer
     w = make_workload(config, compute_dtype, B, 1, dev)
-    batches = resident_batches(args.resident_batches, B, 1, 0, w["num_langs"], dev)
+    noise = default_label_noise(config)
+    batches = resident_batches(args.resident_batches, B, 1, 0, w["num_langs"], dev, label_noise=noise)
     trainer = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=not args.no_graph, num_buckets=1, metric=w["metric"])
 
     def sync_all():
@@ -502,10 +568,15 @@ def secondary_run(nv, config, compute_dtype, B, dev, args):
     ms = 1e3 * elapsed / args.steps
     value = B * args.steps / elapsed
     out = {"config": {"workload": w["workload"], "baseline_config": config, "reference_model": w["model_name"], "per_gpu_batch": B,
-                      "languages": w["num_langs"], "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6)},
+                      "languages": w["num_langs"], "label_noise": noise, "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6)},
            "metric": w["metric_name"], "dtype": "bf16" if w["bf16"] else "f32", "value": round(value, 1), "unit": "utterances/s",
            "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup,
            "step_tflops": round(value * w["flops_per_utt"] / 1e12, 2)}
+    if args.sustain_seconds > 0:
+        sec = min(args.sustain_seconds, 2.0)
+        s_el, s_n, s_loss = sustained_steps(trainer, batches, args.warmup + args.steps, sec, ms, sync_all, prefetch=args.prefetch)
+        out["sustained"] = {"value": round(B * s_n / s_el, 1), "ms_per_step": round(1e3 * s_el / s_n, 4), "steps": s_n,
+                            "seconds": round(s_el, 3), "final_loss": round(s_loss, 6)}
     if w["metric"] is not None:
         out["config"]["c_avg"] = round(float(w["metric"].result()), 4)
     if not args.no_kernel_timing:
@@ -544,8 +615,9 @@ def main():
     global_B = B * world
     w = make_workload(args.config, args.compute_dtype, B, world, dev)
     bf16, num_langs, metric = w["bf16"], w["num_langs"], w["metric"]
-    batches = resident_batches(args.resident_batches, B, world, rank, num_langs, dev)
-    trainer = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=not args.no_graph, num_buckets=args.buckets, metric=metric)
+    batches = resident_batches(args.resident_batches, B, world, rank, num_langs, dev, label_noise=args.label_noise)
+    trainer = Trainer(w["model"], loss=w["loss"], feature=w["feature"], use_graph=not args.no_graph, num_buckets=args.buckets, metric=metric,
+                      grad_wire_dtype=args.grad_wire_dtype)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -569,10 +641,26 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = global_B * args.steps / elapsed
 
+    # the same replayed steps for >= --sustain-seconds (outside the timed region; max over ranks like the headline)
+    sustained = None
+    if args.sustain_seconds > 0:
+        s_el, s_n, s_loss = sustained_steps(trainer, batches, args.warmup + args.steps, args.sustain_seconds, ms_per_step, sync_all,
+                                            prefetch=args.prefetch)
+        if world > 1:
+            t = torch.tensor([s_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            s_el = float(t.item())
+        if not np.isfinite(s_loss):
+            raise SystemExit("non-finite loss %r in the sustained block" % s_loss)
+        sustained = {"value": round(global_B * s_n / s_el, 1), "ms_per_step": round(1e3 * s_el / s_n, 4), "steps": s_n,
+                     "seconds": round(s_el, 3), "final_loss": round(s_loss, 6),
+                     "note": "the timed region's captured steps replayed for >= --sustain-seconds more (wall clock, barrier + "
+                             "synchronize on both sides, max over ranks); `value` above is the K-step timed region"}
+
     # per-step HIP events over K more steps (outside the timed region): the distribution behind the wall-clock mean
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for i, (e0, e1) in enumerate(evs):
-        j = args.warmup + args.steps + i                      # continue the rotation of the timed loop
+        j = args.warmup + args.steps + i + (sustained["steps"] if sustained else 0)   # continue the rotation of the timed loop
         e0.record()
         if not args.prefetch:
             trainer.train_step(*batches[j % len(batches)])
@@ -600,17 +688,27 @@ def main():
                    # what the timed steps did with the gradient exchange: none (one process) | in_graph (RCCL all-reduces
                    # captured inside the step's hipGraph) | segmented (host-launched between graph segments) | eager
                    "grad_sync": trainer.grad_sync_mode,
-                   "allreduce_bytes_per_step": 4 * int(w["model"].num_flat) if sync_active else 0,
+                   "allreduce_bytes_per_step": trainer.sync.wire_bytes if sync_active else 0,
+                   "allreduce_wire_dtype": args.grad_wire_dtype if sync_active else None,
                    "hip_graph": not args.no_graph, "resident_batches": len(batches),
                    "feature_prefetch": bool(args.prefetch),
+                   "label_noise": args.label_noise,
                    "first_loss": round(first_loss, 6), "final_loss": round(final_loss, 6),
-                   "loss_note": "SURVEY 8d's synthetic languages (one sine frequency each) are separable: the loss reaches ~0 within a "
-                                "few dozen Adam steps; every step still runs the full dense forward / backward / optimizer work"},
+                   "loss_note": "first_loss: the first step on the first resident batch; final_loss: the last step of the timed region. "
+                                "SURVEY 8d's synthetic languages (one sine frequency each) are separable, so with clean labels the loss "
+                                "reaches ~0 within a few dozen Adam steps; label_noise replaces that fraction of the labels by another "
+                                "language so that the timed backward passes carry real gradients (the work per step is the same "
+                                "either way)"},
     }
+    if sustained is not None:
+        result["sustained"] = sustained
     if rank_ms is not None:
         result["rank_ms_per_step"] = rank_ms
+    if sync_active:
         bounds = trainer.sync.bounds
-        result["config"]["allreduce_bucket_bytes"] = [4 * (b - a) for a, b in zip(bounds, bounds[1:])]
+        per = trainer.sync.wire_bytes // max(1, trainer.sync.flat.numel())
+        result["config"]["allreduce_bucket_bytes"] = [per * (b - a) for a, b in zip(bounds, bounds[1:])]
+        result["grad_sync_exposed_wait_us"] = exposed_wait(w, trainer, batches[0], dev, world)
 
     sys.stdout.flush()
     # RCCL writes its banner through C stdio, which is fully buffered when stdout is not a terminal: flush the C

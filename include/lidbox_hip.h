@@ -365,6 +365,10 @@ int lidbox_refresh_bf16_weights(const float* flat, void* flat16, long n, const l
                                 lidbox_stream_t stream);
 /* dst[i] = bf16(src[i]) (round-to-nearest-even), n elements; dst[c][r] = bf16(src[r][c]) for an R x C matrix */
 int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_stream_t stream);
+/* dst[i] = float(src[i]) (exact), n elements.  With lidbox_f32_to_bf16: the bf16 wire format of the data-parallel gradient
+ * exchange (Trainer(grad_wire_dtype="bfloat16"): a bucket is rounded once, all-reduced as bf16, widened back to fp32 for
+ * Adam).  New in this build: the reference is single-device (lidbox/models/keras_utils.py:191-203). */
+int lidbox_bf16_to_f32(const void* src, float* dst, long n, lidbox_stream_t stream);
 /* Measurement aid (no reference counterpart): one wave that runs for `microseconds` by the device's constant-rate wall clock.
  * A kernel of known duration -- bench.py brackets it with HIP events to measure what a bracket adds to a launch. */
 int lidbox_calibration_spin(double microseconds, lidbox_stream_t stream);

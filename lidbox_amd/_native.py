@@ -153,6 +153,7 @@ _SIGS = {
     "lidbox_gemm_bf16s_nt_carry": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _i, _vp]),
     "lidbox_gemm_bf16s_last_carried": (_i, []),
     "lidbox_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),
+    "lidbox_bf16_to_f32": (_i, [_vp, _vp, _l, _vp]),
     "lidbox_calibration_spin": (_i, [C.c_double, _vp]),
     "lidbox_transpose_f32_to_bf16": (_i, [_vp, _i, _i, _l, _vp, _l, _vp]),
     "lidbox_scale": (_i, [_vp, _l, _f, _vp]),

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include <type_traits>
@@ -1025,11 +1026,15 @@ int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool 
         // the log-mel instantiations with their own launch shape: the wide workgroup and / or the bf16 shadow store
 #define LBX_LOGMEL(NWV, SH)                                                                                                          \
     do {                                                                                                                             \
-        static bool attr_set = false;                                                                                                \
-        if (!attr_set && NWV != 4) {                                                                                                 \
+        /* the wide workgroup's LDS depends on the plan (tables + NWV wave slices): raise the limit to the CU's 160 KiB once per  */ \
+        /* DEVICE, so that a later plan with more mel bins / another sample rate, or a second GPU in the process, still launches   */ \
+        static std::atomic<unsigned long long> attr_devs{0};                                                                         \
+        int dev_ = 0;                                                                                                                \
+        LBX_HIP(hipGetDevice(&dev_));                                                                                                \
+        if (NWV != 4 && (dev_ >= 64 || !(attr_devs.load() >> dev_ & 1ull))) {                                                        \
             LBX_HIP(hipFuncSetAttribute((const void*)fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, NWV, SH>,            \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                      \
-            attr_set = true;                                                                                                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                    \
+            if (dev_ < 64) attr_devs.fetch_or(1ull << dev_);                                                                         \
         }                                                                                                                            \
         hipLaunchKernelGGL((fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, NWV, SH>), dim3(a.nwg), dim3(64 * NWV), lds,  \
                            st, a);                                                                                                   \

@@ -778,6 +778,23 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ src, unsigned short
         dst[i] = __builtin_bit_cast(unsigned short, (__bf16)src[i]);
 }
 
+// elementwise bf16 -> fp32 (exact), 4 values per thread when aligned
+__global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long n) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src + 4 * i);
+        f32x4 o;
+        o[0] = __uint_as_float(v.x << 16);
+        o[1] = __uint_as_float(v.x & 0xffff0000u);
+        o[2] = __uint_as_float(v.y << 16);
+        o[3] = __uint_as_float(v.y & 0xffff0000u);
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = o;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = __uint_as_float((unsigned)src[i] << 16);
+}
+
 // dst[c][r] = bf16(src[r][c]): 32 x 32 tiles through LDS (coalesced on both sides)
 __global__ __launch_bounds__(256) void transpose_f32_to_bf16_kernel(const float* __restrict__ src, int R, int C, long ld_src,
                                                                     unsigned short* __restrict__ dst, long ld_dst) {
@@ -1271,6 +1288,17 @@ extern "C" int lidbox_f32_to_bf16(const float* src, void* dst, long n, lidbox_st
     long g = lbx_cdiv(n / 4 + 1, 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_bf16_to_f32(const void* src, float* dst, long n, lidbox_stream_t stream) {
+    LBX_ARG(src && dst && n >= 0, "src, dst != NULL");
+    LBX_ARG(aligned16(dst) && (((uintptr_t)src) & 7) == 0, "dst 16-byte, src 8-byte aligned");
+    if (n == 0) return LIDBOX_OK;
+    long g = lbx_cdiv(n / 4 + 1, 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)src, dst, n);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -128,22 +128,36 @@ __global__ __launch_bounds__(256) void window_norm_kernel(const float* __restric
 
 constexpr int MM_MAX_WG = 1024;
 
+// tf.reduce_min / reduce_max propagate NaN (reference features/__init__.py:7-8 via tf.math.reduce_*); fminf / fmaxf drop it
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+__device__ __forceinline__ float wave_nan_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nan_min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_nan_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = nan_max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void minmax_stage1(const float* __restrict__ x, long n,
                                                      float* __restrict__ scratch) {
     __shared__ float smin[4], smax[4];
     float mn = FLT_MAX, mx = -FLT_MAX;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = x[i];
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+        mn = nan_min(mn, v);
+        mx = nan_max(mx, v);
     }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
+    mn = wave_nan_min(mn);
+    mx = wave_nan_max(mx);
     if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        scratch[blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-        scratch[MM_MAX_WG + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        scratch[blockIdx.x] = nan_min(nan_min(smin[0], smin[1]), nan_min(smin[2], smin[3]));
+        scratch[MM_MAX_WG + blockIdx.x] = nan_max(nan_max(smax[0], smax[1]), nan_max(smax[2], smax[3]));
     }
 }
 
@@ -152,16 +166,16 @@ __global__ __launch_bounds__(256) void minmax_stage2(const float* __restrict__ s
     __shared__ float smin[4], smax[4];
     float mn = FLT_MAX, mx = -FLT_MAX;
     for (int i = threadIdx.x; i < nwg; i += 256) {
-        mn = fminf(mn, scratch[i]);
-        mx = fmaxf(mx, scratch[MM_MAX_WG + i]);
+        mn = nan_min(mn, scratch[i]);
+        mx = nan_max(mx, scratch[MM_MAX_WG + i]);
     }
-    mn = wave_min(mn);
-    mx = wave_max(mx);
+    mn = wave_nan_min(mn);
+    mx = wave_nan_max(mx);
     if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out2[0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-        out2[1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        out2[0] = nan_min(nan_min(smin[0], smin[1]), nan_min(smin[2], smin[3]));
+        out2[1] = nan_max(nan_max(smax[0], smax[1]), nan_max(smax[2], smax[3]));
     }
 }
 
@@ -185,39 +199,42 @@ __global__ void log10_kernel(const float* __restrict__ x, long n, float* __restr
 // feature_scaling over ONE axis (features/__init__.py:5-9 with axis = k): x viewed as [outer][R][inner], min / max over R for
 // every (outer, inner), out = lo + (hi - lo) * divide_no_nan(x - min, max - min).  The decomposition of cmvn_kernel: a
 // workgroup owns cw consecutive inner positions of one outer index, 256 / cw row groups share the R rows.
-__global__ __launch_bounds__(256) void axis_scaling_kernel(const float* __restrict__ x, long R, long inner, int cw, float lo, float hi,
+__global__ __launch_bounds__(256) void axis_scaling_kernel(const float* __restrict__ x, long outer, long R, long inner, int cw, float lo, float hi,
                                                            float* __restrict__ out) {
     __shared__ float rmin[256], rmax[256];
     const int tid = threadIdx.x;
     const int col = tid % cw, g = tid / cw, ng = 256 / cw;
     const long c = (long)blockIdx.x * cw + col;
-    const long o = blockIdx.y;
     const bool active = c < inner;
-    const float* xp = x + o * R * inner + c;
-    float* op = out + o * R * inner + c;
-    float mn = INFINITY, mx = -INFINITY;
-    if (active)
-        for (long r = g; r < R; r += ng) {
-            const float v = xp[r * inner];
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
-        }
-    rmin[tid] = mn;
-    rmax[tid] = mx;
-    __syncthreads();
-    for (int h = ng / 2; h > 0; h >>= 1) {
-        if (g < h) {
-            rmin[tid] = fminf(rmin[tid], rmin[tid + h * cw]);
-            rmax[tid] = fmaxf(rmax[tid], rmax[tid + h * cw]);
-        }
+    // grid.y strides over the outer index (a grid dimension holds at most 65 535 workgroups)
+    for (long o = blockIdx.y; o < outer; o += gridDim.y) {
+        const float* xp = x + o * R * inner + c;
+        float* op = out + o * R * inner + c;
+        float mn = INFINITY, mx = -INFINITY;
+        if (active)
+            for (long r = g; r < R; r += ng) {
+                const float v = xp[r * inner];
+                mn = nan_min(mn, v);
+                mx = nan_max(mx, v);
+            }
+        rmin[tid] = mn;
+        rmax[tid] = mx;
         __syncthreads();
-    }
-    const float lo_x = rmin[col], range = rmax[col] - rmin[col];
-    if (active)
-        for (long r = g; r < R; r += ng) {
-            const float q = range != 0.f ? (xp[r * inner] - lo_x) / range : 0.f;      // divide_no_nan
-            op[r * inner] = lo + (hi - lo) * q;
+        for (int h = ng / 2; h > 0; h >>= 1) {
+            if (g < h) {
+                rmin[tid] = nan_min(rmin[tid], rmin[tid + h * cw]);
+                rmax[tid] = nan_max(rmax[tid], rmax[tid + h * cw]);
+            }
+            __syncthreads();
         }
+        const float lo_x = rmin[col], range = rmax[col] - rmin[col];
+        if (active)
+            for (long r = g; r < R; r += ng) {
+                const float q = range != 0.f ? (xp[r * inner] - lo_x) / range : 0.f;      // divide_no_nan
+                op[r * inner] = lo + (hi - lo) * q;
+            }
+        __syncthreads();                                   // rmin / rmax are rewritten by the next outer index
+    }
 }
 
 __global__ void power_to_db_kernel(const float* __restrict__ S, long n, const float* __restrict__ mm,
@@ -250,7 +267,6 @@ extern "C" int lidbox_cmvn_strided_fwd(const float* x, long outer, long R, long 
     LBX_ARG(outer >= 0 && R >= 0 && inner >= 0, "non-negative shape");
     LBX_ARG(x_outer_stride >= R * inner && out_outer_stride >= R * inner, "outer strides >= R * inner");
     if (outer == 0 || R == 0 || inner == 0) return LIDBOX_OK;
-    LBX_ARG(outer <= 65535, "outer <= 65535");
     int cw = 64;
     while (cw > 1 && cw / 2 >= inner) cw /= 2;
     dim3 grid((unsigned)lbx_cdiv(inner, cw), (unsigned)outer);
@@ -299,10 +315,9 @@ extern "C" int lidbox_feature_scaling_axis_fwd(const float* x, long outer, long 
     LBX_ARG(x && out, "x, out != NULL");
     LBX_ARG(outer >= 0 && R >= 0 && inner >= 0, "non-negative shape");
     if (outer == 0 || R == 0 || inner == 0) return LIDBOX_OK;
-    LBX_ARG(outer <= 65535, "outer <= 65535");
     int cw = 64;
     while (cw > 1 && cw / 2 >= inner) cw /= 2;
-    hipLaunchKernelGGL(axis_scaling_kernel, dim3((unsigned)lbx_cdiv(inner, cw), (unsigned)outer), dim3(256), 0, (hipStream_t)stream, x, R, inner,
+    hipLaunchKernelGGL(axis_scaling_kernel, dim3((unsigned)lbx_cdiv(inner, cw), (unsigned)(outer < 65535 ? outer : 65535)), dim3(256), 0, (hipStream_t)stream, x, outer, R, inner,
                        cw, lo, hi, out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;

@@ -34,16 +34,32 @@ def _cmvn(X, axis, normalize_variance):
 def feature_scaling(X, min, max, axis=None):
     """reference lidbox/features/__init__.py:5-9.  axis=None (the form the pipeline uses, tf_utils.py:189-190): the fused
     min/max + rescale kernels over the whole tensor; an explicit axis: one kernel that takes min / max over that axis
-    (lidbox_feature_scaling_axis_fwd); a tuple of axes is not in the reference's callers and raises."""
+    (lidbox_feature_scaling_axis_fwd); a tuple of axes is reduced as one axis (after a permutation when they are not adjacent)."""
     X = nv.require_gpu_tensor(X, "X", torch.float32)
     if axis is not None:
-        if not isinstance(axis, int):
-            raise NotImplementedError("feature_scaling: axis must be None or one int")
         X = X.contiguous()
         out = torch.empty_like(X)
+        if isinstance(axis, int):
+            outer, R, inner = _as_outer_r_inner(X, axis)
+        else:
+            # a tuple / list of axes (tf.math.reduce_min accepts one): adjacent axes are one reduced axis of the
+            # contiguous tensor; anything else is reduced after a permutation that makes them adjacent
+            axes = sorted({int(a) % X.dim() for a in axis})
+            if not axes:
+                raise ValueError("feature_scaling: empty axis tuple")
+            if axes != list(range(axes[0], axes[-1] + 1)):
+                keep = [d for d in range(X.dim()) if d not in axes]
+                perm = keep[:axes[0]] + axes + keep[axes[0]:]
+                inv = [perm.index(d) for d in range(X.dim())]
+                res = feature_scaling(X.permute(perm).contiguous(), min, max, axis=tuple(range(axes[0], axes[0] + len(axes))))
+                return res.permute(inv).contiguous()
+            outer, _, _ = _as_outer_r_inner(X, axes[0])
+            _, _, inner = _as_outer_r_inner(X, axes[-1])
+            R = 1
+            for a in axes:
+                R *= X.shape[a]
         if X.numel() == 0:
             return out
-        outer, R, inner = _as_outer_r_inner(X, axis)
         with torch.cuda.device(X.device):
             nv.check(nv.lib.lidbox_feature_scaling_axis_fwd(nv.ptr(X), outer, R, inner, float(min), float(max), nv.ptr(out),
                                                             nv.current_stream()))

@@ -223,8 +223,10 @@ class _Workspace:
         self.gemm_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.gemm_ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)     # wgrad side stream's own workspace
         # carried reduces (lidbox_hip.h: lidbox_reduce_job_t): a wgrad's slices wait in their workspace until a later GEMM
-        # launch has summed them, so consecutive wgrads alternate between two regions
-        self.tn_regions = (self.gemm_ws2, torch.empty(ws_bytes, dtype=torch.uint8, device=dev))
+        # launch has summed them, so consecutive wgrads alternate between two regions.  Both are buffers of their own: gemm_ws2
+        # belongs to the wgrad side streams (`_launch_wgrad`), which nothing orders against the main stream's carried slices
+        # until `join_wgrad` at the end of a stage
+        self.tn_regions = (torch.empty(ws_bytes, dtype=torch.uint8, device=dev), torch.empty(ws_bytes, dtype=torch.uint8, device=dev))
         self.pending = []                    # [(nv.ReduceJob, region index)], oldest first
 
     def select_input_buffer(self, parity):
@@ -342,9 +344,10 @@ class SequentialTDNN:
         self.state = torch.zeros(max(soff, 4), dtype=torch.float32, device=self.device)
         self._init_weights(seed)
         # bf16-storage GEMM path (LIDBOX_BF16_STORAGE=0 keeps the fp32-source bf16 kernels: A/B aid): bf16 weight shadows,
-        # refreshed from the fp32 master copy at the start of every forward pass -- `flat16` mirrors `flat` element for
-        # element (dgrad reads a Keras kernel [k*C_in, C_out] as the [N][K] operand it is), `w16t[i]` is conv i's kernel
-        # transposed to [C_out, k*C_in] (forward's [N][K] operand)
+        # refreshed from the fp32 master copy at the start of every forward pass -- `flat16` has the element layout of `flat`
+        # (dgrad reads a Keras kernel [k*C_in, C_out] as the [N][K] operand it is) but only the kernels listed in
+        # `_flat16_live` are refreshed (`_refresh_bf16_weights`); every other element stays zero and `_p16` refuses to hand
+        # it out.  `w16t[i]` is conv i's kernel transposed to [C_out, k*C_in] (forward's [N][K] operand)
         import os as _os
         self.bf16_storage = self.compute_dtype == "bfloat16" and _os.environ.get("LIDBOX_BF16_STORAGE", "1") != "0" \
             and attention is None and not self.frontend
@@ -482,12 +485,14 @@ class SequentialTDNN:
         mats = getattr(self, "_w16t_descs", None)
         if mats is None:
             items = []
+            live = self._flat16_live = set()          # parameters whose flat16 image is refreshed (what `_p16` may return)
             for i, c in enumerate(self.convs):
                 off, cin, co = self.layout[c.name + ".W"][0], self._cin(i), c.filters
                 if self.w16t[i] is not None:
                     items.append((off, c.k * cin, co, self.w16t[i].data_ptr(), c.k * cin, 1))
                 if i >= 1 and self.shadow_dgrad_ok(i) and not self.wd16[i]:
                     items.append((off, c.k * cin, co, self.flat16.data_ptr() + 2 * off, co, 0))       # read through _p16
+                    live.add(c.name + ".W")
                 for key, img in self.wd16[i].items():
                     if key == "fused":
                         items.append((off, c.k * cin, co, img.data_ptr(), img.shape[1], 0))
@@ -502,6 +507,9 @@ class SequentialTDNN:
         nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(self.flat), None, self.num_flat, mats, self._w16t_n, nv.current_stream()))
 
     def _p16(self, name):
+        """the bf16 image of parameter `name` inside flat16 -- only for the kernels `_refresh_bf16_weights` keeps current"""
+        if name not in getattr(self, "_flat16_live", ()):
+            raise RuntimeError("flat16 holds no refreshed image of %r (refreshed: %s)" % (name, sorted(getattr(self, "_flat16_live", ()))))
         off, _ = self.layout[name]
         return ctypes.c_void_p(self.flat16.data_ptr() + 2 * off)
 

@@ -64,18 +64,31 @@ class GradSync:
     10 us per step slower.)  On CPU (gloo, used by the CPU tests) the same calls apply.
     """
 
-    def __init__(self, flat, bucket_bounds, group=None):
+    def __init__(self, flat, bucket_bounds, group=None, wire_dtype=None):
         import torch.distributed as dist
         self.dist = dist
         self.flat, self.bounds, self.group = flat, list(bucket_bounds), group
         assert self.bounds[0] == 0 and self.bounds[-1] == flat.numel()
         assert all(a < b for a, b in zip(self.bounds, self.bounds[1:]))
+        # wire format of the exchange.  None / float32: the gradient buffer itself is all-reduced in place (18.2 MB per step for
+        # the 100-language x-vector).  "bfloat16": a bucket is rounded ONCE to a bf16 staging buffer (lidbox_f32_to_bf16), the
+        # staging buffer is all-reduced (half the bytes on the xGMI links: what the 1.3 ms bf16-compute step of configs[4]
+        # asks for), and widened back into the fp32 gradient buffer for Adam (lidbox_bf16_to_f32).  The sum over ranks is then
+        # formed in bf16 by the collective: ~3 significant digits per element, the precision of the bf16 backward that
+        # produced the gradients; fp32 master weights and Adam moments are untouched.
+        wire_dtype = {None: None, "float32": None, "bfloat16": torch.bfloat16, torch.float32: None,
+                      torch.bfloat16: torch.bfloat16}[wire_dtype]
+        if wire_dtype is not None and flat.dtype != torch.float32:
+            raise ValueError("a bfloat16 wire format needs a float32 gradient buffer")
+        self.wire_dtype = wire_dtype
+        self.wire = torch.zeros(flat.numel(), dtype=wire_dtype, device=flat.device) if wire_dtype is not None else None
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if os.environ.get("LIDBOX_FORCE_GRAD_SYNC") and dist.is_available() and dist.is_initialized():
             self.active = True           # test aid: exercise the collective path even at world_size 1
         self.world = dist.get_world_size(group) if self.active else 1
         self.cuda = flat.is_cuda
         self._pending = []
+        self.wait_events = None          # a list: `wait` appends (before, after) HIP events of the compute stream (bench.py)
         # RCCL collectives can be captured into a hipGraph (torch.distributed's nccl backend records them on its own
         # communication stream, forked from / joined to the capturing stream); gloo stages through the host and cannot
         self.capturable = bool(self.active and self.cuda and dist.get_backend(group) == "nccl")
@@ -94,14 +107,49 @@ class GradSync:
         """all-reduce bucket i; everything enqueued on the current stream so far is visible to it."""
         if not self.active:
             return
-        view = self.flat[self.bounds[i]:self.bounds[i + 1]]
-        self._pending.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        view = self.flat[lo:hi]
+        if self.wire is not None:
+            w = self.wire[lo:hi]
+            self._narrow(view, w)
+            self._pending.append((self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
+            return
+        self._pending.append((self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), lo, hi))
+
+    def _narrow(self, src32, dst16):
+        """fp32 -> wire format on the current stream (round-to-nearest-even); bucket bounds keep both 16-byte aligned"""
+        if self.cuda:
+            nv.check(nv.lib.lidbox_f32_to_bf16(nv.ptr(src32), nv.ptr(dst16), src32.numel(), nv.current_stream()))
+        else:
+            dst16.copy_(src32)                   # gloo on host tensors (CPU tests): torch's conversion rounds the same way
+
+    def _widen(self, src16, dst32):
+        if self.cuda:
+            nv.check(nv.lib.lidbox_bf16_to_f32(nv.ptr(src16), nv.ptr(dst32), src16.numel(), nv.current_stream()))
+        else:
+            dst32.copy_(src16)
 
     def wait(self):
         """make the reduced gradients visible to the compute stream (HIP) / the caller (CPU)"""
-        for work in self._pending:
+        ev = None
+        if self.wait_events is not None and self.cuda and self._pending:
+            # measurement aid (bench.py, eager steps only): HIP events on the compute stream around the joins.  The stream has
+            # nothing else to do between them, so their distance is the part of the exchange the backward did NOT hide
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for work, lo, hi in self._pending:
             work.wait()
+            if self.wire is not None:
+                self._widen(self.wire[lo:hi], self.flat[lo:hi])
+        if ev is not None:
+            ev[1].record()
+            self.wait_events.append(ev)
         self._pending.clear()
+
+    @property
+    def wire_bytes(self):
+        """bytes one rank hands to the collectives per step"""
+        return self.flat.numel() * (2 if self.wire is not None else self.flat.element_size())
 
     @property
     def grad_scale(self):
@@ -154,7 +202,7 @@ class Trainer:
 
     def __init__(self, model, loss="sparse_categorical_crossentropy", optimizer=None, feature=None,
                  use_graph=True, num_buckets=2, group=None, metric=None, overlap_wgrad=False, overlap_head_wgrad=False,
-                 sync_state_every_step=False):
+                 sync_state_every_step=False, grad_wire_dtype=None):
         self.model = model
         self.device = model.device
         opt = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
@@ -179,7 +227,8 @@ class Trainer:
         bounds, splits = plan_buckets(model, num_buckets)
         self.splits = [] if splits is None else ([splits] if isinstance(splits, int) else list(splits))   # ascending conv indices
         self.split_conv = self.splits[-1] if self.splits else None
-        self.sync = GradSync(model.flat_grad, bounds, group)
+        # grad_wire_dtype: "bfloat16" halves the bytes of the gradient exchange (GradSync); default: the fp32 buffer in place
+        self.sync = GradSync(model.flat_grad, bounds, group, wire_dtype=grad_wire_dtype)
         # overlap_wgrad: run wgrad GEMMs on a second stream concurrently with the dgrad chain.  Measured neutral
         # (96.1k vs 97.1k utt/s at bs 256): both are bound by the same matrix pipes.  Off by default.
         # fuse_output: the last Dense, log_softmax, the cross-entropy and their backward as two small launches when the model allows
@@ -540,6 +589,9 @@ class Trainer:
                 self.grad_sync_mode = "none"
         else:
             self.grad_sync_mode = "eager" if self.sync.active else "none"
+        # whether the CAPTURED backward carries the optimizer's prepare half: the eager Adam segment of the segmented form must
+        # follow what its own graphs do, not what the most recent trace (possibly another entry's warm-up) left in _prepared
+        entry["prepared"] = bool(getattr(self, "_prepared", False)) if entry["graphs"] is not None else None
         return entry
 
     # ---------------------------------------------------------------- public API
@@ -586,6 +638,8 @@ class Trainer:
                 self._graphs[key] = entry
             ws = entry["ws"]
             self._set_lr()
+            if entry["prepared"] is not None:
+                self._prepared = entry["prepared"]
             if entry["graphs"] is not None and len(entry["graphs"]) == 1:
                 entry["graphs"][0]()
             else:

@@ -170,6 +170,19 @@ _DP_WORKER = textwrap.dedent("""
     s2 = GradSync(flat2, [0, 250, n])
     s2.launch(1); s2.launch(0); s2.wait()
     assert float((flat2 - per2.mean(0)).abs().max()) < 1e-12
+    # bf16 wire format (Trainer(grad_wire_dtype="bfloat16")): every bucket is rounded once, summed as bf16 by the
+    # collective, widened back into the fp32 buffer -- exactly bf16(bf16(g0) + bf16(g1)), within 2^-7 of the fp32 sum
+    per3 = torch.randn(B, n, dtype=torch.float32)
+    mine = (per3[lo:hi].sum(0) / B).contiguous()
+    other = (torch.cat([per3[:lo], per3[hi:]]).sum(0) / B).contiguous()
+    flat3 = mine.clone()
+    s3 = GradSync(flat3, [0, 252, n], wire_dtype="bfloat16")
+    assert s3.wire_bytes == 2 * n and GradSync(flat3.clone(), [0, n]).wire_bytes == 4 * n
+    s3.launch(1); s3.launch(0); s3.wait()
+    expect3 = (mine.to(torch.bfloat16).float() + other.to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    assert flat3.dtype == torch.float32 and torch.equal(flat3, expect3)
+    ref3 = per3.mean(0)
+    assert float((flat3 - ref3).abs().max()) <= 2.0 ** -7 * float(ref3.abs().max()) + 1e-6
     # C_avg-style counters: all-reduce(sum) of integer-valued float counters is exact
     c = torch.full((7,), float(rank + 1))
     dist.all_reduce(c)

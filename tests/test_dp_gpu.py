@@ -36,6 +36,7 @@ _WORKER = textwrap.dedent("""
     use_graph = bool(int(sys.argv[1]))
     out_path = sys.argv[2]
     num_buckets = int(sys.argv[3])
+    wire = sys.argv[4] if len(sys.argv) > 4 else None
     os.environ["LOCAL_RANK"] = "0"                       # both ranks on the only GPU
     rank, world, _ = init_distributed(backend="gloo")
     torch.cuda.set_device(0)
@@ -46,8 +47,9 @@ _WORKER = textwrap.dedent("""
     yd = torch.from_numpy(y[lo:hi].astype(np.int32)).cuda()
     model = xvector.create((48, 40), 4, seed=0)
     plan = audio.get_plan(16000, 400, 160)
-    tr = Trainer(model, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=use_graph, num_buckets=num_buckets)
+    tr = Trainer(model, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=use_graph, num_buckets=num_buckets, grad_wire_dtype=wire)
     assert tr.sync.active == (world > 1) and tr.sync.num_buckets == num_buckets == tr.num_stages
+    assert tr.sync.wire_bytes == model.num_flat * (2 if wire == "bfloat16" else 4)
     losses = []
     for _ in range(3):
         losses.append(float(tr.train_step(sd, yd)))
@@ -80,13 +82,13 @@ def _free_port():
     return p
 
 
-def _run(script, world, use_graph, out, num_buckets=2):
+def _run(script, world, use_graph, out, num_buckets=2, wire=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script), str(int(use_graph)), str(out), str(num_buckets)], env=env,
+        procs.append(subprocess.Popen([sys.executable, str(script), str(int(use_graph)), str(out), str(num_buckets)] + ([wire] if wire else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for rank, p in enumerate(procs):
         try:
@@ -121,6 +123,22 @@ def test_two_rank_step_equals_single_process_step(tmp_path, use_graph, num_bucke
     assert np.abs(single["per_th"] - dual["per_th"]).max() <= 0.1
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_step_with_bf16_gradient_wire_tracks_the_fp32_exchange(tmp_path, use_graph):
+    """Trainer(grad_wire_dtype="bfloat16"): the buckets are rounded once (lidbox_f32_to_bf16), summed as bf16 by the collective and
+    widened back (lidbox_bf16_to_f32) -- half the bytes on the links.  Against the single-process fp32 step: the loss
+    trajectory stays within bf16's relative step, no weight moves by more than the steps' worth of +-lr."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    single = _run(script, 1, use_graph, tmp_path / "single.npz", 3)
+    dual = _run(script, 2, use_graph, tmp_path / "dual16.npz", 3, wire="bfloat16")
+    assert str(dual["grad_sync"]) == ("segmented" if use_graph else "eager")
+    assert np.allclose(single["losses"], dual["losses"], rtol=2e-2, atol=1e-4), (single["losses"], dual["losses"])
+    assert not np.array_equal(single["flat"], dual["flat"])              # the wire format did round something
+    diff = np.abs(single["flat"] - dual["flat"])
+    assert np.median(diff) <= 2e-4 and diff.max() <= 3 * 2e-3 + 1e-6, (np.median(diff), diff.max())
+
+
 def test_rccl_backend_between_graph_segments_world1():
     """The real RCCL backend (nccl) on the one GPU there is: world_size 1 with the collective path forced on,
     so init_process_group('nccl'), the side-stream all_reduce launches and the three-segment hipGraph replay are
@@ -141,6 +159,16 @@ def test_rccl_backend_between_graph_segments_world1():
     # error) and the line says which form the timed steps used
     assert r["config"]["grad_sync"] == "in_graph", r["config"]
     assert r["config"]["grad_buckets"] == 3 and r["config"]["allreduce_bytes_per_step"] == 4 * 4510176
+    assert r["config"]["allreduce_wire_dtype"] == "float32" and sum(r["config"]["allreduce_bucket_bytes"]) == 4 * 4510176
+    assert r["grad_sync_exposed_wait_us"]["steps"] == 8 and r["grad_sync_exposed_wait_us"]["median"] >= 0.0
+    assert r["sustained"]["steps"] >= 20 and r["sustained"]["value"] > 0
+    # the same with the bf16 wire format: half the bytes, still captured inside the step graph
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    p = subprocess.run(cmd + ["--grad-wire-dtype", "bfloat16", "--sustain-seconds", "0"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert r["config"]["grad_sync"] == "in_graph" and r["config"]["allreduce_bytes_per_step"] == 2 * 4510176
+    assert r["config"]["allreduce_wire_dtype"] == "bfloat16" and np.isfinite(r["config"]["final_loss"]) and "sustained" not in r
 
 
 def test_segmented_sync_is_refused_when_in_graph_is_required():
@@ -159,7 +187,7 @@ def test_bench_line_contract_single_process():
     """`python bench.py` (no launcher): one JSON line with the contract's keys, the roofline of the dominant GEMM
     instantiation from live HIP events and the feature kernel's HBM roofline"""
     import json
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--sustain-seconds", "1.0"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -184,6 +212,12 @@ def test_bench_line_contract_single_process():
     ff = r["roofline_feature"]
     assert ff["bound"] == "hbm" and ff["bytes_per_launch"] == 256 * 159680 and 0 < ff["frac"] < 1
     assert abs(r["value"] - 256 * 1e3 / r["ms_per_step"]) <= 1e-3 * r["value"]
+    # the sustained block (same captured steps, >= --sustain-seconds) and the label noise that keeps the loss off zero
+    su = r["sustained"]
+    assert su["seconds"] >= 1.0 and su["steps"] >= 20 and abs(su["value"] - 256 * 1e3 / su["ms_per_step"]) <= 1e-3 * su["value"]
+    assert 0.5 * r["value"] <= su["value"] <= 2.0 * r["value"]
+    assert r["config"]["label_noise"] == 0.35 and su["final_loss"] > 0.3 and r["config"]["first_loss"] > 0.3
+    assert all("sustained" in x and x["sustained"]["value"] > 0 for x in sec) and sec[0]["config"]["label_noise"] == 0.35
 
 
 def test_uneven_shards_equal_the_global_batch_step(tmp_path):

@@ -234,8 +234,17 @@ def test_feature_scaling_and_power_to_db():
     for axis in (1, 2):
         assert np.abs(F.feature_scaling(_dev(xw), 0.0, 1.0, axis=axis).cpu().numpy() - fo.feature_scaling(xw, 0.0, 1.0, axis=axis)).max() < 1e-5
     assert F.feature_scaling(torch.zeros(0, 5, 3, device="cuda"), 0.0, 1.0, axis=1).shape == (0, 5, 3)
-    with pytest.raises(NotImplementedError):
-        F.feature_scaling(_dev(x), 0.0, 1.0, axis=(1, 2))
+    # tuples of axes (tf.math.reduce_min takes them; reference features/__init__.py:7-8): adjacent and non-adjacent
+    for axes in ((1, 2), (0, 1), (0, 2), (0, 1, 2), (-1, 0)):
+        y = F.feature_scaling(_dev(x), -1.0, 3.0, axis=axes).cpu().numpy()
+        assert y.shape == x.shape and np.abs(y - fo.feature_scaling(x, -1.0, 3.0, axis=axes)).max() < 1e-5, axes
+    # more outer indices than one grid dimension holds (X[B*T, C] with axis=-1); NaN propagates like tf.reduce_min / max
+    xt = rng.normal(0, 2, size=(70000, 9)).astype(np.float32)
+    assert np.abs(F.feature_scaling(_dev(xt), 0.0, 1.0, axis=-1).cpu().numpy() - fo.feature_scaling(xt, 0.0, 1.0, axis=-1)).max() < 1e-5
+    xn = x.copy(); xn[1, 2, 3] = np.nan
+    yn = F.feature_scaling(_dev(xn), 0.0, 1.0, axis=1).cpu().numpy()
+    assert np.isnan(yn[1, :, 3]).all() and not np.isnan(np.delete(yn, 3, axis=2)).any()
+    assert np.isnan(F.feature_scaling(_dev(xn), 0.0, 1.0).cpu().numpy()).all()
     # audio.log10 (audio.py:162-164) on its own kernel
     p = np.abs(rng.standard_normal((5, 1000)).astype(np.float32)) + 1e-3
     got = audio.log10(_dev(p)).cpu().numpy()
@@ -302,6 +311,24 @@ def test_fused_path_other_mel_configurations(sr, mel):
             assert (np.abs(got - ref) / np.abs(ref).max()).max() <= 2e-5
         else:
             assert np.abs(got - ref).max() <= tol
+
+
+def test_wide_logmel_shape_with_plans_of_growing_lds():
+    """Several plans in one process through the persistent 14-wave log-mel workgroup (>= 4 tiles per CU), smallest LDS
+    footprint first: the kernel's dynamic-LDS limit is raised per device, not to the first caller's size, so a later plan
+    with more mel bins (more table + wave-slice bytes) still launches (features.hip LBX_LOGMEL)."""
+    from lidbox_amd.data import tf_utils
+    rng = np.random.default_rng(77)
+    sig = (rng.standard_normal((96, 16000)) * 0.1).astype(np.float32)          # 96 x 13 tiles = 1 248 tiles
+    for mel in (dict(num_mel_bins=24), dict(num_mel_bins=40), dict(num_mel_bins=64), dict(num_mel_bins=16, fmin=100.0, fmax=4000.0)):
+        ref = fo.extract_features(sig[:8], [16000] * 8, "logmelspectrogram", melspec_kwargs=mel)
+        got = tf_utils.extract_features(_dev(sig), [16000] * 96, "logmelspectrogram", melspec_kwargs=mel)
+        torch.cuda.synchronize()
+        assert got.shape == (96, 98, mel["num_mel_bins"])
+        assert np.abs(got[:8].cpu().numpy() - ref).max() <= LOGMEL_TOL, mel
+        # batch independence across the launch shapes: the 8-utterance call takes the 4-wave workgroups
+        small = tf_utils.extract_features(_dev(sig[:8]), [16000] * 8, "logmelspectrogram", melspec_kwargs=mel)
+        assert torch.equal(small, got[:8]), mel
 
 
 def test_concurrent_callers_on_one_plan_are_bit_identical():

@@ -217,3 +217,81 @@ def test_config5_bf16_step_time_smoke():
     ms = (time.perf_counter() - t0) / 20 * 1e3
     assert np.isfinite(loss) and np.isfinite(float(tr.train_step(sig, y)))
     assert ms < 6.0, "bf16 config-5 shard step took %.2f ms" % ms
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One whole step at bench.py's shapes against the float64 oracle ("next" item 6).  The small-batch oracle tests
+# (tests/test_model_gpu.py) never select the launches the production dispatch picks at these sizes -- stream-K forward and
+# wgrad, the eight-wave LDS-DMA tiles, pair launches, carried slice reduces, the fused softmax head, the 256-row bf16 tiles --
+# so here the CAPTURED train step itself (Trainer(use_graph=True).train_step, exactly what bench.py replays) is compared, in
+# one piece, with oracle/torch_ref.py evaluated in float64 on the host: loss + every gradient tensor.
+def _oracle_step64(config, w0, sig, y, num_langs):
+    """loss and gradients of the step's math in float64 (torch autograd on the host; features from oracle/features_np)"""
+    import os
+    from oracle import features_np as fo
+    from oracle import torch_ref as tref
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    sr = [SR] * sig.shape[0]
+    if config == 3:      # MFCC(1:13) + CMVN, reference tf_utils.py:180-185, features/__init__.py:22-32
+        x = fo.cmvn(fo.extract_features(sig, sr, "mfcc"), axis=1)
+    else:
+        x = fo.extract_features(sig, sr, "logmelspectrogram")
+    x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+    p = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in w0.items()}
+    yt = torch.from_numpy(y.astype(np.int64))
+    if config == 3:
+        loss = tref.sparse_ce_from_logits(tref.cnn_fwd(p, x), yt)                      # cnn.py:25-45 + keras_utils.py:141-147
+    elif config == 4:
+        z = torch.nn.functional.normalize(tref.xvector_fwd(p, x, embedding=True), dim=1)
+        loss = tref.ap_loss(yt, z, num_langs)                                          # losses.py:25-49
+    else:
+        loss = tref.sparse_ce_from_logits(tref.xvector_fwd(p, x), yt)                  # xvector.py:46-67
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("config", [1, 3, 4])
+def test_whole_captured_step_at_bench_shape_matches_float64_oracle(config):
+    from lidbox_amd import _native as nv
+    from lidbox_amd.features import audio
+    from lidbox_amd.losses import SparseAngularProximity
+    from lidbox_amd.models import cnn, xvector
+    from lidbox_amd.models.tdnn import DenseSpec, SequentialTDNN
+    from lidbox_amd.train import Trainer
+    plan = audio.get_plan(SR, 400, 160)
+    if config == 1:        # BASELINE configs[1]: log-mel + x-vector, 4 languages, bs 256, fp32
+        B, langs, bf16 = 256, 4, False
+        m = xvector.create((T, MEL), langs, seed=0)
+        tr = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=True)
+    elif config == 3:      # configs[3]: MFCC + CMVN + cnn, bs 256, fp32
+        B, langs, bf16 = 256, 4, False
+        m = cnn.create((T, 12), langs, seed=0)
+        tr = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_MFCC, cmvn=True), use_graph=True)
+    else:                  # configs[4], one GPU's shard: x-vector trunk + AP loss, 100 languages, bs 512, bf16 compute
+        B, langs, bf16 = 512, 100, True
+        convs = [xvector.frame_layer(512, 5, 1, name="frame1"), xvector.frame_layer(512, 3, 2, name="frame2"),
+                 xvector.frame_layer(512, 3, 3, name="frame3"), xvector.frame_layer(512, 1, 1, name="frame4"),
+                 xvector.frame_layer(1500, 1, 1, name="frame5")]
+        m = SequentialTDNN((T, MEL), convs, "stats", [DenseSpec("segment1", 512, relu=False)], output_activation=None, seed=0,
+                           compute_dtype="bfloat16")
+        tr = Trainer(m, loss=SparseAngularProximity(langs, 512), feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=True)
+    # non-zero biases so that every bias path carries signal (the initialiser gives zeros)
+    rng = np.random.default_rng(11)
+    m.set_weights({k: rng.standard_normal(v.shape) * 0.05 for k, v in m.get_weights().items() if k.endswith(".b")})
+    w0 = {k: v.copy() for k, v in m.get_weights().items()}
+    sig, y = _batch(B, langs=langs, seed=4321)
+    loss = float(tr.train_step(sig, y))              # eager warm-up pass (no optimizer), capture, ONE replay: gradients of w0
+    assert tr.step_count == 1 and tr.grad_sync_mode == "none"
+    got = {k: m.param(k, grad=True).cpu().numpy() for k in w0}
+    ref_loss, ref_g = _oracle_step64(config, w0, sig.cpu().numpy(), y.cpu().numpy(), langs)
+    if not bf16:
+        # the tolerances of tests/test_model_gpu.py::test_xvector_loss_and_gradients_match_oracle
+        assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
+        for name, g in ref_g.items():
+            assert np.abs(got[name] - g).max() <= 1e-3 * np.abs(g).max(), name
+    else:
+        # the tolerances of tests/test_bf16_model_gpu.py::test_bf16_loss_and_gradients_close_to_float64_oracle
+        assert abs(loss - ref_loss) <= 2e-2 * abs(ref_loss), (loss, ref_loss)
+        for name, g in ref_g.items():
+            rel = np.linalg.norm(got[name] - g) / max(np.linalg.norm(g), 1e-30)
+            assert rel <= 5e-2, (name, rel)
