@@ -466,18 +466,25 @@ def timed_steps(trainer, batches, warmup, steps, sync_all, prefetch=False):
     return time.perf_counter() - t0, first_loss, float(loss)
 
 
-def sustained_steps(trainer, batches, start, seconds, est_ms, sync_all, prefetch=False):
-    """the same captured steps for >= `seconds` (step count fixed up front from the timed region's rate, so that every rank
-    runs the same number): (elapsed s, steps, last loss)"""
+def sustained_steps(trainer, batches, start, seconds, est_ms, sync_all, prefetch=False, agree=None):
+    """the same captured steps for >= `seconds`: chunks of a step count fixed from the timed region's rate, each between
+    barrier + synchronize pairs, until their times add up to `seconds`.  agree(t) -> the max over ranks of a chunk's time, so
+    that every rank runs the same number of chunks.  Returns (elapsed s, steps, last loss)."""
     n = len(batches)
-    steps = max(20, int(np.ceil(1e3 * seconds / max(est_ms, 1e-3))))
+    chunk = max(20, int(np.ceil(1e3 * seconds / max(est_ms, 1e-3))))
     nxt = (lambda i: dict(next_inputs=batches[(i + 1) % n][0])) if prefetch else (lambda i: {})
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = trainer.train_step(*batches[(start + i) % n], **nxt(start + i))
-    sync_all()
-    return time.perf_counter() - t0, steps, float(loss)
+    elapsed, steps = 0.0, 0
+    while elapsed < seconds and steps < 100 * chunk:
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(chunk):
+            loss = trainer.train_step(*batches[(start + steps + i) % n], **nxt(start + steps + i))
+        sync_all()
+        dt = time.perf_counter() - t0
+        elapsed += agree(dt) if agree is not None else dt
+        steps += chunk
+        chunk = max(20, int(np.ceil(chunk * max(0.05, (seconds - elapsed) / max(dt, 1e-6)) * 1.05)))
+    return elapsed, steps, float(loss)
 
 
 def exposed_wait(w, trainer, batch, dev, world, nsteps=8):
@@ -644,12 +651,14 @@ def main():
     # the same replayed steps for >= --sustain-seconds (outside the timed region; max over ranks like the headline)
     sustained = None
     if args.sustain_seconds > 0:
-        s_el, s_n, s_loss = sustained_steps(trainer, batches, args.warmup + args.steps, args.sustain_seconds, ms_per_step, sync_all,
-                                            prefetch=args.prefetch)
-        if world > 1:
-            t = torch.tensor([s_el], dtype=torch.float64, device=dev)
+        def agree(dt):
+            if world == 1:
+                return dt
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            s_el = float(t.item())
+            return float(t.item())
+        s_el, s_n, s_loss = sustained_steps(trainer, batches, args.warmup + args.steps, args.sustain_seconds, ms_per_step, sync_all,
+                                            prefetch=args.prefetch, agree=agree)
         if not np.isfinite(s_loss):
             raise SystemExit("non-finite loss %r in the sustained block" % s_loss)
         sustained = {"value": round(global_B * s_n / s_el, 1), "ms_per_step": round(1e3 * s_el / s_n, 4), "steps": s_n,

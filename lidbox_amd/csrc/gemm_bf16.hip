@@ -43,6 +43,9 @@
 // of 4, row/batch strides multiples of 4 -- true of every layer of the x-vector / CNN models.
 // Roofline: MFMA bf16 dense, 2.5 PFLOP/s (MI355X_MICROARCH.md); practical bound = L2->LDS traffic.
 #include <string.h>
+
+#include <atomic>
+
 #include "gemm_shared.h"
 
 namespace {
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
 
 }  // namespace
 #include "gemm16_dma.h"
+#include "gemm16_pp.h"
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -981,7 +985,9 @@ Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes) {
     int bm = 0, bn = 0, stg = 0, sp = 0;
     if (const char* e = getenv("LIDBOX_GEMM16S_DMA")) {
         if (sscanf(e, "%d,%d,%d,%d", &bm, &bn, &stg, &sp) < 3) return c;
-        if (!((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && stg >= 2 && stg <= 4)) return c;
+        // bm == 256: the eight-wave ping-pong tile (gemm16_pp.h); its third number is SUB (1 | 2), not a ring depth
+        const bool pp = bm == 256 && (bn == 128 || bn == 256) && (stg == 1 || stg == 2);
+        if (!pp && !((bm == 64 || bm == 128) && (bn == 64 || bn == 128) && stg >= 2 && stg <= 4)) return c;
     } else {
         // (round 3's table: profiles/r03_bf16_dma_variants.txt -- deeper rings lose: the launches are latency-, not bandwidth-bound,
         // and every stage costs a resident workgroup)
@@ -1043,11 +1049,50 @@ int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh
     return LIDBOX_OK;
 }
 
+// the eight-wave ping-pong tile (gemm16_pp.h): dc.bm == 256, dc.stages = SUB
+template <int BN, int SUB, int PA0, int PB0>
+int launch_rows16s_pp_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M,
+                        int K, int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
+    constexpr size_t lds_bytes = (size_t)2 * (256 + BN) * D16_ROW_BYTES;
+    static std::atomic<unsigned long long> attr_devs{0};
+    int dev = 0;
+    LBX_HIP(hipGetDevice(&dev));
+    if (dev >= 64 || !(attr_devs.load() >> dev & 1ull)) {
+        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_pp_kernel<BN, SUB, PA0, PB0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));
+        if (dev < 64) attr_devs.fetch_or(1ull << dev);
+    }
+    const int tiles_n = (int)lbx_cdiv((long)N, (long)BN);
+    const long ntiles = lbx_cdiv(M, 256L) * tiles_n;
+    hipLaunchKernelGGL((gemm16s_rows_pp_kernel<BN, SUB, PA0, PB0>), dim3((unsigned)ntiles + rj.total, (unsigned)dc.splits), dim3(512), lds_bytes, st,
+                       Ah, Bh, Co, S, P, 0L, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, dc.k_per_split, mask16, rj);
+    LBX_LAUNCH_OK();
+    if (dc.splits > 1) {
+        long g = lbx_cdiv(M * N, 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(rows_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)P, dc.splits, 0L, M, N, Co, epi, aux, S,
+                           mask16);
+        LBX_LAUNCH_OK();
+    }
+    return LIDBOX_OK;
+}
+
 thread_local int g16_last_carried = 0;                 // jobs the calling thread's last lidbox_gemm_bf16s_nt_carry ran inside its GEMM launch
 thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the calling thread's last lidbox_gemm_bf16s_nt (0: register-staged)
 
 int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
                        int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
+    if (dc.bm == 256) {
+        // LIDBOX_GEMM16S_PP_SPLIT: how many of a wave pair's pieces group 0 issues (tuning aid): 0 = even, 1 = 3/4 (default), 2 = all
+        static const int psplit = getenv("LIDBOX_GEMM16S_PP_SPLIT") ? atoi(getenv("LIDBOX_GEMM16S_PP_SPLIT")) : 1;
+#define LBX_PP(BN_, SUB_, PA0_, PB0_) \
+        return launch_rows16s_pp_t<BN_, SUB_, PA0_, PB0_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj)
+        if (dc.bn == 256 && dc.stages == 1) { if (psplit == 0) LBX_PP(256, 1, 4, 4); if (psplit == 2) LBX_PP(256, 1, 8, 8); LBX_PP(256, 1, 6, 6); }
+        if (dc.bn == 256 && dc.stages == 2) { if (psplit == 0) LBX_PP(256, 2, 4, 4); if (psplit == 2) LBX_PP(256, 2, 8, 8); LBX_PP(256, 2, 6, 6); }
+        if (dc.bn == 128 && dc.stages == 1) { if (psplit == 0) LBX_PP(128, 1, 4, 2); if (psplit == 2) LBX_PP(128, 1, 8, 4); LBX_PP(128, 1, 6, 3); }
+        if (dc.bn == 128 && dc.stages == 2) { if (psplit == 0) LBX_PP(128, 2, 4, 2); if (psplit == 2) LBX_PP(128, 2, 8, 4); LBX_PP(128, 2, 6, 3); }
+#undef LBX_PP
+    }
 #define LBX_D16(BM_, BN_, ST_, OCC_) \
     if (dc.bm == BM_ && dc.bn == BN_ && dc.stages == ST_) return launch_rows16s_dma_t<BM_, BN_, ST_, OCC_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj)
     LBX_D16(64, 64, 2, 5);

@@ -216,7 +216,7 @@ def test_bench_line_contract_single_process():
     su = r["sustained"]
     assert su["seconds"] >= 1.0 and su["steps"] >= 20 and abs(su["value"] - 256 * 1e3 / su["ms_per_step"]) <= 1e-3 * su["value"]
     assert 0.5 * r["value"] <= su["value"] <= 2.0 * r["value"]
-    assert r["config"]["label_noise"] == 0.35 and su["final_loss"] > 0.3 and r["config"]["first_loss"] > 0.3
+    assert r["config"]["label_noise"] == 0.35 and r["config"]["final_loss"] > 0.3 and r["config"]["first_loss"] > 0.3
     assert all("sustained" in x and x["sustained"]["value"] > 0 for x in sec) and sec[0]["config"]["label_noise"] == 0.35
 
 

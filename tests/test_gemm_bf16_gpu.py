@@ -203,14 +203,16 @@ def test_bf16_gemm_tail_split_matches_single_launch(M, K, N):
     assert np.all(got[:, :3, :] == 7.0)
 
 
-@pytest.mark.parametrize("variant", [None, "64,64,2", "64,64,3", "128,64,2", "64,128,2", "128,128,2", "128,128,3"])
+@pytest.mark.parametrize("variant", [None, "64,64,2", "64,64,3", "128,64,2", "64,128,2", "128,128,2", "128,128,3",
+                                     "256,256,2", "256,256,1", "256,128,2", "256,128,1"])
 @pytest.mark.parametrize("M,K,N", [(128, 32, 128), (200, 200, 512), (33, 1536, 512), (1000, 264, 40), (5, 8, 8),
                                    (256, 3000, 512), (700, 512, 1024), (1, 8, 4), (50688 // 8, 200, 512)])
 def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N, variant, monkeypatch):
     """lidbox_gemm_bf16s_nt: operands already bf16 in HBM ([M][K] and [N][K]); same numbers as the fp32-source kernel on the
     unrounded originals; the bf16 shadow of C equals bf16(C); split-K, epilogues, converters.
     variant: None = the library's own choice (small problems: the register-staged 128 x 128 kernel), "bm,bn,stages" = that
-    instantiation of the LDS-DMA kernel (csrc/gemm16_dma.h; K tails of 8 .. 56 past a 64-deep step, ragged M / N edges)"""
+    instantiation of the LDS-DMA kernel (csrc/gemm16_dma.h; K tails of 8 .. 56 past a 64-deep step, ragged M / N edges);
+    "256,bn,sub" = the eight-wave ping-pong tile (csrc/gemm16_pp.h)"""
     from lidbox_amd import _native as nv
     if variant is not None:
         monkeypatch.setenv("LIDBOX_GEMM16S_DMA", variant)

@@ -4,7 +4,9 @@ keep it), bf16 ReLU mask on the dgrads.  One process per variant (the override i
 attributes are set once).  usage: python tools/bf16s_variants.py [B=256]  ->  table of us per call (medians of 7 x 5)"""
 import os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = ["policy", "0", "64,64,2", "64,128,2", "128,64,2", "128,128,2", "64,128,3"]
+VARIANTS = ["policy", "64,128,2", "128,128,2", "256,256,2", "256,256,1", "256,128,2", "256,128,1"]
+if os.environ.get("BF16S_VARIANTS"):
+    VARIANTS = os.environ["BF16S_VARIANTS"].split(";")
 if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     sys.path.insert(0, ROOT)
     import torch
