@@ -236,7 +236,9 @@ class KernelTimer:
                 elif self.ENTRY[_n] in (13, 15):
                     out3 = (ctypes.c_int * 3)()
                     self.nv.check(self.nv.lib.lidbox_gemm_bf16s_last_variant(out3))
-                    if out3[0]:
+                    if out3[0] == 256:     # the eight-wave ping-pong tile (gemm16_pp.h): <BN, SUB>
+                        key = "gemm16s_rows_pp_kernel<%d, %d>" % (out3[1], out3[2])
+                    elif out3[0]:
                         key = "gemm16s_rows_dma_kernel<%d, %d, %d>" % (out3[0], out3[1], out3[2])
                 self.records.setdefault(key, []).append((e0, e1, work, nk))
                 return rc

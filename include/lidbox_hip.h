@@ -498,6 +498,12 @@ int lidbox_l2_normalize_bwd(const float* x, const float* dout, int B, int D, flo
 int lidbox_ap_loss_fwd_bwd(const float* z, const int32_t* labels, int B, int D, int N,
                            float delta_weight, float scale, float* loss_per_example, float* dz,
                            lidbox_stream_t stream);
+/* The angular-proximity head of a train step in one launch (D <= 4096): zn = l2_normalize(x) (may be NULL), the per-example loss
+ * of lidbox_ap_loss_fwd_bwd on zn, dx (may be NULL) = the loss gradient taken back through the normalisation
+ * (lidbox_l2_normalize_bwd), scores (may be NULL) [B,N] = -acos(zn[:, :N]) (SparseAngularProximity.predict, losses.py:51-52).
+ * Bit-identical to the four separate calls.  Replaces: lidbox/losses.py:25-52 behind an L2-normalised output (ap_lstm.py:42). */
+int lidbox_ap_head_fwd_bwd(const float* x, const int32_t* labels, int B, int D, int N, float delta_weight, float scale,
+                           float* zn, float* loss_per_example, float* dx, float* scores, lidbox_stream_t stream);
 
 /* lidbox/metrics.py:51-71 AverageDetectionCost.update_state with sparse labels: counters
  * tp, fn [N,Th]; fp_pairs, tn_pairs [N,N,Th] (float32, accumulated in place). */

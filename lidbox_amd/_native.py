@@ -137,6 +137,7 @@ _SIGS = {
     "lidbox_l2_normalize_fwd": (_i, [_vp, _i, _i, _vp, _vp]),
     "lidbox_l2_normalize_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "lidbox_ap_loss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "lidbox_ap_head_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "lidbox_cavg_update": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "lidbox_cavg_result": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),

@@ -29,35 +29,50 @@
 
 namespace {
 
-// this wave's NPC pieces (8 rows x 128 B each) of one operand, pieces first .. first + NPC - 1 of the tile's rows
+// this wave's NPC pieces (8 rows x 128 B each = one wave DMA instruction = 1 KB of LDS) of one operand: pieces first ..
+// first + NPC - 1 of the operand's tile rows; piece p lands at p * 1024 of the operand's stage
 template <int NPC>
 struct PpPieces {
     const float* sb;                        // wave-uniform byte base (+ k of the next step to issue)
-    unsigned vo[NPC > 0 ? NPC : 1];         // this lane's byte offsets: row offset + swizzled chunk
-    int kq;
+    unsigned vo[NPC];                       // this lane's byte offsets: row offset + swizzled chunk
+    unsigned kqs;                           // 3 bits per piece: the chunk this lane fetches
+    int p0;
 
     __device__ __forceinline__ void init(const RowsH& X, long row0, long nrows, int kbeg, int lane, int first) {
+        static_assert(NPC <= 10, "kqs holds ten pieces");
         sb = sk_uniform(reinterpret_cast<const float*>(X.base + kbeg));
-        const int chunk = (lane & 7) ^ (lane >> 3);
-        kq = chunk * 8;
+        kqs = 0;
+        p0 = first;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
-            long r = row0 + 8 * (first + i) + (lane >> 3);
+            const int trow = 8 * (first + i) + (lane >> 3);            // row inside the tile = LDS row
+            const int chunk = (lane & 7) ^ d16_swz(trow);
+            kqs |= (unsigned)chunk << (3 * i);
+            long r = row0 + trow;
             if (r >= nrows) r = row0;
             vo[i] = (unsigned)((row_offset(X, (unsigned)r) + chunk * 8) * 2);
         }
     }
-    __device__ __forceinline__ void issue(int i, unsigned dst) const { sk_dma_s(sb, vo[i], dst); }
-    __device__ __forceinline__ void issue_tail(int i, unsigned dst, int kvalid) const {
-        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
-        sk_dma_f(kq < kvalid ? p : g_sk_zero, dst);
+    // every piece of the current step into the operand stage at LDS byte address `stage_lds`, then on to the next step;
+    // kvalid < 64: the K range's last, partial step (chunks at or past kvalid come from the zero source)
+    __device__ __forceinline__ void issue_step(unsigned stage_lds, int kvalid) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const unsigned dst = stage_lds + (unsigned)(p0 + i) * 1024u;
+            if (kvalid < D16_BK) {
+                const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(sb) + vo[i]);
+                sk_dma_f((int)((kqs >> (3 * i)) & 7u) * 8 < kvalid ? p : g_sk_zero, dst);
+            } else {
+                sk_dma_s(sb, vo[i], dst);
+            }
+        }
+        sb += D16_ROW_BYTES / 4;
     }
-    __device__ __forceinline__ void advance() { sb += D16_ROW_BYTES / 4; }
 };
 
 // operand registers of block b (32 rows from `row`) for k slice ks (16 k): lane -> row lane & 31, k 16 ks + 8 (lane >> 5) ..+7
 __device__ __forceinline__ bf16x8 pp_read(const char* op, int row, int lane, int b, int ks) {
-    const int pos = (2 * ks + (lane >> 5)) ^ (lane & 7);
+    const int pos = (2 * ks + (lane >> 5)) ^ d16_swz(lane & 31);       // row and b * 32 are multiples of 32: the key is the lane's
     return *reinterpret_cast<const bf16x8*>(op + (row + b * 32 + (lane & 31)) * D16_ROW_BYTES + pos * 16);
 }
 
@@ -66,14 +81,215 @@ __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ void pp_loop_barrier();
 __device__ __forceinline__ void pp_wait_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+#ifndef LBX_PP_ABLATE
+#define LBX_PP_ABLATE 0
+#endif
+__device__ __forceinline__ void pp_loop_barrier() {
+    if (LBX_PP_ABLATE & 8) __builtin_amdgcn_sched_barrier(0);
+    else pp_barrier();
+}
+
+// Epilogue of one wave's MI x NJ accumulator blocks through a wave-private LDS strip: a 32-row x (32 NJ)-column strip is
+// written in the accumulator layout (lane = column), read back row-wise -- a lane then holds 8 consecutive columns of one row
+// -- and leaves as 16-byte stores (two for the fp32 value, one for the bf16 shadow), the mask / old values arrive as 16-byte
+// loads.  Why: with one workgroup per CU nothing overlaps the epilogue, and gemm_shared.h's store_rows_tile issues one 2- or
+// 4-byte access per lane and element (128 + 128 store instructions per wave of a 128 x 64 tile: store-issue bound, measured
+// ~30 us of a launch); here it is 16 + 32.  Same arithmetic per element, in the same order, as store_rows_tile:
+// x = acc + bias; mask; + old; ReLU.  Vector accesses need 16-byte aligned bases and row / batch strides that are multiples
+// of 8 elements (true of every buffer of the model; anything else takes the element-wise path below, wave-uniformly).
+constexpr int PP_EPI_LDW = 68;                                   // floats per strip row: 64 + 4 (conflict-free both ways)
+constexpr int PP_EPI_BYTES = 32 * PP_EPI_LDW * 4;                // 8 704 bytes per wave
+
+template <int MI, int NJ>
+__device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float* __restrict__ wlds, long mrow0, int ncol0, int lane, long m_beg,
+                                              long M, int N, int epi, const float* __restrict__ aux, const RowsOutD& Cd, float* __restrict__ P,
+                                              int split, unsigned short* __restrict__ shadow, const unsigned short* __restrict__ mask16) {
+    static_assert(NJ == 2, "pp_store_tile: 64-column strips");
+    const int h = lane >> 5, l = lane & 31;
+    const bool partial = gridDim.y > 1;
+    const bool has_bias = !partial && (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU);
+    const bool do_relu = !partial && (epi == LIDBOX_EPI_BIAS_RELU || epi == LIDBOX_EPI_ACCUM_RELU || epi == LIDBOX_EPI_RELU);
+    const bool has_mask = !partial && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    const bool accum = !partial && (epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU);
+    float bias[NJ];
+#pragma unroll
+    for (int bj = 0; bj < NJ; ++bj) {
+        const int c = ncol0 + bj * 32 + l;
+        bias[bj] = (has_bias && c < N) ? aux[c] : 0.f;
+    }
+    float* const out_base = partial ? P + ((long)split * (M - m_beg) - m_beg) * N : Cd.base;    // P[split][row - m_beg][n]
+    unsigned short* const sh = partial ? nullptr : shadow;
+    const bool batched = !partial && Cd.batch != 1;
+    const long rs = partial ? (long)N : Cd.rs;
+    // wave-uniform: may the fp32 / bf16 arrays laid out like C be accessed 16 bytes (4 floats / 8 bf16) at a time
+    const bool str8 = rs % 8 == 0 && (!batched || Cd.bs % 8 == 0);
+    const bool v32 = str8 && (((uintptr_t)out_base) & 15) == 0 && (!(has_mask && !mask16) || (((uintptr_t)aux) & 15) == 0);
+    const bool v16 = str8 && (((uintptr_t)sh) & 15) == 0 && (((uintptr_t)mask16) & 15) == 0;
+    const bool vec = v32 && v16;
+#pragma unroll
+    for (int bi = 0; bi < MI; ++bi) {
+#pragma unroll
+        for (int bj = 0; bj < NJ; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wlds[((r & 3) + 8 * (r >> 2) + 4 * h) * PP_EPI_LDW + bj * 32 + l] = acc[bi][bj][r] + bias[bj];
+        wave_lds_sync();
+        // INNER (wave-uniform): the strip lies wholly inside the matrix and vector accesses apply -- no per-lane predicates, and the
+        // four chunks of a lane go in batches (offsets, then every mask / old-value load, then the arithmetic, then the stores):
+        // chunk by chunk, a mask epilogue is sixteen dependent round trips to memory per wave with nothing else on the CU to hide them
+        if (vec && mrow0 + bi * 32 + 32 <= M && ncol0 + 64 <= N) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {               // two chunks per batch: the temporaries of four do not fit beside 128 accumulators
+            long off[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long R = mrow0 + bi * 32 + (lane >> 3) + 8 * (2 * half + i);
+                off[i] = (partial ? R * (long)N : row_offset(Cd, (unsigned)R)) + ncol0 + (lane & 7) * 8;
+            }
+            u32x4_t mk[2];
+            f32x4 ma[2], mb[2], oa[2], ob[2];
+            if (has_mask) {
+                if (mask16) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) mk[i] = *reinterpret_cast<const u32x4_t*>(mask16 + off[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ma[i] = *reinterpret_cast<const f32x4*>(aux + off[i]);
+                        mb[i] = *reinterpret_cast<const f32x4*>(aux + off[i] + 4);
+                    }
+                }
+            }
+            if (accum) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    oa[i] = *reinterpret_cast<const f32x4*>(out_base + off[i]);
+                    ob[i] = *reinterpret_cast<const f32x4*>(out_base + off[i] + 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = wlds + ((lane >> 3) + 8 * (2 * half + i)) * PP_EPI_LDW + (lane & 7) * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+                float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (has_mask) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float mvj = mask16 ? __builtin_bit_cast(float, (j & 1) ? (mk[i][j >> 1] & 0xffff0000u) : (mk[i][j >> 1] << 16))
+                                                 : (j < 4 ? ma[i][j & 3] : mb[i][j & 3]);
+                        x[j] = mvj > 0.f ? x[j] : 0.f;
+                    }
+                }
+                if (accum) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += j < 4 ? oa[i][j & 3] : ob[i][j & 3];
+                }
+                if (do_relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                }
+                if (out_base) {
+                    *reinterpret_cast<f32x4*>(out_base + off[i]) = f32x4{x[0], x[1], x[2], x[3]};
+                    *reinterpret_cast<f32x4*>(out_base + off[i] + 4) = f32x4{x[4], x[5], x[6], x[7]};
+                }
+                if (sh) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[j];
+                    *reinterpret_cast<bf16x8*>(sh + off[i]) = o;
+                }
+            }
+          }
+            wave_lds_sync();
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i, row = c >> 3, cc = c & 7;
+            const long R = mrow0 + bi * 32 + row;
+            const int col = ncol0 + cc * 8;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + row * PP_EPI_LDW + cc * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + row * PP_EPI_LDW + cc * 8 + 4);
+            float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (R >= M || col >= N) continue;
+            const long off = (partial ? R * (long)N : row_offset(Cd, (unsigned)R)) + col;
+            if (vec && col + 8 <= N) {
+                if (has_mask) {
+                    if (mask16) {
+                        const u32x4_t mk = *reinterpret_cast<const u32x4_t*>(mask16 + off);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {          // sign and zero-ness are all that is looked at: bits << 16 is the value
+                            const float mvj = __builtin_bit_cast(float, (j & 1) ? (mk[j >> 1] & 0xffff0000u) : (mk[j >> 1] << 16));
+                            x[j] = mvj > 0.f ? x[j] : 0.f;
+                        }
+                    } else {
+                        const f32x4 m0v = *reinterpret_cast<const f32x4*>(aux + off), m1v = *reinterpret_cast<const f32x4*>(aux + off + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            x[j] = m0v[j] > 0.f ? x[j] : 0.f;
+                            x[4 + j] = m1v[j] > 0.f ? x[4 + j] : 0.f;
+                        }
+                    }
+                }
+                if (accum) {
+                    const f32x4 o0 = *reinterpret_cast<const f32x4*>(out_base + off), o1 = *reinterpret_cast<const f32x4*>(out_base + off + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[j] += o0[j];
+                        x[4 + j] += o1[j];
+                    }
+                }
+                if (do_relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                }
+                if (out_base) {
+                    *reinterpret_cast<f32x4*>(out_base + off) = f32x4{x[0], x[1], x[2], x[3]};
+                    *reinterpret_cast<f32x4*>(out_base + off + 4) = f32x4{x[4], x[5], x[6], x[7]};
+                }
+                if (sh) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[j];
+                    *reinterpret_cast<bf16x8*>(sh + off) = o;
+                }
+            } else {
+                for (int j = 0; j < 8 && col + j < N; ++j) {
+                    float v = x[j];
+                    if (has_mask) {
+                        const float mvj = mask16 ? __builtin_bit_cast(float, (unsigned)mask16[off + j] << 16) : aux[off + j];
+                        v = mvj > 0.f ? v : 0.f;
+                    }
+                    if (accum) v += out_base[off + j];
+                    if (do_relu) v = fmaxf(v, 0.f);
+                    if (out_base) out_base[off + j] = v;
+                    if (sh) sh[off + j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 // C[M,N] = epi(A[M,K] . B[N,K]^T), bf16 operands, fp32 accumulate; 512 threads, tile 256 x BN (BN = 256: waves 2 x 4, 128 x 64
 // each; BN = 128: waves 4 x 2, 64 x 64 each); grid.x = [carried reduce blocks] + tiles (XCD-chunk remapped), grid.y = K splits.
-// PA0 / PB0: A / B pieces a group-0 wave issues per step (group 1 takes the rest: its pieces have one phase less to land).
-template <int BN, int SUB, int PA0, int PB0>
+// LDS: an A ring of THREE stages (3 x 32 KB) and a B ring of two (2 x BN x 128 B): 160 KB at BN = 256, the whole CU.
+// LBX_PP_ABLATE (measurement builds only, results are wrong): 1 = no LDS-DMA issue after the prologue, 2 = operand fetches of the
+// first sub-step only, 4 = no MFMAs, 8 = no barriers inside the loop, 16 = no epilogue, 32 = no DMA at all (with 1)
+#ifndef LBX_PP_ABLATE
+#define LBX_PP_ABLATE 0
+#endif
+
+template <int BN>
+constexpr int pp_lds_bytes() {
+    return 3 * 256 * D16_ROW_BYTES + 2 * BN * D16_ROW_BYTES;
+}
+
+template <int BN, int SUB>
 __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
                                                                   float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
                                                                   const float* __restrict__ aux, int tiles_n, unsigned ntiles,
@@ -85,16 +301,15 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
     constexpr int BM = 256;
     constexpr int WN = BN / 64, WM = 8 / WN;                  // waves along N / M
     constexpr int MI = BM / WM / 32, NJ = 2;                  // 32 x 32 blocks per wave
-    constexpr int A_ST = BM * D16_ROW_BYTES, ST = (BM + BN) * D16_ROW_BYTES;
-    constexpr int TA = BM / 8, TB = BN / 8;                   // pieces per stage
-    constexpr int PA1 = TA / 4 - PA0, PB1 = TB / 4 - PB0;
-    static_assert(PA1 >= 0 && PB1 >= 0 && (SUB == 1 || SUB == 2), "piece split");
+    constexpr int A_ST = BM * D16_ROW_BYTES, B_ST = BN * D16_ROW_BYTES, B_RING = 3 * A_ST;
+    constexpr int NA = BM / 64, NB = BN / 64;                 // DMA pieces per wave and step: 4 of A, 4 | 2 of B
+    static_assert(SUB == 1 || SUB == 2, "sub-steps");
     constexpr int KH = 4 / SUB;                               // k slices (16 k) per sub-step
     extern __shared__ __attribute__((aligned(16))) char smem16p[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wv >> 2, q = wv & 3;
+    const int grp = wv >> 2;
     const int wm = wv / WN, wn = wv % WN;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem16p);
     const unsigned chunk = xcd_chunk_id(blockIdx.x - rj.total, ntiles);
@@ -106,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
     const int kend = min(K, kbeg + k_per_split);
     const int n = (kend - kbeg + D16_BK - 1) / D16_BK;
     const int ktail = kend - kbeg - (n - 1) * D16_BK;          // valid k of the last step: 8 .. 64
-    const int rowA = wm * (BM / WM), rowB = wn * 64;           // this wave's first row inside the A / B part of a stage
+    const int rowA = wm * (BM / WM), rowB = wn * 64;           // this wave's first row inside an A / B stage
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -116,44 +331,60 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    PpPieces<NA> pa;
+    PpPieces<NB> pb;
+    pa.init(A, m0, M, kbeg, lane, wv * NA);
+    pb.init(Bw, n0, N, kbeg, lane, wv * NB);
+    // A of step `step` into A stage step % 3, B of step `step` into B stage step & 1 (the lists advance with every issue: A runs
+    // two steps ahead of the step being computed, B one)
+    auto issue_a = [&](int step, int sa) {
+        if ((LBX_PP_ABLATE & 32) || ((LBX_PP_ABLATE & 1) && step > 1)) return;
+        pa.issue_step(lds0 + (unsigned)(sa * A_ST), step == n - 1 ? ktail : D16_BK);
+    };
+    auto issue_b = [&](int step, int sb) {
+        if ((LBX_PP_ABLATE & 32) || ((LBX_PP_ABLATE & 1) && step > 0)) return;
+        pb.issue_step(lds0 + (unsigned)(B_RING + sb * B_ST), step == n - 1 ? ktail : D16_BK);
+    };
+
     auto body = [&](auto grp_tag) {
         constexpr int G = decltype(grp_tag)::value;
-        constexpr int NA = G == 0 ? PA0 : PA1, NB = G == 0 ? PB0 : PB1;
-        PpPieces<NA> pa;
-        PpPieces<NB> pb;
-        const int fa = G == 0 ? q * PA0 : 4 * PA0 + q * PA1, fb = G == 0 ? q * PB0 : 4 * PB0 + q * PB1;
-        pa.init(A, m0, M, kbeg, lane, fa);
-        pb.init(Bw, n0, N, kbeg, lane, fb);
-        // this wave's pieces of step `step` into stage `stage`
-        auto issue = [&](int step, int stage) {
-            const bool tail = step == n - 1 && ktail < D16_BK;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const unsigned d = lds0 + (unsigned)(stage * ST + (fa + i) * 1024);
-                if (tail) pa.issue_tail(i, d, ktail);
-                else pa.issue(i, d);
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const unsigned d = lds0 + (unsigned)(stage * ST + A_ST + (fb + i) * 1024);
-                if (tail) pb.issue_tail(i, d, ktail);
-                else pb.issue(i, d);
-            }
-            pa.advance();
-            pb.advance();
-        };
         bf16x8 a[MI][KH], b[NJ][KH];
-        auto load = [&](int stage, int j) {
-            const char* st = smem16p + stage * ST;
+        bool first_load = true;
+        auto load = [&](int sa, int sb, int j) {
+            if (LBX_PP_ABLATE & 2) {
+                if (!first_load) {
+#pragma unroll
+                    for (int kk = 0; kk < KH; ++kk) {
+#pragma unroll
+                        for (int bj = 0; bj < NJ; ++bj) asm volatile("" : "+v"(b[bj][kk]));
+#pragma unroll
+                        for (int bi = 0; bi < MI; ++bi) asm volatile("" : "+v"(a[bi][kk]));
+                    }
+                    return;
+                }
+                first_load = false;
+            }
+            const char* sta = smem16p + sa * A_ST;
+            const char* stb = smem16p + B_RING + sb * B_ST;
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk) {
 #pragma unroll
-                for (int bj = 0; bj < NJ; ++bj) b[bj][kk] = pp_read(st + A_ST, rowB, lane, bj, j * KH + kk);
+                for (int bj = 0; bj < NJ; ++bj) b[bj][kk] = pp_read(stb, rowB, lane, bj, j * KH + kk);
 #pragma unroll
-                for (int bi = 0; bi < MI; ++bi) a[bi][kk] = pp_read(st, rowA, lane, bi, j * KH + kk);
+                for (int bi = 0; bi < MI; ++bi) a[bi][kk] = pp_read(sta, rowA, lane, bi, j * KH + kk);
             }
         };
         auto comp = [&]() {
+            if (LBX_PP_ABLATE & 4) {
+#pragma unroll
+                for (int kk = 0; kk < KH; ++kk) {
+#pragma unroll
+                    for (int bj = 0; bj < NJ; ++bj) asm volatile("" ::"v"(b[bj][kk]));
+#pragma unroll
+                    for (int bi = 0; bi < MI; ++bi) asm volatile("" ::"v"(a[bi][kk]));
+                }
+                return;
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk)
@@ -164,40 +395,68 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
                         acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[bi][kk], b[bj][kk], acc[bi][bj], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
-        // step 0 into stage 0: every wave its pieces, then the first hand-off
-        issue(0, 0);
-        sk_wait_vm<0>();
+        // prologue: A(0), B(0), then A(1), which stays in flight across the first hand-off
+        issue_a(0, 0);
+        issue_b(0, 0);
+        if (n > 1) {
+            issue_a(1, 1);
+            sk_wait_vm<NA>();
+        } else {
+            sk_wait_vm<0>();
+        }
         pp_barrier();
         if (G == 1) pp_barrier();                              // phase 0 belongs to group 0 alone
-        int cur = 0;
+        int sa = 0, sb = 0;                                    // A / B stages of the step being computed
         for (int t = 0; t < n; ++t) {
-            const bool more = t + 1 < n;
+            const bool more_b = t + 1 < n, more_a = t + 2 < n;
+            int sa2 = sa + 2;
+            if (sa2 >= 3) sa2 -= 3;
 #pragma unroll
             for (int j = 0; j < SUB; ++j) {
-                if (j == 0 && more) issue(t + 1, cur ^ 1);
-                load(cur, j);
+                load(sa, sb, j);                               // operand fetches first: they complete under the DMA issues
+                // B(t + 1) in the step's first LOAD phase (its stage was read last in the phase before), A(t + 2) in the last one
+                // (no deadline until two steps on): every LOAD phase of either group carries its share of the DMA traffic
+                if (j == 0 && more_b) issue_b(t + 1, sb ^ 1);
+                if (j == SUB - 1 && more_a) issue_a(t + 2, sa2);
                 pp_wait_lds();
-                if (G == 1 && j == SUB - 1 && more) sk_wait_vm<0>();
-                pp_barrier();
+                if (G == 1 && j == SUB - 1 && more_b) {        // step t + 1's operands: everything but the A pieces just issued
+                    if (more_a) sk_wait_vm<NA>();
+                    else sk_wait_vm<0>();
+                }
+                pp_loop_barrier();
                 comp();
                 if (G == 0) {
-                    if (j == SUB - 1 && more) sk_wait_vm<0>();
-                    pp_barrier();
-                } else if (!(j == SUB - 1 && !more)) {
-                    pp_barrier();
+                    if (j == SUB - 1 && more_b) {
+                        if (more_a) sk_wait_vm<NA>();
+                        else sk_wait_vm<0>();
+                    }
+                    pp_loop_barrier();
+                } else if (!(j == SUB - 1 && !more_b)) {
+                    pp_loop_barrier();
                 }
             }
-            cur ^= 1;
+            sa = sa + 1 == 3 ? 0 : sa + 1;
+            sb ^= 1;
         }
     };
     if (grp == 0) body(IntTag<0>{});
     else body(IntTag<1>{});
 
-    // epilogue: the wave's tile as 64-row halves (store_rows_tile addresses rows as m0 + wm * 64 + block * 32)
+    // epilogue through this wave's LDS strip: no wave reads a stage any more once group 0 has passed the last barrier (group
+    // 1's last sub-step runs from registers), and no DMA is in flight
+    if (LBX_PP_ABLATE & 16) {                                  // no epilogue: one store per wave keeps the accumulators alive
+        float sacc = 0.f;
 #pragma unroll
-    for (int hh = 0; hh < MI / 2; ++hh)
-        store_rows_tile<2, NJ, true>(reinterpret_cast<const f32x16(&)[2][NJ]>(acc[2 * hh]), m0 + rowA + 64 * hh, n0, 0, wn, lane, m_beg, M, N, epi,
-                                     aux, Cd, P, split, 0ull, false, C16, mask16);
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.f) P[tid] = sacc;
+        return;
+    }
+    pp_store_tile<MI, NJ>(acc, reinterpret_cast<float*>(smem16p + wv * PP_EPI_BYTES), m0 + rowA, n0 + rowB, lane, m_beg, M, N, epi, aux, Cd, P,
+                          split, C16, mask16);
 }
 
 }  // namespace

@@ -1000,6 +1000,20 @@ Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes) {
         // 3 x 256 slots just over once (792 tiles: 1.03 rounds) runs a nearly empty second round -- 64 x 64 tiles win there by
         // 10-15 % (128 x 128 for K >= 1536) -- and launches of less than half a round of 128 x 128 tiles, which round 3 left on
         // the register-staged kernel, take 64 x 64 tiles split along K (bs 64: 14.7 / 7.5 / 16.5 / 9.4 us against 26 / 24 / 26 / 24).
+        // Round 5: the eight-wave ping-pong tile (gemm16_pp.h, 256 x 256, one workgroup per CU).  tools/bf16s_variants.py at bs 256 /
+        // 512 (profiles/r05_bf16_pp_variants.txt): it wins wherever its tiles fill >= 3/4 of the CUs in every round and the
+        // contraction is >= 512 deep -- frame2 forward 59 -> 49 us / 122 -> 98 us, frame2's dgrads 56 + 37 -> 38 + 27 us, frame3's
+        // dgrad 38 -> 27 us -- and for K >= 1500 from half a round on (bs 512: frame5 dgrad 55 -> 48 us); it loses on short
+        // contractions (frame1: K = 200, four steps under a 256 x 256 epilogue) and on launches of a quarter round (M = 8 448).
+        const long t256 = lbx_cdiv(M, 256L) * lbx_cdiv((long)N, 256L);
+        const long r256 = lbx_cdiv(t256, (long)NUM_CU);
+        static const bool no_pp = getenv("LIDBOX_GEMM16S_NO_PP") != nullptr;          // A/B aid
+        if (!no_pp && ((K >= 512 && 4 * t256 >= 3 * r256 * NUM_CU) || (K >= 1500 && 2 * t256 >= r256 * NUM_CU))) {
+            c.bm = 256; c.bn = 256; c.stages = 2;
+            c.splits = 1;
+            c.k_per_split = (int)(lbx_cdiv((long)K, (long)D16_BK) * D16_BK);
+            return c;
+        }
         const long t128 = lbx_cdiv(M, 128L) * lbx_cdiv((long)N, 128L);
         const long t64x128 = lbx_cdiv(M, 64L) * lbx_cdiv((long)N, 128L);
         const bool just_over_a_round = t64x128 > 3 * NUM_CU && 10 * t64x128 <= 12 * 3 * NUM_CU;
@@ -1050,21 +1064,21 @@ int launch_rows16s_dma_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh
 }
 
 // the eight-wave ping-pong tile (gemm16_pp.h): dc.bm == 256, dc.stages = SUB
-template <int BN, int SUB, int PA0, int PB0>
+template <int BN, int SUB>
 int launch_rows16s_pp_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M,
                         int K, int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
-    constexpr size_t lds_bytes = (size_t)2 * (256 + BN) * D16_ROW_BYTES;
+    constexpr size_t lds_bytes = (size_t)pp_lds_bytes<BN>();
     static std::atomic<unsigned long long> attr_devs{0};
     int dev = 0;
     LBX_HIP(hipGetDevice(&dev));
     if (dev >= 64 || !(attr_devs.load() >> dev & 1ull)) {
-        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_pp_kernel<BN, SUB, PA0, PB0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_pp_kernel<BN, SUB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
         if (dev < 64) attr_devs.fetch_or(1ull << dev);
     }
     const int tiles_n = (int)lbx_cdiv((long)N, (long)BN);
     const long ntiles = lbx_cdiv(M, 256L) * tiles_n;
-    hipLaunchKernelGGL((gemm16s_rows_pp_kernel<BN, SUB, PA0, PB0>), dim3((unsigned)ntiles + rj.total, (unsigned)dc.splits), dim3(512), lds_bytes, st,
+    hipLaunchKernelGGL((gemm16s_rows_pp_kernel<BN, SUB>), dim3((unsigned)ntiles + rj.total, (unsigned)dc.splits), dim3(512), lds_bytes, st,
                        Ah, Bh, Co, S, P, 0L, M, K, N, epi, aux, tiles_n, (unsigned)ntiles, dc.k_per_split, mask16, rj);
     LBX_LAUNCH_OK();
     if (dc.splits > 1) {
@@ -1083,15 +1097,10 @@ thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the
 int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
                        int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
     if (dc.bm == 256) {
-        // LIDBOX_GEMM16S_PP_SPLIT: how many of a wave pair's pieces group 0 issues (tuning aid): 0 = even, 1 = 3/4 (default), 2 = all
-        static const int psplit = getenv("LIDBOX_GEMM16S_PP_SPLIT") ? atoi(getenv("LIDBOX_GEMM16S_PP_SPLIT")) : 1;
-#define LBX_PP(BN_, SUB_, PA0_, PB0_) \
-        return launch_rows16s_pp_t<BN_, SUB_, PA0_, PB0_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj)
-        if (dc.bn == 256 && dc.stages == 1) { if (psplit == 0) LBX_PP(256, 1, 4, 4); if (psplit == 2) LBX_PP(256, 1, 8, 8); LBX_PP(256, 1, 6, 6); }
-        if (dc.bn == 256 && dc.stages == 2) { if (psplit == 0) LBX_PP(256, 2, 4, 4); if (psplit == 2) LBX_PP(256, 2, 8, 8); LBX_PP(256, 2, 6, 6); }
-        if (dc.bn == 128 && dc.stages == 1) { if (psplit == 0) LBX_PP(128, 1, 4, 2); if (psplit == 2) LBX_PP(128, 1, 8, 4); LBX_PP(128, 1, 6, 3); }
-        if (dc.bn == 128 && dc.stages == 2) { if (psplit == 0) LBX_PP(128, 2, 4, 2); if (psplit == 2) LBX_PP(128, 2, 8, 4); LBX_PP(128, 2, 6, 3); }
-#undef LBX_PP
+        if (dc.bn == 256 && dc.stages == 2) return launch_rows16s_pp_t<256, 2>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj);
+        if (dc.bn == 256 && dc.stages == 1) return launch_rows16s_pp_t<256, 1>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj);
+        if (dc.bn == 128 && dc.stages == 2) return launch_rows16s_pp_t<128, 2>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj);
+        if (dc.bn == 128 && dc.stages == 1) return launch_rows16s_pp_t<128, 1>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj);
     }
 #define LBX_D16(BM_, BN_, ST_, OCC_) \
     if (dc.bm == BM_ && dc.bn == BN_ && dc.stages == ST_) return launch_rows16s_dma_t<BM_, BN_, ST_, OCC_>(dc, Ah, Bh, Co, S, P, M, K, N, epi, aux, mask16, st, rj)

@@ -610,6 +610,69 @@ __global__ __launch_bounds__(256) void ap_loss_kernel(const float* __restrict__ 
         for (int d = N + lane; d < D; d += 64) dz[(long)row * D + d] = 0.f;
 }
 
+// The angular-proximity head of a train step in ONE launch, one wave per example (D <= AP_HEAD_MAX_D): L2 normalisation
+// (tf.math.l2_normalize, what ap_lstm.py:42 puts in front of the loss), SparseAngularProximity.call (losses.py:25-40) with its
+// gradient, the gradient through the normalisation, and the scores predict() hands to the metrics (losses.py:51-52).  Every
+// value is computed by the expressions, in the order, of l2norm_fwd_kernel -> ap_loss_kernel -> l2norm_bwd_kernel ->
+// neg_acos_kernel (the separate entry points stay: the API leaves use them) -- bit-identical results, four launches fewer.
+constexpr int AP_HEAD_MAX_D = 4096;
+__global__ __launch_bounds__(256) void ap_head_kernel(const float* __restrict__ x, const int32_t* __restrict__ labels, int B, int D, int N,
+                                                      float delta, float scale, float* __restrict__ zn_out, float* __restrict__ loss,
+                                                      float* __restrict__ dx, float* __restrict__ scores) {
+    extern __shared__ float s_ap[];               // [4 waves][2][D]: the wave's normalised row and its gradient
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float* zr = s_ap + (threadIdx.x >> 6) * 2 * D;
+    float* gz = zr + D;
+    const float* xr = x + (long)row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(xr[d], xr[d], s);
+    s = wave_sum(s);
+    const float inv = rsqrtf(fmaxf(s, L2_EPS));
+    for (int d = lane; d < D; d += 64) {
+        const float z = xr[d] * inv;
+        zr[d] = z;
+        gz[d] = 0.f;
+        if (zn_out) zn_out[(long)row * D + d] = z;
+    }
+    wave_lds_sync();
+    if (scores)
+        for (int n = lane; n < N; n += 64) scores[(long)row * N + n] = -acosf(zr[n]);
+    const int y = labels[row];
+    if (y < 0 || y >= N) {                                 // label outside the N language vectors: NaN loss, zero gradient row
+        if (lane == 0) loss[row] = NAN;
+    } else {
+        const float th_y = acosf(zr[y]);
+        float L = 0.f, dsum = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            if (n == y) continue;
+            const float zv = zr[n];
+            const float th = acosf(zv);
+            const float sg = 1.f / (1.f + expf(-delta * (th_y - th)));
+            L += sg;
+            const float ds = delta * sg * (1.f - sg);
+            dsum += ds;
+            gz[n] = ds * rsqrtf(fmaxf(1.f - zv * zv, AP_ACOS_CLAMP)) * scale;
+        }
+        L = wave_sum(L);
+        dsum = wave_sum(dsum);
+        if (lane == 0) {
+            loss[row] = L;
+            const float zv = zr[y];
+            gz[y] = -dsum * rsqrtf(fmaxf(1.f - zv * zv, AP_ACOS_CLAMP)) * scale;
+        }
+    }
+    wave_lds_sync();
+    if (dx) {
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot = fmaf(xr[d], gz[d], dot);
+        dot = wave_sum(dot);
+        const bool clipped = s < L2_EPS;
+        const float k = clipped ? 0.f : dot * inv * inv * inv;
+        for (int d = lane; d < D; d += 64) dx[(long)row * D + d] = gz[d] * inv - xr[d] * k;
+    }
+}
+
 // C_avg counters (reference metrics.py:51-71).  grid (N scored classes m, ceil(Th / 64)); 256 threads = 4 waves x 64 thresholds.
 // LDS pos[wave][l][th] counts the examples with label l whose score for class m is >= threshold: every wave takes every
 // fourth block of 64 examples, loads their scores and labels with ONE load per lane and walks them through v_readlane
@@ -989,6 +1052,19 @@ extern "C" int lidbox_ap_loss_fwd_bwd(const float* z, const int32_t* labels, int
     if (B == 0) return LIDBOX_OK;
     hipLaunchKernelGGL(ap_loss_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream,
                        z, labels, B, D, N, delta_weight, scale, loss_per_example, dz);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_ap_head_fwd_bwd(const float* x, const int32_t* labels, int B, int D, int N, float delta_weight, float scale,
+                                      float* zn, float* loss_per_example, float* dx, float* scores, lidbox_stream_t stream) {
+    LBX_ARG(x && labels && loss_per_example, "x, labels, loss != NULL");
+    LBX_ARG(N >= 1 && D >= N, "N >= 1 and D >= N (losses.py:14-15)");
+    LBX_ARG(delta_weight > 0.f, "delta_weight > 0 (losses.py:16)");
+    LBX_ARG(D <= AP_HEAD_MAX_D, "D <= 4096 (wider rows: the separate entry points)");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(ap_head_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), (size_t)8 * D * sizeof(float), (hipStream_t)stream, x, labels,
+                       B, D, N, delta_weight, scale, zn, loss_per_example, dx, scores);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -333,13 +333,20 @@ class Trainer:
         else:
             D = out.shape[1]
             zn, dzn, per = self._ap_buffers(ws, D)
-            nv.check(lib.lidbox_l2_normalize_fwd(nv.ptr(out), B, D, nv.ptr(zn), st))
-            nv.check(lib.lidbox_ap_loss_fwd_bwd(nv.ptr(zn), nv.ptr(labels), B, D, self.ap.N, self.ap.delta_weight,
-                                                scale, nv.ptr(per), nv.ptr(dzn), st))
-            nv.check(lib.lidbox_l2_normalize_bwd(nv.ptr(out), nv.ptr(dzn), B, D, nv.ptr(ws.dh[-1]), st))
+            want_scores = self.metric is not None and not self._warming
+            if D <= 4096 and not os.environ.get("LIDBOX_AP_SEPARATE"):
+                # normalise -> loss + gradient -> gradient through the normalisation -> predict() scores: one launch
+                nv.check(lib.lidbox_ap_head_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, D, self.ap.N, self.ap.delta_weight, scale, None,
+                                                    nv.ptr(per), nv.ptr(ws.dh[-1]), nv.ptr(ws.ap_scores) if want_scores else None, st))
+            else:
+                nv.check(lib.lidbox_l2_normalize_fwd(nv.ptr(out), B, D, nv.ptr(zn), st))
+                nv.check(lib.lidbox_ap_loss_fwd_bwd(nv.ptr(zn), nv.ptr(labels), B, D, self.ap.N, self.ap.delta_weight,
+                                                    scale, nv.ptr(per), nv.ptr(dzn), st))
+                nv.check(lib.lidbox_l2_normalize_bwd(nv.ptr(out), nv.ptr(dzn), B, D, nv.ptr(ws.dh[-1]), st))
+                if want_scores:
+                    nv.check(lib.lidbox_neg_acos(nv.ptr(zn), B, D, self.ap.N, nv.ptr(ws.ap_scores), st))
             nv.check(lib.lidbox_mean(nv.ptr(per), B, nv.ptr(ws.loss), st))
-            if self.metric is not None and not self._warming:
-                nv.check(lib.lidbox_neg_acos(nv.ptr(zn), B, D, self.ap.N, nv.ptr(ws.ap_scores), st))
+            if want_scores:
                 self.metric._update_sparse(labels, ws.ap_scores)
         if self.loss_kind == "nll" and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)

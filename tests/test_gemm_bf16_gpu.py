@@ -460,12 +460,13 @@ def test_bf16_storage_gemm_shadow_only_output_and_bf16_mask(M, K, N):
                                              nv.EPI_BIAS | nv.EPI_MASK_BF16, nv.ptr(mask16), None, 0, st))
 
 
-@pytest.mark.parametrize("M,K,N,want", [(8448, 512, 512, [64, 128, 2]), (8448, 512, 1536, [64, 128, 2]), (25344, 1024, 512, [64, 128, 2]),
-                                         (25344, 1536, 512, [128, 128, 2])])
+@pytest.mark.parametrize("M,K,N,want", [(8448, 512, 512, [64, 128, 2]), (8448, 512, 1536, [256, 256, 2]), (25344, 1024, 512, [256, 256, 2]),
+                                         (25344, 1536, 512, [256, 256, 2]), (50688, 200, 512, [64, 128, 2]), (16896, 1504, 512, [256, 256, 2])])
 def test_bf16_storage_gemm_policy_at_layer_sizes(M, K, N, want):
     """x-vector layer shapes at bs 256: which kernel lidbox_gemm_bf16s_nt picks on its own (csrc/gemm_bf16.hip:
-    choose_dma16 -- 64 x 128 LDS-DMA tiles, except the longest contraction on a full chip: 128 x 128) and that the product is
-    the bf16-operand product whichever it is"""
+    choose_dma16 -- the eight-wave 256 x 256 ping-pong tile where its tiles fill three quarters of the CUs and K >= 512, or half
+    of them and K >= 1500; 64 x 128 LDS-DMA tiles for quarter rounds and short contractions) and that the product is the
+    bf16-operand product whichever it is"""
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(K + N)
     A, B = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((N, K)).astype(np.float32)

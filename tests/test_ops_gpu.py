@@ -291,6 +291,45 @@ def test_ap_loss_known_answers_and_grad():
         SparseAngularProximity(5, 8, delta_weight=0.0)
 
 
+def test_ap_head_one_launch_equals_the_four_separate_calls():
+    """lidbox_ap_head_fwd_bwd (what the train step runs for the angular-proximity loss): normalised rows, per-example loss,
+    gradient through the normalisation and predict() scores, bit for bit what lidbox_l2_normalize_fwd -> lidbox_ap_loss_fwd_bwd
+    -> lidbox_l2_normalize_bwd -> lidbox_neg_acos give; against the float64 oracle as well; an out-of-range label gives a NaN
+    loss and a zero gradient row in both forms"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(21)
+    st = nv.current_stream()
+    for B, D, N, delta in ((37, 512, 100, 1.0), (5, 40, 17, 1.7), (64, 100, 100, 0.5), (3, 4096, 3, 2.0)):
+        x = rng.standard_normal((B, D)).astype(np.float32)
+        y = rng.integers(0, N, size=B).astype(np.int32)
+        if B > 4:
+            y[2] = N + 3                                               # invalid label
+        xd, yd = _dev(x), _dev(y, np.int32)
+        zn, dzn, dx = torch.zeros_like(xd), torch.zeros_like(xd), torch.zeros_like(xd)
+        per, sc = torch.zeros(B, device="cuda"), torch.zeros((B, N), device="cuda")
+        nv.check(nv.lib.lidbox_l2_normalize_fwd(nv.ptr(xd), B, D, nv.ptr(zn), st))
+        nv.check(nv.lib.lidbox_ap_loss_fwd_bwd(nv.ptr(zn), nv.ptr(yd), B, D, N, delta, 1.0 / B, nv.ptr(per), nv.ptr(dzn), st))
+        nv.check(nv.lib.lidbox_l2_normalize_bwd(nv.ptr(xd), nv.ptr(dzn), B, D, nv.ptr(dx), st))
+        nv.check(nv.lib.lidbox_neg_acos(nv.ptr(zn), B, D, N, nv.ptr(sc), st))
+        zn2, dx2 = torch.full_like(xd, 7.0), torch.full_like(xd, 7.0)
+        per2, sc2 = torch.full((B,), 7.0, device="cuda"), torch.full((B, N), 7.0, device="cuda")
+        nv.check(nv.lib.lidbox_ap_head_fwd_bwd(nv.ptr(xd), nv.ptr(yd), B, D, N, delta, 1.0 / B, nv.ptr(zn2), nv.ptr(per2), nv.ptr(dx2), nv.ptr(sc2), st))
+        assert torch.equal(zn2, zn) and torch.equal(dx2, dx) and torch.equal(sc2, sc)
+        assert torch.equal(torch.nan_to_num(per2, nan=-1.0), torch.nan_to_num(per, nan=-1.0))
+        ok = y < N
+        assert bool(torch.isnan(per2[torch.from_numpy(~ok).cuda()]).all()) and float(dx2[torch.from_numpy(~ok).cuda()].abs().sum()) == 0.0
+        # float64 oracle on the valid rows: loss per example and the gradient with respect to the un-normalised rows (autograd)
+        xt = torch.tensor(x[ok].astype(np.float64), requires_grad=True)
+        from oracle import torch_ref as tref
+        z64 = torch.nn.functional.normalize(xt, dim=1)
+        assert np.abs(per2.cpu().numpy()[ok] - mo.ap_loss_per_example(y[ok], z64.detach().numpy(), N, delta)).max() < 1e-4
+        (tref.ap_loss(torch.from_numpy(y[ok].astype(np.int64)), z64, N, delta) * ok.sum() / B).backward()
+        _close(dx2.cpu().numpy()[ok], xt.grad.numpy(), 1e-4)
+        # optional outputs may be NULL
+        nv.check(nv.lib.lidbox_ap_head_fwd_bwd(nv.ptr(xd), nv.ptr(yd), B, D, N, delta, 1.0 / B, None, nv.ptr(per2), None, None, st))
+    assert nv.lib.lidbox_ap_head_fwd_bwd(nv.ptr(xd), nv.ptr(yd), 3, 8192, 3, 1.0, 1.0, None, nv.ptr(per2), None, None, st) == -1   # D > 4096
+
+
 def test_l2_normalize():
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(14)
