@@ -100,8 +100,9 @@ __device__ __forceinline__ void pp_loop_barrier() {
 // loads.  Why: with one workgroup per CU nothing overlaps the epilogue, and gemm_shared.h's store_rows_tile issues one 2- or
 // 4-byte access per lane and element (128 + 128 store instructions per wave of a 128 x 64 tile: store-issue bound, measured
 // ~30 us of a launch); here it is 16 + 32.  Same arithmetic per element, in the same order, as store_rows_tile:
-// x = acc + bias; mask; + old; ReLU.  Vector accesses need 16-byte aligned bases and row / batch strides that are multiples
-// of 8 elements (true of every buffer of the model; anything else takes the element-wise path below, wave-uniformly).
+// x = acc + bias; mask; + old; ReLU.  Vector accesses need 16-byte aligned fp32 / 8-byte aligned bf16 bases and row / batch
+// strides that are multiples of 4 elements (true of every buffer of the model; anything else takes the element-wise path
+// below, wave-uniformly).
 constexpr int PP_EPI_LDW = 68;                                   // floats per strip row: 64 + 4 (conflict-free both ways)
 constexpr int PP_EPI_BYTES = 32 * PP_EPI_LDW * 4;                // 8 704 bytes per wave
 
@@ -126,11 +127,31 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
     unsigned short* const sh = partial ? nullptr : shadow;
     const bool batched = !partial && Cd.batch != 1;
     const long rs = partial ? (long)N : Cd.rs;
-    // wave-uniform: may the fp32 / bf16 arrays laid out like C be accessed 16 bytes (4 floats / 8 bf16) at a time
-    const bool str8 = rs % 8 == 0 && (!batched || Cd.bs % 8 == 0);
-    const bool v32 = str8 && (((uintptr_t)out_base) & 15) == 0 && (!(has_mask && !mask16) || (((uintptr_t)aux) & 15) == 0);
-    const bool v16 = str8 && (((uintptr_t)sh) & 15) == 0 && (((uintptr_t)mask16) & 15) == 0;
+    // wave-uniform: may the arrays laid out like C be accessed in vectors?  Row / batch strides that are multiples of 4 elements
+    // put every 8-column chunk on a 16-byte boundary of the fp32 arrays and an 8-byte boundary of the bf16 ones (frame5's 1 500
+    // channels: 6 000- / 3 000-byte rows); multiples of 8 elements make the bf16 chunks 16-byte accesses too.
+    const bool str4 = rs % 4 == 0 && (!batched || Cd.bs % 4 == 0);
+    const bool v32 = str4 && (((uintptr_t)out_base) & 15) == 0 && (!(has_mask && !mask16) || (((uintptr_t)aux) & 15) == 0);
+    const bool v16 = str4 && (((uintptr_t)sh) & 7) == 0 && (((uintptr_t)mask16) & 7) == 0;
     const bool vec = v32 && v16;
+    const bool w16 = rs % 8 == 0 && (!batched || Cd.bs % 8 == 0) && (((uintptr_t)sh) & 15) == 0 && (((uintptr_t)mask16) & 15) == 0;   // 16-byte bf16 accesses
+    auto ld16 = [&](const unsigned short* p) -> u32x4_t {           // 8 bf16 at an 8-byte (w16: 16-byte) aligned address
+        if (w16) return *reinterpret_cast<const u32x4_t*>(p);
+        const uint2 a = *reinterpret_cast<const uint2*>(p), b = *reinterpret_cast<const uint2*>(p + 4);
+        return u32x4_t{a.x, a.y, b.x, b.y};
+    };
+    auto st16 = [&](unsigned short* p, const float (&x)[8]) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[j];
+        if (w16) {
+            *reinterpret_cast<bf16x8*>(p) = o;
+        } else {
+            const u32x4_t u = __builtin_bit_cast(u32x4_t, o);
+            *reinterpret_cast<uint2*>(p) = make_uint2(u[0], u[1]);
+            *reinterpret_cast<uint2*>(p + 4) = make_uint2(u[2], u[3]);
+        }
+    };
 #pragma unroll
     for (int bi = 0; bi < MI; ++bi) {
 #pragma unroll
@@ -155,7 +176,7 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
             if (has_mask) {
                 if (mask16) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) mk[i] = *reinterpret_cast<const u32x4_t*>(mask16 + off[i]);
+                    for (int i = 0; i < 2; ++i) mk[i] = ld16(mask16 + off[i]);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -196,12 +217,7 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
                     *reinterpret_cast<f32x4*>(out_base + off[i]) = f32x4{x[0], x[1], x[2], x[3]};
                     *reinterpret_cast<f32x4*>(out_base + off[i] + 4) = f32x4{x[4], x[5], x[6], x[7]};
                 }
-                if (sh) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[j];
-                    *reinterpret_cast<bf16x8*>(sh + off[i]) = o;
-                }
+                if (sh) st16(sh + off[i], x);
             }
           }
             wave_lds_sync();
@@ -220,7 +236,7 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
             if (vec && col + 8 <= N) {
                 if (has_mask) {
                     if (mask16) {
-                        const u32x4_t mk = *reinterpret_cast<const u32x4_t*>(mask16 + off);
+                        const u32x4_t mk = ld16(mask16 + off);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {          // sign and zero-ness are all that is looked at: bits << 16 is the value
                             const float mvj = __builtin_bit_cast(float, (j & 1) ? (mk[j >> 1] & 0xffff0000u) : (mk[j >> 1] << 16));
@@ -251,12 +267,7 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
                     *reinterpret_cast<f32x4*>(out_base + off) = f32x4{x[0], x[1], x[2], x[3]};
                     *reinterpret_cast<f32x4*>(out_base + off + 4) = f32x4{x[4], x[5], x[6], x[7]};
                 }
-                if (sh) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[j];
-                    *reinterpret_cast<bf16x8*>(sh + off) = o;
-                }
+                if (sh) st16(sh + off, x);
             } else {
                 for (int j = 0; j < 8 && col + j < N; ++j) {
                     float v = x[j];

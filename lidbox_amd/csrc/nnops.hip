@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void ap_head_kernel(const float* __restrict__ 
 // 512 x 100 x 100), counting with ds_add_u32 into its own copy (lane = threshold = column: conflict-free, no ordering
 // question: every addend is 1.0f and integer counters: exact in any order).  The workgroup is
 // the only writer of cells [*, m, th-tile]: no global atomics, exact results.
-constexpr int CAVG_WAVES = 4;
+constexpr int CAVG_WAVES = 4, CAVG_BATCH = 9;
 __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restrict__ scores,
                                                           const int32_t* __restrict__ labels, int B, int N,
                                                           const float* __restrict__ thresholds, int Th,
@@ -715,21 +715,38 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
             }
         }
         __syncthreads();
-        if (th < Th)
-            for (int l = wv; l < nl; l += CAVG_WAVES) {
-                const int lab = l0 + l;
-                unsigned pu = 0u;
+        // write-out, a wave's labels in batches of CAVG_BATCH: every counter load of a batch first, then the sums, then the stores
+        // (label by label it is one dependent read-modify-write round trip to HBM per label: 25 in a row at N = 100)
+        if (th < Th) {
+            for (int lb = wv; lb < nl; lb += CAVG_WAVES * CAVG_BATCH) {
+                float* pa[CAVG_BATCH];
+                float* pb[CAVG_BATCH];
+                float va[CAVG_BATCH], vb[CAVG_BATCH];
 #pragma unroll
-                for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
-                const float p = (float)pu, ng = (float)(cnt[l] - pu);          // s < thr  (:61)
-                if (lab == m) {
-                    tp[(long)m * Th + th] += p;                                // :63-66
-                    fn[(long)m * Th + th] += ng;
-                } else {
-                    fp[((long)lab * N + m) * Th + th] += p;                    // :68-71
-                    tn[((long)lab * N + m) * Th + th] += ng;
+                for (int u = 0; u < CAVG_BATCH; ++u) {
+                    const int l = lb + u * CAVG_WAVES, lab = l0 + l;
+                    const bool diag = lab == m;
+                    const long cell = diag ? (long)m * Th + th : ((long)lab * N + m) * Th + th;
+                    pa[u] = (diag ? tp : fp) + cell;                                   // :63-66 / :68-71
+                    pb[u] = (diag ? fn : tn) + cell;
+                    if (l < nl) {
+                        va[u] = *pa[u];
+                        vb[u] = *pb[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CAVG_BATCH; ++u) {
+                    const int l = lb + u * CAVG_WAVES;
+                    if (l < nl) {
+                        unsigned pu = 0u;
+#pragma unroll
+                        for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
+                        *pa[u] = va[u] + (float)pu;
+                        *pb[u] = vb[u] + (float)(cnt[l] - pu);                          // s < thr  (:61)
+                    }
                 }
             }
+        }
         __syncthreads();
     }
 }

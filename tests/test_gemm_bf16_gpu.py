@@ -206,7 +206,7 @@ def test_bf16_gemm_tail_split_matches_single_launch(M, K, N):
 @pytest.mark.parametrize("variant", [None, "64,64,2", "64,64,3", "128,64,2", "64,128,2", "128,128,2", "128,128,3",
                                      "256,256,2", "256,256,1", "256,128,2", "256,128,1"])
 @pytest.mark.parametrize("M,K,N", [(128, 32, 128), (200, 200, 512), (33, 1536, 512), (1000, 264, 40), (5, 8, 8),
-                                   (256, 3000, 512), (700, 512, 1024), (1, 8, 4), (50688 // 8, 200, 512)])
+                                   (256, 3000, 512), (700, 512, 1024), (1, 8, 4), (50688 // 8, 200, 512), (300, 72, 1500), (257, 64, 36)])
 def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N, variant, monkeypatch):
     """lidbox_gemm_bf16s_nt: operands already bf16 in HBM ([M][K] and [N][K]); same numbers as the fp32-source kernel on the
     unrounded originals; the bf16 shadow of C equals bf16(C); split-K, epilogues, converters.

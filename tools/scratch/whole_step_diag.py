@@ -24,7 +24,7 @@ sig, y = tf._batch(B, langs=langs, seed=4321)
 loss = float(tr.train_step(sig, y))
 got = {k: m.param(k, grad=True).cpu().numpy() for k in w0}
 x_gpu = m.workspace(B, tf.T).input_view().cpu().numpy()
-ref_loss, ref_g = tf._oracle_step64(config, w0, x_gpu, y.cpu().numpy(), langs)
+ref_loss, ref_g, _ = tf._oracle_step64(config, w0, x_gpu, y.cpu().numpy(), langs)
 print("loss", loss, ref_loss, abs(loss - ref_loss) / abs(ref_loss))
 for name, g in ref_g.items():
     d = np.abs(got[name] - g)
@@ -32,3 +32,21 @@ for name, g in ref_g.items():
     print("%-12s shape %-16s maxerr/maxabs %.2e  norm-rel %.2e  argmax %s got %.4e ref %.4e  frac>1e-3*max %.2e" % (
         name, g.shape, d.max() / np.abs(g).max(), np.linalg.norm(got[name] - g) / np.linalg.norm(g), i, got[name][i], g[i],
         (d > 1e-3 * np.abs(g).max()).mean()))
+# ReLU decisions: the captured step's activations against the float64 forward pass on the same features
+import torch.nn.functional as F
+from oracle import torch_ref as tref, model_np
+ws = m.workspace(B, tf.T)
+p64 = {k: torch.tensor(np.asarray(v, dtype=np.float64)) for k, v in w0.items()}
+h = torch.from_numpy(x_gpu.astype(np.float64))
+layers = model_np.CNN_CONVS if config == 3 else model_np.XVECTOR_FRAMES
+for i, (name, f, k, s_) in enumerate(layers):
+    z = tref.conv1d_causal(h, p64[name + ".W"], p64[name + ".b"], s_, relu=False)
+    h = F.relu(z)
+    a_gpu = ws.act[i + 1][:, ws.pads[i + 1]:ws.pads[i + 1] + ws.Ts[i + 1], :].cpu().numpy() if i + 1 < len(ws.act) else None
+    if a_gpu is None:
+        break
+    zz = z.numpy()
+    flips = ((a_gpu > 0) != (zz > 0))
+    print("%-8s outputs %9d  |z| < 1e-6: %5d  ReLU decisions that differ: %4d  (|z| there: max %.2e)  max|act - relu(z)| %.2e" % (
+        name, zz.size, int((np.abs(zz) < 1e-6).sum()), int(flips.sum()), float(np.abs(zz[flips]).max()) if flips.any() else 0.0,
+        float(np.abs(a_gpu - np.maximum(zz, 0)).max())))
