@@ -477,6 +477,16 @@ int lidbox_log_softmax_fwd(const float* z, int B, int N, float* logp, lidbox_str
 int lidbox_nll_fwd_bwd(const float* logp, const int32_t* labels, int B, int N, float scale,
                        float* loss_out, float* dz, lidbox_stream_t stream);
 
+/* tf.nn.softmax over rows of z [B,N]: the output layer of a model built with output_activation="softmax"
+ * (lidbox/models/cnn.py:43-44: getattr(tf.nn, output_activation)) */
+int lidbox_softmax_fwd(const float* z, int B, int N, float* out, lidbox_stream_t stream);
+/* Keras SparseCategoricalCrossentropy(from_logits=False) on softmax outputs, mean reduction (keras_utils.py:141-147 with such a
+ * model): from the logits z, p = softmax(z) (written to probs when not NULL), q = clip(p, 1e-7, 1 - 1e-7), loss_out[0] =
+ * mean_b(log sum_j q_bj - log q_b,y); dz (may be NULL) = d(loss)/dz * B * scale through the clip (a clipped probability passes
+ * no gradient) and the softmax; labels outside [0,N): NaN loss, zero gradient row. */
+int lidbox_softmax_nll_fwd_bwd(const float* z, const int32_t* labels, int B, int N, float scale, float* probs,
+                               float* loss_out, float* dz, lidbox_stream_t stream);
+
 /* Output layer + loss of a classifier and their backward in two small launches (train step, few classes): logp =
  * log_softmax(h W + b) with h [B,K] the previous layer's output, W [K,N] a Keras Dense kernel (xvector.py:62-65); loss_out[0]
  * and dz as lidbox_nll_fwd_bwd (scale = 1/global_batch; labels outside [0,N): NaN loss, zero gradient row); dW [K,N] =
@@ -529,6 +539,17 @@ int lidbox_adam_step(float* param, const float* grad, float* m, float* v, long n
  * job for lidbox_reduce_jobs_run -- the launch that finishes the step's last wgrad then prepares the optimizer too (GEMM
  * launches do not carry this kind: *_carry calls reject it) -- and lidbox_adam_apply is the elementwise update with the lr_t
  * found in `state`.  lidbox_adam_step == the job on its own + lidbox_adam_apply, bit for bit. */
+/* tf.keras.optimizers.SGD / RMSprop dense updates (keras_utils.py:137-140: the config names the optimizer class), state = the
+ * 16-byte device state of lidbox_adam_step {int64 step, float lr_t, float lr_now} (step advanced, lr_now honoured).
+ * SGD: velocity (n floats, may be NULL when momentum == 0): v = momentum v - lr g; w += nesterov ? momentum v - lr g : v.
+ * RMSprop: rms = rho rms + (1 - rho) g^2; centered: mean_grad = rho mean_grad + (1 - rho) g, denom = rms - mean_grad^2;
+ * momentum == 0: w -= lr g / (sqrt(denom) + epsilon); momentum > 0: mom = momentum mom + lr g / sqrt(denom + epsilon), w -= mom
+ * (TensorFlow 2.3's two forms).  g = grad * grad_scale. */
+int lidbox_sgd_step(float* param, const float* grad, float* velocity, long n, float lr, float momentum, int nesterov,
+                    float grad_scale, void* state, lidbox_stream_t stream);
+int lidbox_rmsprop_step(float* param, const float* grad, float* rms, float* mean_grad, float* mom, long n, float lr, float rho,
+                        float momentum, float epsilon, int centered, float grad_scale, void* state, lidbox_stream_t stream);
+
 int lidbox_adam_prepare_job(void* state, float lr, float beta1, float beta2, lidbox_reduce_job_t* job);
 int lidbox_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
                       float grad_scale, const void* state, lidbox_stream_t stream);

@@ -140,6 +140,10 @@ _SIGS = {
     "lidbox_ap_head_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "lidbox_cavg_update": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "lidbox_cavg_result": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "lidbox_softmax_fwd": (_i, [_vp, _i, _i, _vp, _vp]),
+    "lidbox_softmax_nll_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "lidbox_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _i, _f, _vp, _vp]),
+    "lidbox_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "lidbox_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _vp]),
     "lidbox_adam_prepare_job": (_i, [_vp, _f, _f, _f, C.POINTER(ReduceJob)]),
     "lidbox_adam_apply": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp, _vp]),

@@ -351,6 +351,69 @@ __global__ __launch_bounds__(256) void nll_kernel(const float* __restrict__ logp
     if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
 }
 
+// tf.nn.softmax over rows (cnn.py:43-44 with output_activation="softmax"), one wave per row
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ z, int B, int N, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* zr = z + (long)row * N;
+    float m = -FLT_MAX;
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, zr[n]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += expf(zr[n] - m);
+    s = wave_sum(s);
+    for (int n = lane; n < N; n += 64) out[(long)row * N + n] = expf(zr[n] - m) / s;
+}
+
+// Keras SparseCategoricalCrossentropy(from_logits=False) on softmax outputs (keras_utils.py:141-142 with a model built with
+// output_activation="softmax"): p = softmax(z); q = clip(p, 1e-7, 1 - 1e-7); the backend then takes
+// sparse_softmax_cross_entropy_with_logits(labels, log q), i.e. loss = log(sum_j q_j) - log q_y (the sum is 1 up to the
+// clipping); dz = the gradient with respect to the logits z through clip and softmax (a clipped probability passes no
+// gradient).  Single workgroup like nll_kernel; probs (may be NULL) receives p.
+constexpr float KERAS_EPSILON = 1e-7f;
+__global__ __launch_bounds__(256) void softmax_nll_kernel(const float* __restrict__ z, const int32_t* __restrict__ labels, int B, int N,
+                                                          float scale, float* __restrict__ probs, float* __restrict__ loss_out,
+                                                          float* __restrict__ dz) {
+    __shared__ float red[4];
+    float part = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* zr = z + (long)b * N;
+        const int y = labels[b];
+        const bool ok = y >= 0 && y < N;
+        float m = -FLT_MAX;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, zr[n]);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += expf(zr[n] - m);
+        float sq = 0.f, qy = 1.f, dot = 0.f;                        // sum of clipped probabilities, q_y, sum_j p_j g_j
+        for (int n = 0; n < N; ++n) {
+            const float p = expf(zr[n] - m) / s;
+            if (probs) probs[(long)b * N + n] = p;
+            sq += fminf(fmaxf(p, KERAS_EPSILON), 1.f - KERAS_EPSILON);
+        }
+        for (int n = 0; n < N; ++n) {
+            const float p = expf(zr[n] - m) / s;
+            const float q = fminf(fmaxf(p, KERAS_EPSILON), 1.f - KERAS_EPSILON);
+            const bool open = p > KERAS_EPSILON && p < 1.f - KERAS_EPSILON;        // clip_by_value passes the gradient inside only
+            if (n == y) qy = q;
+            const float g = open ? (1.f / sq - (n == y ? 1.f / q : 0.f)) : 0.f;
+            dot += p * g;
+        }
+        part += ok ? logf(sq) - logf(qy) : NAN;
+        if (dz)
+            for (int n = 0; n < N; ++n) {
+                const float p = expf(zr[n] - m) / s;
+                const float q = fminf(fmaxf(p, KERAS_EPSILON), 1.f - KERAS_EPSILON);
+                const bool open = p > KERAS_EPSILON && p < 1.f - KERAS_EPSILON;
+                const float g = open ? (1.f / sq - (n == y ? 1.f / q : 0.f)) : 0.f;
+                dz[(long)b * N + n] = ok ? p * (g - dot) * scale : 0.f;
+            }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Output layer + loss of a classifier in TWO small launches (train step only) instead of nine: z = h W + b (Dense(N),
 // xvector.py:62-64), logp = log_softmax(z) (xvector.py:65), Keras SparseCategoricalCrossentropy(from_logits=True) on logp
@@ -840,6 +903,57 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Optimizers other than Adam that a config may name (keras_utils.py:137-140: getattr(tf.keras.optimizers, cls)(**kwargs)).
+// The step counter and the rate of the step live in the same 16-byte device state as Adam's {int64 step, float lr_t, float
+// lr_now}: lr_t = the scheduled rate (lr_now, when a schedule wrote one) or lr, no bias correction.
+__global__ void opt_prepare_kernel(AdamState* st, float lr) {
+    ++st->step;
+    st->lr_t = __float_as_uint(st->lr_now) != 0u ? fabsf(st->lr_now) : lr;
+}
+
+// tf.keras.optimizers.SGD: momentum == 0: w -= lr g;  else v = momentum v - lr g;  w += nesterov ? momentum v - lr g : v
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel, long n,
+                           const AdamState* __restrict__ st, float momentum, int nesterov, float gscale) {
+    const float lr = st->lr_t;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale;
+        if (vel) {
+            const float v = momentum * vel[i] - lr * gr;
+            vel[i] = v;
+            p[i] += nesterov ? momentum * v - lr * gr : v;
+        } else {
+            p[i] -= lr * gr;
+        }
+    }
+}
+
+// tf.keras.optimizers.RMSprop (TF 2.3 rmsprop.py): rms = rho rms + (1 - rho) g^2; centered: mg = rho mg + (1 - rho) g,
+// denom = rms - mg^2.  momentum == 0: w -= lr g / (sqrt(denom) + eps);  momentum > 0 (the fused training op): mom = momentum
+// mom + lr g / sqrt(denom + eps); w -= mom -- epsilon sits inside the root there, as in TensorFlow's kernels.
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ rms, float* __restrict__ mg,
+                               float* __restrict__ mom, long n, const AdamState* __restrict__ st, float rho, float momentum, float eps,
+                               float gscale) {
+    const float lr = st->lr_t;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gscale;
+        const float r = rho * rms[i] + (1.f - rho) * gr * gr;
+        rms[i] = r;
+        float denom = r;
+        if (mg) {
+            const float a = rho * mg[i] + (1.f - rho) * gr;
+            mg[i] = a;
+            denom = r - a * a;
+        }
+        if (mom) {
+            const float m = momentum * mom[i] + lr * gr / sqrtf(denom + eps);
+            mom[i] = m;
+            p[i] -= m;
+        } else {
+            p[i] -= lr * gr / (sqrtf(denom) + eps);
+        }
+    }
+}
+
 // mean of n floats, one workgroup (fixed summation order: deterministic)
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
     __shared__ float red[4];
@@ -1117,6 +1231,48 @@ extern "C" int lidbox_cavg_result(const float* tp, const float* fn, const float*
     LBX_ARG(N >= 2 && Th >= 1, "N >= 2, Th >= 1");
     hipLaunchKernelGGL(cavg_result_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tp, fn, fp_pairs,
                        tn_pairs, N, Th, C_miss, C_fa, P_tar, c_avg_out, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_softmax_fwd(const float* z, int B, int N, float* out, lidbox_stream_t stream) {
+    LBX_ARG(z && out && B >= 0 && N >= 1, "z, out != NULL; N >= 1");
+    if (B == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, z, B, N, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_softmax_nll_fwd_bwd(const float* z, const int32_t* labels, int B, int N, float scale, float* probs,
+                                          float* loss_out, float* dz, lidbox_stream_t stream) {
+    LBX_ARG(z && labels && loss_out && B >= 1 && N >= 1, "z, labels, loss_out != NULL; B, N >= 1");
+    hipLaunchKernelGGL(softmax_nll_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, z, labels, B, N, scale, probs, loss_out, dz);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_sgd_step(float* param, const float* grad, float* velocity, long n, float lr, float momentum, int nesterov,
+                               float grad_scale, void* state, lidbox_stream_t stream) {
+    LBX_ARG(param && grad && state && n >= 0, "param, grad, state != NULL");
+    LBX_ARG(momentum >= 0.f && (momentum == 0.f || velocity), "momentum >= 0; momentum > 0 needs the velocity buffer");
+    hipLaunchKernelGGL(opt_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (AdamState*)state, lr);
+    LBX_LAUNCH_OK();
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum > 0.f ? velocity : nullptr, n,
+                       (const AdamState*)state, momentum, nesterov, grad_scale);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_rmsprop_step(float* param, const float* grad, float* rms, float* mean_grad, float* mom, long n, float lr, float rho,
+                                   float momentum, float epsilon, int centered, float grad_scale, void* state, lidbox_stream_t stream) {
+    LBX_ARG(param && grad && rms && state && n >= 0, "param, grad, rms, state != NULL");
+    LBX_ARG((!centered || mean_grad) && (momentum == 0.f || mom) && momentum >= 0.f, "centered needs mean_grad, momentum > 0 needs mom");
+    hipLaunchKernelGGL(opt_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (AdamState*)state, lr);
+    LBX_LAUNCH_OK();
+    if (n == 0) return LIDBOX_OK;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, rms, centered ? mean_grad : nullptr,
+                       momentum > 0.f ? mom : nullptr, n, (const AdamState*)state, rho, momentum, epsilon, grad_scale);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -201,10 +201,10 @@ def _loss_from_config(loss_conf):
     """reference keras_utils.py:141-142: `getattr(tf.keras.losses, cls)(**kwargs)`"""
     cls, kwargs = loss_conf["cls"], loss_conf.get("kwargs", {})
     if cls == "SparseCategoricalCrossentropy":
-        if not kwargs.get("from_logits", False):
-            raise ValueError("the x-vector / CNN outputs are log-probabilities: use SparseCategoricalCrossentropy("
-                             "from_logits=True) (softmax of log-softmax is the softmax; SURVEY a19)")
-        return "sparse_categorical_crossentropy"
+        # from_logits=True: the models' default log-softmax outputs (softmax of log-softmax is the softmax; SURVEY a19).
+        # from_logits=False (the Keras default): probabilities, i.e. a model built with output_activation="softmax"
+        # (cnn.py:43-44) -- Trainer checks that the model and the loss agree
+        return "sparse_categorical_crossentropy" if kwargs.get("from_logits", False) else "sparse_categorical_crossentropy_probs"
     if cls == "SparseAngularProximity":
         return SparseAngularProximity(**kwargs)
     raise ValueError("unsupported loss %r" % (cls,))
@@ -240,16 +240,25 @@ def lr_schedule_from_config(conf):
 
 
 def _optimizer_from_config(opt_conf):
-    """reference keras_utils.py:135-140: Adam with Keras argument names; `lr_scheduler` as there"""
-    if opt_conf["cls"] != "Adam":
-        raise ValueError("only the Adam optimizer is implemented (got %r)" % (opt_conf["cls"],))
+    """reference keras_utils.py:135-140: `getattr(tf.keras.optimizers, cls)(**kwargs)` -- Adam, SGD and RMSprop with their Keras
+    argument names; `lr_scheduler` as there"""
+    names = {"Adam": ("beta_1", "beta_2", "epsilon"), "SGD": ("momentum", "nesterov"), "RMSprop": ("rho", "momentum", "epsilon", "centered")}
+    if opt_conf["cls"] not in names:
+        raise ValueError("unsupported optimizer %r (Adam, SGD, RMSprop)" % (opt_conf["cls"],))
     kw = dict(opt_conf.get("kwargs", {}))
-    out = {}
+    out = {"cls": opt_conf["cls"]}
     if "lr_scheduler" in kw:
         out["lr_schedule"] = lr_schedule_from_config(kw.pop("lr_scheduler"))
-    for src, dst in (("learning_rate", "lr"), ("lr", "lr"), ("beta_1", "beta_1"), ("beta_2", "beta_2"), ("epsilon", "epsilon")):
+    for src in ("learning_rate", "lr"):
         if src in kw:
-            out[dst] = float(kw[src])
+            out["lr"] = float(kw.pop(src))
+    for name in names[opt_conf["cls"]]:
+        if name in kw:
+            v = kw.pop(name)
+            out[name] = bool(v) if name in ("nesterov", "centered") else float(v)
+    kw.pop("name", None)
+    if kw:
+        raise ValueError("%s: unsupported optimizer arguments %s" % (opt_conf["cls"], sorted(kw)))
     return out
 
 

@@ -284,8 +284,12 @@ class SequentialTDNN:
             # clstm.py:32
             raise ValueError("amount of frequency channels (%d) must be evenly divisible by the amount of frequency "
                              "attention bins (d_f=%d)" % (self.convs[-1].filters, attention.d_f))
-        if output_activation not in ("log_softmax", None):
-            raise ValueError("output_activation must be 'log_softmax' or None")
+        # the reference takes getattr(tf.nn, output_activation) (cnn.py:43-44, xvector_2d.py:86-87): log_softmax (its default),
+        # softmax, or no activation ("linear" / None)
+        if output_activation == "linear":
+            output_activation = None
+        if output_activation not in ("log_softmax", "softmax", None):
+            raise ValueError("output_activation must be 'log_softmax', 'softmax' or None / 'linear'")
         self.output_activation = output_activation
         self.channel_dropout_rate = float(channel_dropout_rate)
         if not 0.0 <= self.channel_dropout_rate < 1.0:
@@ -756,6 +760,9 @@ class SequentialTDNN:
             x, din = out, d.units
         if self.output_activation is None:
             return ws.h[-1]
+        if self.output_activation == "softmax":                      # ws.logp holds the probabilities then
+            nv.check(lib.lidbox_softmax_fwd(nv.ptr(ws.h[-1]), ws.B, din, nv.ptr(ws.logp), st))
+            return ws.logp
         nv.check(lib.lidbox_log_softmax_fwd(nv.ptr(ws.h[-1]), ws.B, din, nv.ptr(ws.logp), st))
         return ws.logp
 

@@ -205,8 +205,19 @@ class Trainer:
                  sync_state_every_step=False, grad_wire_dtype=None):
         self.model = model
         self.device = model.device
-        opt = dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7)
+        # optimizer: dict(cls="Adam" | "SGD" | "RMSprop", ...) with the Keras argument names and defaults (TensorFlow 2.3); the class
+        # is what a config names at keras_utils.py:137-140
+        cls_ = (optimizer or {}).get("cls", "Adam")
+        defaults = {"Adam": dict(lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7),
+                    "SGD": dict(lr=0.01, momentum=0.0, nesterov=False),
+                    "RMSprop": dict(lr=1e-3, rho=0.9, momentum=0.0, epsilon=1e-7, centered=False)}
+        if cls_ not in defaults:
+            raise ValueError("unsupported optimizer %r (Adam, SGD, RMSprop)" % (cls_,))
+        opt = dict(defaults[cls_], cls=cls_)
         opt.update(optimizer or {})
+        unknown = set(opt) - set(defaults[cls_]) - {"cls", "lr_schedule"}
+        if unknown:
+            raise ValueError("%s: unknown optimizer arguments %s" % (cls_, sorted(unknown)))
         self.opt = opt
         self.feature = feature
         self.metric = metric
@@ -218,6 +229,11 @@ class Trainer:
             if model.output_activation != "log_softmax":
                 raise ValueError("sparse_categorical_crossentropy expects log_softmax outputs")
             self.loss_kind, self.ap = "nll", None
+        elif loss == "sparse_categorical_crossentropy_probs":
+            # Keras SparseCategoricalCrossentropy(from_logits=False): the model must end in tf.nn.softmax
+            if model.output_activation != "softmax":
+                raise ValueError("SparseCategoricalCrossentropy(from_logits=False) expects a model built with output_activation='softmax'")
+            self.loss_kind, self.ap = "nll_probs", None
         else:
             raise ValueError("unknown loss %r" % (loss,))
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -330,6 +346,10 @@ class Trainer:
             if not getattr(ws, "output_layer_done", False):
                 nv.check(lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(labels), B, out.shape[1], scale,
                                                 nv.ptr(ws.loss), nv.ptr(ws.dh[-1]), st))
+        elif self.loss_kind == "nll_probs":
+            # clipped-probability cross-entropy and its gradient with respect to the logits, from the logits (ws.h[-1])
+            nv.check(lib.lidbox_softmax_nll_fwd_bwd(nv.ptr(ws.h[-1]), nv.ptr(labels), B, out.shape[1], scale, None,
+                                                    nv.ptr(ws.loss), nv.ptr(ws.dh[-1]), st))
         else:
             D = out.shape[1]
             zn, dzn, per = self._ap_buffers(ws, D)
@@ -348,7 +368,7 @@ class Trainer:
             nv.check(lib.lidbox_mean(nv.ptr(per), B, nv.ptr(ws.loss), st))
             if want_scores:
                 self.metric._update_sparse(labels, ws.ap_scores)
-        if self.loss_kind == "nll" and self.metric is not None and not self._warming:
+        if self.loss_kind in ("nll", "nll_probs") and self.metric is not None and not self._warming:
             self.metric._update_sparse(labels, out)
         if nxt is not None:
             torch.cuda.current_stream().wait_stream(self._prefetch_stream)      # the prefetch joins behind the forward pass
@@ -450,7 +470,7 @@ class Trainer:
         for i in range(hi_edges[k] - 1, lo_edges[k] - 1, -1):
             self.model.backward_conv_ws(ws, i)
         self._prepared = False
-        if k == self.num_stages - 1 and not self._warming and not os.environ.get("LIDBOX_ADAM_PREPARE_LAUNCH"):
+        if k == self.num_stages - 1 and not self._warming and self.opt["cls"] == "Adam" and not os.environ.get("LIDBOX_ADAM_PREPARE_LAUNCH"):
             # the optimizer's scalar half (step counter, bias-corrected rate) rides in the launch that finishes the last wgrad
             job = nv.ReduceJob()
             o = self.opt
@@ -492,8 +512,20 @@ class Trainer:
             self._host_step += 1
 
     def _adam(self):
+        """the optimizer segment of a step (Adam: the name of the reference configurations' optimizer stuck to it)"""
         o = self.opt
         m = self.model
+        if o["cls"] == "SGD":
+            nv.check(nv.lib.lidbox_sgd_step(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m) if o["momentum"] > 0 else None, m.num_flat,
+                                            o["lr"], o["momentum"], int(bool(o["nesterov"])), 1.0, nv.ptr(self.adam_state), nv.current_stream()))
+            return
+        if o["cls"] == "RMSprop":
+            if o["centered"] and not hasattr(self, "mg"):
+                self.mg = torch.zeros_like(self.m)
+            nv.check(nv.lib.lidbox_rmsprop_step(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.v), nv.ptr(self.mg) if o["centered"] else None,
+                                                nv.ptr(self.m) if o["momentum"] > 0 else None, m.num_flat, o["lr"], o["rho"], o["momentum"],
+                                                o["epsilon"], int(bool(o["centered"])), 1.0, nv.ptr(self.adam_state), nv.current_stream()))
+            return
         if getattr(self, "_prepared", False):      # the last backward stage carried the prepare half (lidbox_adam_prepare_job)
             nv.check(nv.lib.lidbox_adam_apply(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.m), nv.ptr(self.v), m.num_flat,
                                               o["beta_1"], o["beta_2"], o["epsilon"], 1.0, nv.ptr(self.adam_state), nv.current_stream()))

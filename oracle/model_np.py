@@ -277,6 +277,57 @@ def adam_step(params, grads, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e
         params[k] = (params[k] - lr_t * m[k] / (np.sqrt(v[k]) + eps)).astype(params[k].dtype)
 
 
+def sgd_step(params, grads, vel, lr=0.01, momentum=0.0, nesterov=False):
+    """tf.keras.optimizers.SGD dense update (the class a config may name at lidbox/models/keras_utils.py:137-140; TensorFlow
+    2.3 gradient_descent.py): momentum == 0: w -= lr g; else v = momentum v - lr g, w += (momentum v - lr g if nesterov else v)."""
+    for k in params:
+        g = grads[k]
+        if momentum == 0.0:
+            params[k] = (params[k] - lr * g).astype(params[k].dtype)
+        else:
+            vel[k] = momentum * vel[k] - lr * g
+            params[k] = (params[k] + (momentum * vel[k] - lr * g if nesterov else vel[k])).astype(params[k].dtype)
+
+
+def rmsprop_step(params, grads, rms, mg, mom, lr=1e-3, rho=0.9, momentum=0.0, eps=1e-7, centered=False):
+    """tf.keras.optimizers.RMSprop dense update (keras_utils.py:137-140; TensorFlow 2.3 rmsprop.py:_resource_apply_dense):
+    rms = rho rms + (1 - rho) g^2; centered: mg = rho mg + (1 - rho) g and denom = rms - mg^2.  Without momentum the Python
+    branch: w -= lr g / (sqrt(denom) + eps); with momentum the fused training op (training_ops.apply_rms_prop):
+    mom = momentum mom + lr g / sqrt(denom + eps), w -= mom -- epsilon INSIDE the root there."""
+    for k in params:
+        g = grads[k]
+        rms[k] = rho * rms[k] + (1.0 - rho) * g * g
+        denom = rms[k]
+        if centered:
+            mg[k] = rho * mg[k] + (1.0 - rho) * g
+            denom = rms[k] - mg[k] * mg[k]
+        if momentum > 0.0:
+            mom[k] = momentum * mom[k] + lr * g / np.sqrt(denom + eps)
+            params[k] = (params[k] - mom[k]).astype(params[k].dtype)
+        else:
+            params[k] = (params[k] - lr * g / (np.sqrt(denom) + eps)).astype(params[k].dtype)
+
+
+def sparse_ce_from_probs(z, y, eps=1e-7):
+    """Keras SparseCategoricalCrossentropy(from_logits=False) on the outputs of a model that ends in tf.nn.softmax
+    (lidbox/models/cnn.py:43-44 with output_activation="softmax", loss class from keras_utils.py:141-142).  TensorFlow 2.3
+    backend.sparse_categorical_crossentropy: output = clip_by_value(output, eps, 1 - eps); sparse_softmax_cross_entropy_with_
+    logits(labels, log(output)) -- i.e. log(sum_j q_j) - log q_y -- mean over the batch.  z: the logits; returns (loss, dL/dz)."""
+    z = np.asarray(z, dtype=np.float64)
+    p = softmax(z)
+    q = np.clip(p, eps, 1.0 - eps)
+    B = z.shape[0]
+    idx = np.arange(B)
+    loss = float(np.mean(np.log(q.sum(axis=1)) - np.log(q[idx, y])))
+    opened = (p > eps) & (p < 1.0 - eps)                     # clip_by_value passes the gradient strictly inside only
+    g = np.where(opened, 1.0 / q.sum(axis=1, keepdims=True), 0.0)
+    gy = np.zeros_like(g)
+    gy[idx, y] = 1.0 / q[idx, y]
+    g = g - np.where(opened, gy, 0.0)
+    dz = p * (g - (p * g).sum(axis=1, keepdims=True)) / B
+    return loss, dz
+
+
 # ------------------------------------------------------------------ a17 AP loss
 def ap_theta(z, N):
     """lidbox/losses.py:42-49: reference directions are the first N one-hot axes

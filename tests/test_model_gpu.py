@@ -176,6 +176,96 @@ def test_train_steps_match_oracle_adam_and_graph_equals_eager():
     assert l1 < l0
 
 
+@pytest.mark.parametrize("opt", [dict(cls="SGD", lr=0.05), dict(cls="SGD", lr=0.02, momentum=0.9), dict(cls="SGD", lr=0.02, momentum=0.8, nesterov=True),
+                                 dict(cls="RMSprop", lr=2e-3), dict(cls="RMSprop", lr=1e-3, momentum=0.5, rho=0.8),
+                                 dict(cls="RMSprop", lr=1e-3, centered=True, epsilon=1e-6), dict(cls="RMSprop", lr=1e-4, centered=True, momentum=0.5)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_steps_match_oracle_sgd_and_rmsprop(opt, use_graph):
+    """the optimizer classes a config may name besides Adam (reference keras_utils.py:137-140: getattr(tf.keras.optimizers, cls)):
+    four steps of lidbox_sgd_step / lidbox_rmsprop_step inside the train step against the oracle's restatement of the TensorFlow
+    2.3 dense updates (momentum / Nesterov, RMSprop's two epsilon placements, centered)"""
+    from lidbox_amd.models import xvector
+    from lidbox_amd.train import Trainer
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 50, 24)).astype(np.float32)
+    y = rng.integers(0, 5, size=6).astype(np.int32)
+    xd, yd = _dev(x), _dev(y, np.int32)
+    m = xvector.create((50, 24), 5, seed=7)
+    p = _oracle_params(m)
+    w0 = {k: v.copy() for k, v in p.items()}
+    bufs = [{k: np.zeros_like(v) for k, v in p.items()} for _ in range(3)]
+    tr = Trainer(m, optimizer=opt, use_graph=use_graph)
+    kw = {k: v for k, v in opt.items() if k != "cls"}
+    for step in range(1, 5):
+        l = float(tr.train_step(xd, yd))
+        lo, go, _ = mo.xvector_loss_and_grads(p, x.astype(np.float64), y)
+        if opt["cls"] == "SGD":
+            mo.sgd_step(p, go, bufs[0], **kw)
+        else:
+            mo.rmsprop_step(p, go, bufs[0], bufs[1], bufs[2], **{("eps" if k == "epsilon" else k): v for k, v in kw.items()})
+        assert abs(l - lo) <= (5e-4 if opt["cls"] == "SGD" else 3e-3) * abs(lo), (step, l, lo)
+    assert tr.step_count == 4
+    for k, v in m.get_weights().items():
+        moved = np.abs(p[k] - w0[k]).max()
+        # RMSprop normalises every update to ~lr / sqrt(1 - rho) (like Adam): a weight whose gradient is ~0 may move the other
+        # way on an fp32 summation-order difference, so the bulk is held tight and the worst element to a fraction of the movement
+        # (the update arithmetic itself is pinned to 1e-6 in tests/test_ops_gpu.py::test_sgd_and_rmsprop_updates)
+        err = np.abs(v - p[k])
+        if opt["cls"] == "SGD":
+            assert err.max() <= 2e-2 * moved + 1e-7, (k, err.max(), moved)
+        else:
+            assert np.median(err) <= 1e-3 * moved + 1e-7 and err.max() <= 0.25 * moved + 1e-7, (k, np.median(err), err.max(), moved)
+    with pytest.raises(ValueError):
+        Trainer(m, optimizer=dict(cls="Adagrad"))
+    with pytest.raises(ValueError):
+        Trainer(m, optimizer=dict(cls="SGD", beta_1=0.9))
+
+
+def test_softmax_output_and_crossentropy_on_probabilities():
+    """cnn.create(output_activation="softmax") (reference cnn.py:43-44: getattr(tf.nn, output_activation)) with Keras
+    SparseCategoricalCrossentropy(from_logits=False): probabilities out of the model, the clipped-probability loss and its
+    gradients against the oracle (oracle/model_np.py: sparse_ce_from_probs; torch autograd through the same formula)"""
+    from lidbox_amd.models import cnn
+    from lidbox_amd.train import Trainer
+    from oracle import torch_ref as tr
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((5, 61, 12))
+    y = rng.integers(0, 4, size=5).astype(np.int32)
+    m = cnn.create((61, 12), 4, output_activation="softmax", seed=2)
+    p = _oracle_params(m)
+    probs = m(_dev(x)).cpu().numpy()
+    assert np.abs(probs - np.exp(mo.cnn_fwd(p, x))).max() < 1e-5 and np.abs(probs.sum(axis=1) - 1).max() < 1e-6
+    pt = tr.to_torch_params(p, True, torch.float64)
+    logp = tr.cnn_fwd(pt, torch.tensor(x))
+    q = torch.clamp(torch.exp(logp), 1e-7, 1 - 1e-7)
+    yt = torch.tensor(y.astype(np.int64))
+    ref = (torch.log(q.sum(dim=1)) - torch.log(q.gather(1, yt[:, None])[:, 0])).mean()
+    ref.backward()
+    t = Trainer(m, loss="sparse_categorical_crossentropy_probs", use_graph=False)
+    assert not t.fuse_output
+    loss, _ = t.loss_and_grads(_dev(x), _dev(y, np.int32))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    for k in p:
+        ref_g = pt[k].grad.numpy()
+        assert np.abs(m.param(k, grad=True).cpu().numpy() - ref_g).max() <= 1e-3 * max(1e-12, np.abs(ref_g).max()), k
+    # the loss op alone against the numpy restatement, including saturated rows (a clipped probability passes no gradient)
+    from lidbox_amd import _native as nv
+    z = rng.standard_normal((7, 6)).astype(np.float32) * 3
+    z[0] = [40, 0, 0, 0, 0, 0]                                   # p_0 = 1 - O(1e-17): clipped, zero gradient row
+    z[1] = [-30, 0, 0, 0, 0, 1]                                  # p_0 < 1e-7: its own term is clipped
+    yy = np.array([0, 0, 3, 1, 5, 2, 4], np.int32)
+    zd, dz, pr, lo = _dev(z), torch.zeros(7, 6, device="cuda"), torch.zeros(7, 6, device="cuda"), torch.zeros(1, device="cuda")
+    nv.check(nv.lib.lidbox_softmax_nll_fwd_bwd(nv.ptr(zd), nv.ptr(_dev(yy, np.int32)), 7, 6, 1.0 / 7, nv.ptr(pr), nv.ptr(lo), nv.ptr(dz), nv.current_stream()))
+    rl, rdz = mo.sparse_ce_from_probs(z, yy)
+    assert abs(float(lo) - rl) <= 1e-5 * abs(rl) and np.abs(dz.cpu().numpy() - rdz).max() <= 1e-6
+    assert np.abs(dz.cpu().numpy()[0]).max() <= 1e-9 and np.abs(pr.cpu().numpy() - mo.softmax(z.astype(np.float64))).max() < 1e-6
+    # a loss / model mismatch is refused; from_logits=True still needs the log-softmax outputs
+    with pytest.raises(ValueError):
+        Trainer(cnn.create((61, 12), 4, seed=2), loss="sparse_categorical_crossentropy_probs")
+    with pytest.raises(ValueError):
+        Trainer(m, loss="sparse_categorical_crossentropy")
+
+
 def test_train_step_from_waveforms_writes_features_in_place():
     from lidbox_amd import _native as nv
     from lidbox_amd.features import audio

@@ -588,6 +588,41 @@ def test_softmax_head_limits():
                                                     nv.ptr(x), nv.ptr(x), None, nv.ptr(x), 16, nv.current_stream()))
 
 
+def test_sgd_and_rmsprop_updates():
+    """lidbox_sgd_step / lidbox_rmsprop_step on random vectors against the oracle's restatement of the TensorFlow 2.3 dense updates
+    (oracle/model_np.py, reference call site keras_utils.py:137-140), five steps each, every variant; the device step counter
+    advances and a scheduled rate (lr_now) replaces the constructor's"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(31)
+    n = 1003
+    st = nv.current_stream()
+    w0 = rng.standard_normal(n).astype(np.float32)
+    grads = [rng.standard_normal(n).astype(np.float32) * 0.1 for _ in range(5)]
+    for kw in (dict(momentum=0.0, nesterov=False), dict(momentum=0.9, nesterov=False), dict(momentum=0.6, nesterov=True)):
+        p, vel = {"w": w0.astype(np.float64)}, {"w": np.zeros(n)}
+        wd, vd, state = _dev(w0), torch.zeros(n, device="cuda"), torch.zeros(16, dtype=torch.uint8, device="cuda")
+        for g in grads:
+            mo.sgd_step(p, {"w": g.astype(np.float64)}, vel, lr=0.03, **kw)
+            nv.check(nv.lib.lidbox_sgd_step(nv.ptr(wd), nv.ptr(_dev(g)), nv.ptr(vd), n, 0.03, kw["momentum"], int(kw["nesterov"]), 1.0, nv.ptr(state), st))
+        assert np.abs(wd.cpu().numpy() - p["w"]).max() <= 2e-6, kw
+        assert int(state[:8].view(torch.int64).item()) == 5
+    for kw in (dict(), dict(momentum=0.7), dict(centered=True), dict(centered=True, momentum=0.3, rho=0.8, eps=1e-5)):
+        p, rms, mg, mm = {"w": w0.astype(np.float64)}, {"w": np.zeros(n)}, {"w": np.zeros(n)}, {"w": np.zeros(n)}
+        wd, state = _dev(w0), torch.zeros(16, dtype=torch.uint8, device="cuda")
+        rd, gd, md = (torch.zeros(n, device="cuda") for _ in range(3))
+        for g in grads:
+            mo.rmsprop_step(p, {"w": g.astype(np.float64)}, rms, mg, mm, lr=2e-3, **kw)
+            nv.check(nv.lib.lidbox_rmsprop_step(nv.ptr(wd), nv.ptr(_dev(g)), nv.ptr(rd), nv.ptr(gd), nv.ptr(md), n, 2e-3, kw.get("rho", 0.9),
+                                                kw.get("momentum", 0.0), kw.get("eps", 1e-7), int(kw.get("centered", False)), 1.0, nv.ptr(state), st))
+        assert np.abs(wd.cpu().numpy() - p["w"]).max() <= 5e-6, kw
+    # a scheduled rate in the state's lr_now replaces lr (what Trainer's lr_schedule writes)
+    wd, state = _dev(w0), torch.zeros(16, dtype=torch.uint8, device="cuda")
+    state[12:16].view(torch.float32).fill_(0.5)
+    nv.check(nv.lib.lidbox_sgd_step(nv.ptr(wd), nv.ptr(_dev(grads[0])), None, n, 0.03, 0.0, 0, 1.0, nv.ptr(state), st))
+    assert np.abs(wd.cpu().numpy() - (w0 - 0.5 * grads[0])).max() <= 1e-6
+    assert nv.lib.lidbox_sgd_step(nv.ptr(wd), nv.ptr(wd), None, n, 0.03, 0.9, 0, 1.0, nv.ptr(state), st) == -1        # momentum without a buffer
+
+
 def test_adam_prepare_job_plus_apply_equals_adam_step():
     """lidbox_adam_prepare_job run by lidbox_reduce_jobs_run (together with a wgrad-style slice sum in the same launch) +
     lidbox_adam_apply == lidbox_adam_step bit for bit over three steps, with and without a scheduled rate; GEMM carriers

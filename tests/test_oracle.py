@@ -487,3 +487,46 @@ def test_xvector_2d_oracle_numpy_equals_torch_and_batchnorm_properties():
     assert np.allclose(mm, 0.01 * a.mean(axis=(0, 1))) and np.allclose(mv, 0.99 + 0.01 * a.var(axis=(0, 1), ddof=1))
     y2, mm2, mv2 = mo.batchnorm_fwd(a, g, b, mm, mv, False)
     assert mm2 is mm and np.allclose(y2, (a - mm) / np.sqrt(mv + 1e-3))
+
+
+def test_optimizer_restatements_against_torch_and_closed_forms():
+    """oracle/model_np.py sgd_step / rmsprop_step (the classes a config may name at keras_utils.py:137-140): SGD with momentum /
+    Nesterov against torch.optim.SGD (same recurrences up to the sign convention of the velocity), RMSprop's momentum-free form
+    against torch.optim.RMSprop (eps outside the root, as in that TensorFlow branch), and the fused form's epsilon-inside-the-root
+    placement against its closed form after one step"""
+    import torch
+    from oracle import model_np as mo
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal(50)
+    grads = [rng.standard_normal(50) for _ in range(5)]
+    for mom, nest in ((0.0, False), (0.9, False), (0.7, True)):
+        p, vel = {"w": w.copy()}, {"w": np.zeros(50)}
+        t = torch.tensor(w.copy(), requires_grad=True)
+        opt = torch.optim.SGD([t], lr=0.05, momentum=mom, nesterov=nest)
+        for g in grads:
+            mo.sgd_step(p, {"w": g}, vel, lr=0.05, momentum=mom, nesterov=nest)
+            t.grad = torch.tensor(g)
+            opt.step()
+        assert np.abs(p["w"] - t.detach().numpy()).max() < 1e-12, (mom, nest)
+    for centered in (False, True):
+        p, rms, mg, mm = {"w": w.copy()}, {"w": np.zeros(50)}, {"w": np.zeros(50)}, {"w": np.zeros(50)}
+        t = torch.tensor(w.copy(), requires_grad=True)
+        opt = torch.optim.RMSprop([t], lr=1e-2, alpha=0.9, eps=1e-7, centered=centered)
+        for g in grads:
+            mo.rmsprop_step(p, {"w": g}, rms, mg, mm, lr=1e-2, rho=0.9, eps=1e-7, centered=centered)
+            t.grad = torch.tensor(g)
+            opt.step()
+        assert np.abs(p["w"] - t.detach().numpy()).max() < 1e-10, centered
+    p, rms, mg, mm = {"w": w.copy()}, {"w": np.zeros(50)}, {"w": np.zeros(50)}, {"w": np.zeros(50)}
+    mo.rmsprop_step(p, {"w": grads[0]}, rms, mg, mm, lr=1e-2, rho=0.9, momentum=0.5, eps=1e-3)
+    assert np.abs(p["w"] - (w - 1e-2 * grads[0] / np.sqrt(0.1 * grads[0] ** 2 + 1e-3))).max() < 1e-15
+    # from_logits=False cross-entropy: equals -log p_y inside the clip range, floor log(1 / (1 - 1e-7)) ~ 1e-7 when saturated
+    z = rng.standard_normal((4, 5))
+    y = np.array([0, 1, 2, 3])
+    loss, dz = mo.sparse_ce_from_probs(z, y)
+    lp = mo.log_softmax(z)
+    assert abs(loss - float(-lp[np.arange(4), y].mean())) < 1e-12
+    assert np.abs(dz - (mo.softmax(z) - np.eye(5)[y]) / 4).max() < 1e-12
+    zs = np.array([[50.0, 0, 0]])
+    ls, dzs = mo.sparse_ce_from_probs(zs, np.array([0]))
+    assert 0 <= ls < 3e-7 and np.abs(dzs).max() == 0.0
