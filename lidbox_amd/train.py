@@ -239,6 +239,8 @@ class Trainer:
         f32 = dict(dtype=torch.float32, device=self.device)
         self.m = torch.zeros(model.num_flat, **f32)
         self.v = torch.zeros(model.num_flat, **f32)
+        if opt["cls"] == "RMSprop" and opt["centered"]:
+            self.mg = torch.zeros(model.num_flat, **f32)         # centered RMSprop's running mean of the gradient (allocated here: never inside a capture)
         self.adam_state = torch.zeros(16, dtype=torch.uint8, device=self.device)     # {int64 step, float lr_t, float lr_now}
         bounds, splits = plan_buckets(model, num_buckets)
         self.splits = [] if splits is None else ([splits] if isinstance(splits, int) else list(splits))   # ascending conv indices
@@ -520,8 +522,6 @@ class Trainer:
                                             o["lr"], o["momentum"], int(bool(o["nesterov"])), 1.0, nv.ptr(self.adam_state), nv.current_stream()))
             return
         if o["cls"] == "RMSprop":
-            if o["centered"] and not hasattr(self, "mg"):
-                self.mg = torch.zeros_like(self.m)
             nv.check(nv.lib.lidbox_rmsprop_step(nv.ptr(m.flat), nv.ptr(m.flat_grad), nv.ptr(self.v), nv.ptr(self.mg) if o["centered"] else None,
                                                 nv.ptr(self.m) if o["momentum"] > 0 else None, m.num_flat, o["lr"], o["rho"], o["momentum"],
                                                 o["epsilon"], int(bool(o["centered"])), 1.0, nv.ptr(self.adam_state), nv.current_stream()))

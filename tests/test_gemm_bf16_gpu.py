@@ -259,6 +259,61 @@ def test_bf16_storage_gemm_nt_and_shadow_output(M, K, N, variant, monkeypatch):
     assert torch.equal(c16, c.bfloat16())
 
 
+@pytest.mark.parametrize("variant", ["256,256,2", "256,128,2", "256,256,2,3"])
+def test_bf16_pingpong_tile_carries_reduce_jobs_and_splits_k(variant, monkeypatch):
+    """the eight-wave ping-pong tile (csrc/gemm16_pp.h, 512-thread workgroups) as the carrier of a pending wgrad slice sum
+    (lidbox_gemm_bf16s_tn_partial + lidbox_gemm_bf16s_nt_carry: the leading workgroups' first 256 threads run the job) and along
+    a K split ("bm,bn,sub,splits": grid.y > 1, partial sums through the workspace + rows_reduce_kernel): the same bits as the
+    separate launches / the unsplit launch of the same variant up to fp32 summation order, the float64 product to round-off;
+    ReLU mask from bf16 data, shadow-only output, batched rows that cross utterance boundaries inside a 32-row strip"""
+    from lidbox_amd import _native as nv
+    monkeypatch.setenv("LIDBOX_GEMM16S_DMA", variant)
+    rng = np.random.default_rng(17)
+    Bn, R, Co, N, K1 = 9, 61, 264, 520, 200                       # M = 549 rows in 9 utterances of 61 (+ 3 pad rows each)
+    M = Bn * R
+    dy16 = _dev(rng.standard_normal((M, Co))).bfloat16()
+    w16 = (_dev(rng.standard_normal((N, Co))) * 0.1).bfloat16()
+    x16 = _dev(rng.standard_normal((M, K1))).bfloat16()
+    mask16 = _dev(np.maximum(rng.standard_normal((Bn, R + 3, N)), 0)).bfloat16()
+    st = nv.current_stream()
+    wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(M, N, Co)) + (3 * M * N * 4 if variant.count(",") == 3 else 0)
+    ws1 = _ws(wsb)
+    ws2 = _ws(max(16, nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, Co)))
+    ra, rb = nv.Rows(x16.data_ptr(), 0, K1, 1, M), nv.Rows(dy16.data_ptr(), 0, Co, 1, M)
+
+    def run(carry):
+        dx16 = torch.full((Bn, R + 3, N), 5.0, dtype=torch.bfloat16, device="cuda")
+        dw = torch.full((K1, Co), 3.0, device="cuda")
+        db = torch.full((Co,), 3.0, device="cuda")
+        Cd = nv.Rows(None, (R + 3) * N, N, Bn, R)                   # shadow only, rows behind 3 pad rows per utterance
+        c16 = nv.C.c_void_p(dx16.data_ptr() + 2 * 3 * N)
+        mk = nv.C.c_void_p(mask16.data_ptr() + 2 * 3 * N)
+        epi = nv.EPI_RELU_MASK | nv.EPI_MASK_BF16
+        job = nv.ReduceJob()
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn_partial(ra, rb, nv.ptr(dw), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws2), ws2.numel(), nv.C.byref(job), st))
+        if carry:
+            nv.check(nv.lib.lidbox_gemm_bf16s_nt_carry(rb, nv.ptr(w16), Co, Cd, c16, Co, N, epi, mk, nv.ptr(ws1), ws1.numel(), nv.C.byref(job), 1, st))
+            assert nv.lib.lidbox_gemm_bf16s_last_carried() == 1
+        else:
+            nv.check(nv.lib.lidbox_reduce_jobs_run(nv.C.byref(job), 1, st))
+            nv.check(nv.lib.lidbox_gemm_bf16s_nt(rb, nv.ptr(w16), Co, Cd, c16, Co, N, epi, mk, nv.ptr(ws1), ws1.numel(), st))
+        out3 = (nv.C.c_int * 3)()
+        nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(out3))
+        assert list(out3) == [int(v) for v in variant.split(",")[:3]]
+        torch.cuda.synchronize()
+        return dx16, dw, db
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    dx16, dw, db = a
+    assert bool((dx16[:, :3, :] == 5.0).all())                     # pad rows untouched
+    ref = (dy16.double() @ w16.double().T).reshape(Bn, R, N) * (mask16[:, 3:, :] > 0)
+    assert torch.equal(dx16[:, 3:, :], ref.float().bfloat16()) or float((dx16[:, 3:, :].double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    refw = x16.double().T @ dy16.double()
+    assert float((dw.double() - refw).abs().max()) <= 2e-5 * float(refw.abs().max())
+    assert float((db.double() - dy16.double().sum(0)).abs().max()) <= 2e-5 * float(dy16.double().sum(0).abs().max())
+
+
 def test_bf16_storage_gemm_implicit_rows_and_errors():
     """strided causal windows over a bf16 shadow [B, pad + T, C] (Conv1D k = 3, stride 2) and the alignment rules"""
     from lidbox_amd import _native as nv
