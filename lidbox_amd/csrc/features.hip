@@ -752,6 +752,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
                 float acc[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+                // A row of the transposed buffer is 32 bytes = two ds_read_b128, and the LDS serves a b128 wave access in groups
+                // of 16 lanes that cover the 64 banks once only when they hit 16 different 16-byte slots mod 256 bytes: with every
+                // lane on the FIRST half of its row a group can reach 8 of the 16 slots (2-way conflicts by construction: a third of
+                // this kernel's LDS cycles, profiles/r04_feature_census.txt).  Odd lanes therefore read the second half first -- each
+                // group contains 8 even and 8 odd lanes -- and carry frames 4-7 in acc[0..3], 0-3 in acc[4..7] until the swap below.
+#ifndef LBX_FEAT_MEL_HALFSWAP
+#define LBX_FEAT_MEL_HALFSWAP 0            // measured neutral (profiles/r05_feature_mel_halfswap_ab.txt): off
+#endif
+                const int half0 = (LBX_FEAT_MEL_HALFSWAP && (lane & 1)) ? 4 : 0, half1 = 4 - half0;
                 // chunks of 4 bins: the 12 LDS reads of a chunk are issued before its 32 FMAs (the FFT registers are
                 // dead here, so the operands cost nothing); one LDS round trip per chunk instead of one per bin
                 for (int j0 = 0; j0 < a.seg_len; j0 += 4) {
@@ -763,8 +772,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
                         w[u] = (j < a.seg_len) ? s_segw[min(j, a.seg_len - 1) * 64 + lane] : 0.f;
                         const int bin = min(bin0 + j, 256);
                         const float* row = s_P + (bin + (bin >> 3)) * 8;
-                        p0[u] = *reinterpret_cast<const float4*>(row);
-                        p1[u] = *reinterpret_cast<const float4*>(row + 4);
+                        p0[u] = *reinterpret_cast<const float4*>(row + half0);
+                        p1[u] = *reinterpret_cast<const float4*>(row + half1);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -772,6 +781,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
                         acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
                         acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
                         acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
+                    }
+                }
+                if (LBX_FEAT_MEL_HALFSWAP) {
+                    const bool sw = (lane & 1) != 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float lo = acc[i], hi = acc[4 + i];
+                        acc[i] = sw ? hi : lo;
+                        acc[4 + i] = sw ? lo : hi;
                     }
                 }
                 const int sidx = sinfo & 255, sns = sinfo >> 8;

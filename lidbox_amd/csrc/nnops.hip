@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void ap_head_kernel(const float* __restrict__ 
 // 512 x 100 x 100), counting with ds_add_u32 into its own copy (lane = threshold = column: conflict-free, no ordering
 // question: every addend is 1.0f and integer counters: exact in any order).  The workgroup is
 // the only writer of cells [*, m, th-tile]: no global atomics, exact results.
-constexpr int CAVG_WAVES = 4, CAVG_BATCH = 9;
+constexpr int CAVG_WAVES = 4, CAVG_BATCH = 25;
 __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restrict__ scores,
                                                           const int32_t* __restrict__ labels, int B, int N,
                                                           const float* __restrict__ thresholds, int Th,
@@ -757,16 +757,44 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int th = blockIdx.y * 64 + lane;
     const float thr = th < Th ? thresholds[th] : 0.f;
+    // cell (label l0 + l, class m, threshold th) of the positive / negative counter pairs: (tp, fn) on the diagonal, (fp, tn) off it
+    auto cells = [&](int lab, float*& pa, float*& pb) {
+        const bool diag = lab == m;
+        const long cell = diag ? (long)m * Th + th : ((long)lab * N + m) * Th + th;
+        pa = (diag ? tp : fp) + cell;                                          // metrics.py:63-66 / :68-71
+        pb = (diag ? fn : tn) + cell;
+    };
     for (int l0 = 0; l0 < N; l0 += lch) {
         const int nl = min(lch, N - l0);
-        for (int i = threadIdx.x; i < CAVG_WAVES * lch * 64; i += 256) pos[i] = 0u;
-        for (int l = threadIdx.x; l < nl; l += 256) cnt[l] = 0u;
+        // the counters this thread will update (its wave's labels wv, wv + 4, ...): every load goes out NOW, ahead of the LDS
+        // clear and the walk -- the write-out at the end then adds and stores without a round trip to HBM of its own
+        float va[CAVG_BATCH], vb[CAVG_BATCH];
+#pragma unroll
+        for (int u = 0; u < CAVG_BATCH; ++u) {
+            const int l = wv + u * CAVG_WAVES;
+            va[u] = vb[u] = 0.f;
+            if (th < Th && l < nl) {
+                float *pa, *pb;
+                cells(l0 + l, pa, pb);
+                va[u] = *pa;
+                vb[u] = *pb;
+            }
+        }
+        // first block of examples of this wave: its scores / labels are in flight during the clear as well
+        int b0 = wv * 64;
+        float sv = b0 + lane < B ? scores[(long)(b0 + lane) * N + m] : 0.f;
+        int yv = b0 + lane < B ? labels[b0 + lane] - l0 : -1;
+        {
+            uint4* z = reinterpret_cast<uint4*>(pos);
+            for (int i = threadIdx.x; i < CAVG_WAVES * lch * 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int l = threadIdx.x; l < nl; l += 256) cnt[l] = 0u;
+        }
         __syncthreads();
         unsigned* mine = pos + wv * lch * 64 + lane;
-        for (int b0 = wv * 64; b0 < B; b0 += CAVG_WAVES * 64) {
-            const int bi = b0 + lane;
-            const float sv = bi < B ? scores[(long)bi * N + m] : 0.f;
-            int yv = bi < B ? labels[bi] - l0 : -1;
+        for (; b0 < B; b0 += CAVG_WAVES * 64) {
+            const int b1 = b0 + CAVG_WAVES * 64;                      // the wave's next block: loaded before this one is walked
+            const float sv1 = b1 + lane < B ? scores[(long)(b1 + lane) * N + m] : 0.f;
+            const int yv1 = b1 + lane < B ? labels[b1 + lane] - l0 : -1;
             if (yv < 0 || yv >= nl) yv = -1;
             if (yv >= 0) atomicAdd(&cnt[yv], 1u);                     // examples per label (all thresholds share it)
             const int nb = min(64, B - b0);
@@ -776,38 +804,32 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
                 const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), j));
                 if (sj >= thr) atomicAdd(mine + y * 64, 1u);           // metrics.py:60
             }
+            sv = sv1;
+            yv = yv1;
         }
         __syncthreads();
-        // write-out, a wave's labels in batches of CAVG_BATCH: every counter load of a batch first, then the sums, then the stores
-        // (label by label it is one dependent read-modify-write round trip to HBM per label: 25 in a row at N = 100)
         if (th < Th) {
-            for (int lb = wv; lb < nl; lb += CAVG_WAVES * CAVG_BATCH) {
-                float* pa[CAVG_BATCH];
-                float* pb[CAVG_BATCH];
-                float va[CAVG_BATCH], vb[CAVG_BATCH];
 #pragma unroll
-                for (int u = 0; u < CAVG_BATCH; ++u) {
-                    const int l = lb + u * CAVG_WAVES, lab = l0 + l;
-                    const bool diag = lab == m;
-                    const long cell = diag ? (long)m * Th + th : ((long)lab * N + m) * Th + th;
-                    pa[u] = (diag ? tp : fp) + cell;                                   // :63-66 / :68-71
-                    pb[u] = (diag ? fn : tn) + cell;
-                    if (l < nl) {
-                        va[u] = *pa[u];
-                        vb[u] = *pb[u];
-                    }
+            for (int u = 0; u < CAVG_BATCH; ++u) {
+                const int l = wv + u * CAVG_WAVES;
+                if (l < nl) {
+                    unsigned pu = 0u;
+#pragma unroll
+                    for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
+                    float *pa, *pb;
+                    cells(l0 + l, pa, pb);
+                    *pa = va[u] + (float)pu;
+                    *pb = vb[u] + (float)(cnt[l] - pu);                                // s < thr  (:61)
                 }
+            }
+            for (int l = wv + CAVG_BATCH * CAVG_WAVES; l < nl; l += CAVG_WAVES) {       // label chunks past 100: one by one
+                unsigned pu = 0u;
 #pragma unroll
-                for (int u = 0; u < CAVG_BATCH; ++u) {
-                    const int l = lb + u * CAVG_WAVES;
-                    if (l < nl) {
-                        unsigned pu = 0u;
-#pragma unroll
-                        for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
-                        *pa[u] = va[u] + (float)pu;
-                        *pb[u] = vb[u] + (float)(cnt[l] - pu);                          // s < thr  (:61)
-                    }
-                }
+                for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
+                float *pa, *pb;
+                cells(l0 + l, pa, pb);
+                *pa += (float)pu;
+                *pb += (float)(cnt[l] - pu);
             }
         }
         __syncthreads();
