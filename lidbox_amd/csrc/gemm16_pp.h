@@ -109,7 +109,10 @@ constexpr int PP_EPI_BYTES = 32 * PP_EPI_LDW * 4;                // 8 704 bytes 
 template <int MI, int NJ>
 __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float* __restrict__ wlds, long mrow0, int ncol0, int lane, long m_beg,
                                               long M, int N, int epi, const float* __restrict__ aux, const RowsOutD& Cd, float* __restrict__ P,
-                                              int split, unsigned short* __restrict__ shadow, const unsigned short* __restrict__ mask16) {
+                                              int split, unsigned short* __restrict__ shadow, const unsigned short* __restrict__ mask16,
+                                              const unsigned (&mbits_v)[MI], bool mbits) {
+    // mbits: mbits_v holds the ReLU decisions of this lane's chunks, bit 8 c + j = element j of chunk c = 4 strip + 2 half + i,
+    // collected during the K loop (pp_mask_prefetch below) -- the strips that take the vector path then load no mask
     static_assert(NJ == 2, "pp_store_tile: 64-column strips");
     const int h = lane >> 5, l = lane & 31;
     const bool partial = gridDim.y > 1;
@@ -173,7 +176,7 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
             }
             u32x4_t mk[2];
             f32x4 ma[2], mb[2], oa[2], ob[2];
-            if (has_mask) {
+            if (has_mask && !mbits) {
                 if (mask16) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) mk[i] = ld16(mask16 + off[i]);
@@ -197,7 +200,12 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
                 const float* src = wlds + ((lane >> 3) + 8 * (2 * half + i)) * PP_EPI_LDW + (lane & 7) * 8;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
                 float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                if (has_mask) {
+                if (has_mask && mbits) {
+                    const int c = bi * 4 + 2 * half + i;
+                    const unsigned byte = mbits_v[c >> 2] >> (8 * (c & 3));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = ((byte >> j) & 1u) ? x[j] : 0.f;
+                } else if (has_mask) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float mvj = mask16 ? __builtin_bit_cast(float, (j & 1) ? (mk[i][j >> 1] & 0xffff0000u) : (mk[i][j >> 1] << 16))
@@ -286,11 +294,74 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
     }
 }
 
+// The ReLU mask of a dgrad epilogue, fetched DURING the K loop.  With one workgroup per CU every tile of a round reaches its
+// epilogue at the same time: 256 x (128 KB of mask + 128 KB of output) hit HBM in one burst (~6 us of a ~27 us K = 512 round for the
+// mask alone) while the memory system idles under the MFMA phases before it.  A lane's epilogue chunks (8 consecutive columns of a
+// row: pp_store_tile's vector path) are known up front, and only the SIGN of the mask matters: up to four 16-byte loads per batch
+// go out as inline-asm global loads right BEFORE a batch of LDS-DMA pieces whose covering counted `vmcnt` retires them as well
+// (VMEM operations retire in order), and are folded into one bit per element -- 4 x 32 bits per lane for a 128 x 64 wave tile.
+// Inline asm because hipcc waits vmcnt(0) for an ordinary load's first use, which would drain the DMA ring every step.
+template <int NCH>
+struct PpMaskPrefetch {
+    static constexpr int BATCH = 4;
+    unsigned bits[NCH / 4];
+    u32x4_t pend[BATCH];
+    int issued, folded;                     // chunks whose load has been issued / folded into bits (wave-uniform)
+    bool on;
+
+    __device__ __forceinline__ void init(bool enable) {
+        on = enable;
+        issued = folded = 0;
+#pragma unroll
+        for (int i = 0; i < NCH / 4; ++i) bits[i] = 0u;
+    }
+    // the next batch of loads: chunk c = 4 strip + k covers row mrow0 + 32 strip + (lane >> 3) + 8 k, columns ncol0 + 8 (lane & 7) ..
+    __device__ __forceinline__ void issue(const unsigned short* mask16, const RowsOutD& Cd, long mrow0, int ncol0, int lane) {
+        if (!on || issued >= NCH) return;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int c = issued + u;
+            if (c < NCH) {
+                const long R = mrow0 + (c >> 2) * 32 + (lane >> 3) + 8 * (c & 3);
+                const unsigned short* ptr = mask16 + row_offset(Cd, (unsigned)R) + ncol0 + (lane & 7) * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pend[u]) : "v"(ptr) : "memory");
+            }
+        }
+        issued = min(NCH, issued + BATCH);
+    }
+    // after the counted wait that covers the last issue(): fold the landed chunks into bits
+    __device__ __forceinline__ void fold() {
+        if (!on || folded >= issued) return;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int c = folded + u;
+            if (c < issued) {
+                asm volatile("" : "+v"(pend[u]));                    // the value is defined only behind the wait (asm statements keep their order)
+                unsigned byte = 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned w = pend[u][j >> 1];
+                    const float mv = __builtin_bit_cast(float, (j & 1) ? (w & 0xffff0000u) : (w << 16));
+                    byte |= (mv > 0.f ? 1u : 0u) << j;
+                }
+                // the chunk index is wave-uniform but not a compile-time constant, and an indexed register array would go to scratch:
+                // the words form one shift register -- a byte enters at the top, everything moves down 8 bits; after NCH chunks
+                // chunk c sits at bits 8 c .. 8 c + 7
+#pragma unroll
+                for (int wd = 0; wd + 1 < NCH / 4; ++wd) bits[wd] = __builtin_amdgcn_alignbyte(bits[wd + 1], bits[wd], 1);
+                bits[NCH / 4 - 1] = (bits[NCH / 4 - 1] >> 8) | (byte << 24);
+            }
+        }
+        folded = issued;
+    }
+    __device__ __forceinline__ bool complete() const { return on && folded >= NCH; }
+};
+
 // C[M,N] = epi(A[M,K] . B[N,K]^T), bf16 operands, fp32 accumulate; 512 threads, tile 256 x BN (BN = 256: waves 2 x 4, 128 x 64
 // each; BN = 128: waves 4 x 2, 64 x 64 each); grid.x = [carried reduce blocks] + tiles (XCD-chunk remapped), grid.y = K splits.
 // LDS: an A ring of THREE stages (3 x 32 KB) and a B ring of two (2 x BN x 128 B): 160 KB at BN = 256, the whole CU.
 // LBX_PP_ABLATE (measurement builds only, results are wrong): 1 = no LDS-DMA issue after the prologue, 2 = operand fetches of the
-// first sub-step only, 4 = no MFMAs, 8 = no barriers inside the loop, 16 = no epilogue, 32 = no DMA at all (with 1)
+// first sub-step only, 4 = no MFMAs, 8 = no barriers inside the loop, 16 = no epilogue, 32 = no DMA at all (with 1), 64 = no mask prefetch
 #ifndef LBX_PP_ABLATE
 #define LBX_PP_ABLATE 0
 #endif
@@ -342,6 +413,17 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // the dgrad epilogue's ReLU mask rides in the K loop when the wave's whole tile takes the epilogue's vector path
+    const bool mask_epi = gridDim.y == 1 && mask16 && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);
+    PpMaskPrefetch<MI * 4> mp;
+    // Built, parity-green, and SLOWER (profiles/r05_bf16_pp_mask_prefetch_ab.txt: dgrads +4 ... +6 us at bs 512, the configs[4] step 1.091 vs
+    // 1.070 ms): 16 row-offset divisions, 16 loads and ~400 fold instructions per lane and 28 more registers inside the K loop cost
+    // more than the 6 us of mask traffic they take out of the epilogue burst.  Compiled out (-DLBX_PP_MASK_PREFETCH=1 brings it back).
+#ifndef LBX_PP_MASK_PREFETCH
+#define LBX_PP_MASK_PREFETCH 0
+#endif
+    mp.init(LBX_PP_MASK_PREFETCH && !(LBX_PP_ABLATE & 64) && mask_epi && n >= 4 && m0 + rowA + 32 * MI <= M && n0 + rowB + 64 <= N && Cd.rs % 8 == 0 &&
+            (Cd.batch == 1 || Cd.bs % 8 == 0) && (((uintptr_t)mask16) & 15) == 0);
     PpPieces<NA> pa;
     PpPieces<NB> pb;
     pa.init(A, m0, M, kbeg, lane, wv * NA);
@@ -409,12 +491,14 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
         // prologue: A(0), B(0), then A(1), which stays in flight across the first hand-off
         issue_a(0, 0);
         issue_b(0, 0);
+        mp.issue(mask16, Cd, m0 + rowA, n0 + rowB, lane);      // older than A(1): the wait below retires it too
         if (n > 1) {
             issue_a(1, 1);
             sk_wait_vm<NA>();
         } else {
             sk_wait_vm<0>();
         }
+        mp.fold();
         pp_barrier();
         if (G == 1) pp_barrier();                              // phase 0 belongs to group 0 alone
         int sa = 0, sb = 0;                                    // A / B stages of the step being computed
@@ -428,11 +512,13 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
                 // B(t + 1) in the step's first LOAD phase (its stage was read last in the phase before), A(t + 2) in the last one
                 // (no deadline until two steps on): every LOAD phase of either group carries its share of the DMA traffic
                 if (j == 0 && more_b) issue_b(t + 1, sb ^ 1);
+                if (j == SUB - 1 && more_b) mp.issue(mask16, Cd, m0 + rowA, n0 + rowB, lane);   // ahead of A(t + 2): retired by this step's wait
                 if (j == SUB - 1 && more_a) issue_a(t + 2, sa2);
                 pp_wait_lds();
                 if (G == 1 && j == SUB - 1 && more_b) {        // step t + 1's operands: everything but the A pieces just issued
                     if (more_a) sk_wait_vm<NA>();
                     else sk_wait_vm<0>();
+                    mp.fold();
                 }
                 pp_loop_barrier();
                 comp();
@@ -440,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
                     if (j == SUB - 1 && more_b) {
                         if (more_a) sk_wait_vm<NA>();
                         else sk_wait_vm<0>();
+                        mp.fold();
                     }
                     pp_loop_barrier();
                 } else if (!(j == SUB - 1 && !more_b)) {
@@ -467,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
         return;
     }
     pp_store_tile<MI, NJ>(acc, reinterpret_cast<float*>(smem16p + wv * PP_EPI_BYTES), m0 + rowA, n0 + rowB, lane, m_beg, M, N, epi, aux, Cd, P,
-                          split, C16, mask16);
+                          split, C16, mask16, mp.bits, mp.complete());
 }
 
 }  // namespace
