@@ -114,6 +114,11 @@ struct lidbox_feat_plan {
     int     seg_len, seg_steps;   // bins per segment; shuffle steps that combine a band's segments
     bool    seg_ok;          // the bands split into <= 64 segments of <= 32 bins
     float*  d_dct;           // [M][ncoef]
+    // Bluestein (chirp-z) path for fft_length that is not a power of two (bs_m2 == 0: not available, direct DFT)
+    int     bs_m2;           // convolution length: the power of two >= 2 nfft - 1 (<= 8192)
+    float2* d_bs_chirp;      // [nfft]  w_n = e^{-i pi n^2 / nfft}
+    float2* d_bs_bhat;       // [bs_m2] FFT of the wrapped conjugate chirp, scaled by 1 / bs_m2
+    float2* d_bs_tw;         // [bs_m2] e^{-2 pi i j / bs_m2}
     void*   d_block;         // single allocation backing all of the above
 };
 
@@ -214,6 +219,50 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
         const double a = -2.0 * M_PI * (double)j / (double)nfft;
         twN[j] = make_float2((float)cos(a), (float)sin(a));
     }
+    // Bluestein tables (fft_length not a power of two, 2 nfft - 1 <= 8192): X_k = w_k sum_n (x_n w_n) conj(w)_{k-n}, w_n = e^{-i pi n^2 / N}
+    // -- a circular convolution of length m2 >= 2 N - 1 done with power-of-two FFTs.  n^2 is reduced mod 2 N in integers (exact phase).
+    int m2 = 0;
+    std::vector<float2> bs_chirp(1), bs_bhat(1), bs_tw(1);
+    if (nfft >= 3 && (nfft & (nfft - 1)) != 0 && 2 * nfft - 1 <= 8192) {
+        m2 = 1;
+        while (m2 < 2 * nfft - 1) m2 <<= 1;
+        bs_chirp.resize(nfft);
+        std::vector<double> br(m2, 0.0), bi(m2, 0.0);
+        for (int n = 0; n < nfft; ++n) {
+            const long q = ((long)n * n) % (2L * nfft);
+            const double a = M_PI * (double)q / (double)nfft;
+            bs_chirp[n] = make_float2((float)cos(a), (float)-sin(a));
+            br[n] = cos(a); bi[n] = sin(a);                       // conj(w_n)
+            if (n > 0) { br[m2 - n] = cos(a); bi[m2 - n] = sin(a); }
+        }
+        // iterative radix-2 FFT of b in float64 on the host (once per plan)
+        for (int i = 1, j = 0; i < m2; ++i) {
+            int bit = m2 >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+        }
+        for (int len = 2; len <= m2; len <<= 1) {
+            const double ang = -2.0 * M_PI / (double)len;
+            for (int i = 0; i < m2; i += len)
+                for (int k = 0; k < len / 2; ++k) {
+                    const double wr = cos(ang * k), wi = sin(ang * k);
+                    const double ur = br[i + k], ui = bi[i + k];
+                    const double vr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi;
+                    const double vi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
+                    br[i + k] = ur + vr; bi[i + k] = ui + vi;
+                    br[i + k + len / 2] = ur - vr; bi[i + k + len / 2] = ui - vi;
+                }
+        }
+        bs_bhat.resize(m2);
+        bs_tw.resize(m2);
+        for (int j = 0; j < m2; ++j) {
+            bs_bhat[j] = make_float2((float)(br[j] / m2), (float)(bi[j] / m2));
+            const double a = -2.0 * M_PI * (double)j / (double)m2;
+            bs_tw[j] = make_float2((float)cos(a), (float)sin(a));
+        }
+    }
+    p->bs_m2 = m2;
     // DCT rows: c_k = sqrt(2/M) sum_n x_n cos(pi k (2n+1) / (2M)), k in [coef_begin, coef_end)
     std::vector<float> dct((size_t)M * p->ncoef + (p->ncoef == 0 ? 1 : 0));
     for (int n = 0; n < M; ++n)
@@ -237,7 +286,10 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     size_t o_dct = o_mw + al(wts.size() * 4);
     size_t o_sm = o_dct + al(dct.size() * 4);
     size_t o_sw = o_sm + al(seg_meta.size() * 4);
-    size_t total = o_sw + al(seg_w.size() * 4);
+    size_t o_bc = o_sw + al(seg_w.size() * 4);
+    size_t o_bh = o_bc + al(bs_chirp.size() * 8);
+    size_t o_bt = o_bh + al(bs_bhat.size() * 8);
+    size_t total = o_bt + al(bs_tw.size() * 8);
     char* blk = nullptr;
     if (hipMalloc((void**)&blk, total) != hipSuccess) {
         lidbox_set_error("lidbox_feat_plan_create: hipMalloc(%zu) failed", total);
@@ -263,6 +315,9 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     LBX_UP(o_dct, dct.data(), dct.size() * 4);
     LBX_UP(o_sm, seg_meta.data(), seg_meta.size() * 4);
     LBX_UP(o_sw, seg_w.data(), seg_w.size() * 4);
+    LBX_UP(o_bc, bs_chirp.data(), bs_chirp.size() * 8);
+    LBX_UP(o_bh, bs_bhat.data(), bs_bhat.size() * 8);
+    LBX_UP(o_bt, bs_tw.data(), bs_tw.size() * 8);
 #undef LBX_UP
     p->d_win512 = (float*)(blk + o_win512);
     p->d_tw256 = (float2*)(blk + o_tw256);
@@ -276,6 +331,9 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     p->d_dct = (float*)(blk + o_dct);
     p->d_seg_meta = (int*)(blk + o_sm);
     p->d_seg_w = (float*)(blk + o_sw);
+    p->d_bs_chirp = (float2*)(blk + o_bc);
+    p->d_bs_bhat = (float2*)(blk + o_bh);
+    p->d_bs_tw = (float2*)(blk + o_bt);
 
     // fused path limits: LDS tables must leave room for >= 2 workgroups per CU
     p->fused_ok = (nfft == 512) && (L <= 512) && (M <= 64) && (p->nnz <= 1024) &&
@@ -999,6 +1057,68 @@ __global__ __launch_bounds__(256) void pow2_fft_spectrogram_kernel(
     }
 }
 
+// fft_length that is not a power of two (tf.signal.stft takes any, reference audio.py:229): Bluestein's chirp-z transform.  One
+// workgroup per frame: a_n = x_n win_n w_n (zero beyond the frame), A = FFT_m2(a), C = A . Bhat (the plan's transform of the wrapped
+// conjugate chirp, 1 / m2 folded in), c = IFFT_m2(C) as conj(FFT(conj(C))), X_k = c_k w_k for k <= nfft / 2, then |.|^power.  Both
+// transforms are the radix-2 Stockham passes of pow2_fft_spectrogram_kernel over m2 complex points; LDS = 2 m2 x 8 bytes (128 KB at
+// the largest m2 = 8192, i.e. fft_length <= 4096).  O(m2 log m2) per frame against the direct DFT's O(N^2 / 2): 64 x 1 s at
+// fft_length 2000 runs ~20 x faster (tests/test_features_gpu.py).
+__device__ __forceinline__ float2* stockham_fft(float2* in, float2* outb, int n, const float2* __restrict__ tw, int tid) {
+    const int half = n >> 1;
+    for (int Ns = 1; Ns < n; Ns <<= 1) {
+        const int tw_step = n / (2 * Ns);                    // e^{-2 pi i k / (2 Ns)} = tw[k * n / (2 Ns)]
+        for (int j = tid; j < half; j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 w = tw[k * tw_step];
+            const float2 u0 = in[j], v = in[j + half];
+            const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            const int j0 = ((j - k) << 1) + k;
+            outb[j0] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            outb[j0 + Ns] = make_float2(u0.x - u1.x, u0.y - u1.y);
+        }
+        __syncthreads();
+        float2* tmp = in; in = outb; outb = tmp;
+    }
+    return in;                                               // the buffer that holds the result
+}
+
+__global__ __launch_bounds__(256) void bluestein_spectrogram_kernel(
+    const float* __restrict__ signals, long sig_stride, int T, int L, int S, int nfft, int F, int m2,
+    const float* __restrict__ win, const float2* __restrict__ chirp, const float2* __restrict__ bhat, const float2* __restrict__ tw,
+    float power, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* buf0 = reinterpret_cast<float2*>(smem);
+    float2* buf1 = buf0 + m2;
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int Leff = L < nfft ? L : nfft;
+    const float* src = signals + (long)b * sig_stride + (long)t * S;
+    for (int n = tid; n < m2; n += 256) {
+        float2 v = make_float2(0.f, 0.f);
+        if (n < Leff) {
+            const float x = src[n] * win[n];
+            const float2 w = chirp[n];
+            v = make_float2(x * w.x, x * w.y);
+        }
+        buf0[n] = v;
+    }
+    __syncthreads();
+    float2* A = stockham_fft(buf0, buf1, m2, tw, tid);
+    float2* other = A == buf0 ? buf1 : buf0;
+    for (int k = tid; k < m2; k += 256) {                    // conj(A . Bhat): the inverse transform as conj(FFT(conj(.)))
+        const float2 a = A[k], h = bhat[k];
+        A[k] = make_float2(a.x * h.x - a.y * h.y, -(a.x * h.y + a.y * h.x));
+    }
+    __syncthreads();
+    const float2* c = stockham_fft(A, other, m2, tw, tid);
+    float* dst = out + ((long)b * T + t) * F;
+    for (int k = tid; k < F; k += 256) {
+        const float2 y = make_float2(c[k].x, -c[k].y), w = chirp[k];
+        const float xr = y.x * w.x - y.y * w.y, xi = y.x * w.y + y.y * w.x;
+        const float p2 = xr * xr + xi * xi;
+        dst[k] = (power == 2.0f) ? p2 : powf(p2, 0.5f * power);
+    }
+}
+
 // thread per (frame, band): banded mel (+ optional log)
 __global__ void generic_mel_kernel(const float* __restrict__ spec, long nframes, int F, int M,
                                    const int* __restrict__ ms, const int* __restrict__ mc,
@@ -1218,6 +1338,13 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
             LBX_HIP(hipFuncSetAttribute((const void*)pow2_fft_spectrogram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(pow2_fft_spectrogram_kernel, dim3(T, B), dim3(256), lds, st,
                            signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN, p->power, spec);
+    } else if (p->bs_m2 && !force_dft) {
+        // any other length up to 4096: Bluestein on two power-of-two transforms of bs_m2 points
+        const size_t lds = (size_t)p->bs_m2 * 16;
+        if (lds > 65536)
+            LBX_HIP(hipFuncSetAttribute((const void*)bluestein_spectrogram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(bluestein_spectrogram_kernel, dim3(T, B), dim3(256), lds, st, signals, sig_stride, T, p->L, p->S, p->nfft, p->F,
+                           p->bs_m2, p->d_win, p->d_bs_chirp, p->d_bs_bhat, p->d_bs_tw, p->power, spec);
     } else {
         hipLaunchKernelGGL(generic_spectrogram_kernel, dim3(T, B), dim3(256), (size_t)Leff * 4, st,
                            signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN,

@@ -128,15 +128,17 @@ def test_generic_path_other_fft_lengths(wav_paths):
 
 
 def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths):
-    """fft_length != 512: powers of two run the LDS radix-2 FFT kernel (O(N log N)), other lengths the direct DFT; both
-    against the oracle, the largest accepted length (16384) included, plus log-mel / MFCC on top of the FFT kernel"""
+    """fft_length != 512: powers of two run the LDS radix-2 FFT kernel (O(N log N)), other lengths up to 4096 Bluestein's chirp-z
+    transform on two power-of-two FFTs (tf.signal.stft takes any fft_length, reference audio.py:229), longer ones the direct DFT;
+    all against the oracle, the largest accepted length (16384) included, plus log-mel / MFCC on top of the FFT kernels"""
     import time
     from lidbox_amd.features import audio
     from lidbox_amd.data import tf_utils
     s, r = fo.read_wav_pcm16(wav_paths[2])
     x = _dev(np.stack([s[:16000], s[4000:20000], s[8000:24000]]))
     ref_in = np.stack([s[:16000], s[4000:20000], s[8000:24000]])
-    for n_fft, len_ms in ((128, 5), (1024, 25), (4096, 100), (16384, 500), (600, 25), (1000, 60)):
+    for n_fft, len_ms in ((128, 5), (1024, 25), (4096, 100), (16384, 500), (600, 25), (1000, 60), (400, 25), (401, 25), (1009, 50), (2000, 100),
+                          (4095, 250), (3, 1), (6000, 300)):
         got = audio.spectrograms(x, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft).cpu().numpy()
         ref = fo.spectrograms(ref_in, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft)
         assert got.shape == ref.shape and got.shape[2] == n_fft // 2 + 1
@@ -147,10 +149,14 @@ def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths):
     got = tf_utils.extract_features(x, [r] * 3, "mfcc", spec_kwargs=dict(fft_length=2048)).cpu().numpy()
     ref = fo.extract_features(ref_in, [r] * 3, "mfcc", spec_kwargs=dict(fft_length=2048))
     assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-3
-    # the FFT kernel is not a slower way to the same numbers: 64 x 1 s at fft_length 2048 vs the direct DFT of length 2000
+    got = tf_utils.extract_features(x, [r] * 3, "logmelspectrogram", spec_kwargs=dict(fft_length=400)).cpu().numpy()      # fft_length == frame_length
+    ref = fo.extract_features(ref_in, [r] * 3, "logmelspectrogram", spec_kwargs=dict(fft_length=400))
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-3
+    # the FFT kernels are not a slower way to the same numbers: 64 x 1 s at fft_length 2048 (radix-2), 2000 (Bluestein, two 4096-point
+    # transforms) and 4500 (past Bluestein's range: the direct DFT)
     big = torch.randn(64, 16000, device="cuda") * 0.1
     times = {}
-    for n_fft in (2048, 2000):
+    for n_fft in (2048, 2000, 4500):
         audio.spectrograms(big, 16000, frame_length_ms=100, fft_length=n_fft)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -158,7 +164,7 @@ def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths):
             audio.spectrograms(big, 16000, frame_length_ms=100, fft_length=n_fft)
         torch.cuda.synchronize()
         times[n_fft] = (time.perf_counter() - t0) / 3
-    assert times[2048] < 0.5 * times[2000], times
+    assert times[2048] < times[2000] < 0.25 * times[4500], times
 
 
 def test_linear_to_mel_standalone(wav_paths):
