@@ -79,6 +79,13 @@ struct Dma16Operand {
     }
 };
 
+constexpr int D16_EPI_BYTES = 32 * 68 * 4;                  // one wave's 32-row x 64-column fp32 strip (gemm16_pp.h: PP_EPI_*)
+template <int MI, int NJ>
+__device__ __forceinline__ void d16_store_tile_wide(const f32x16 (&acc)[MI][NJ], float* __restrict__ wlds, long mrow0, int ncol0, int lane,
+                                                    long m_beg, long M, int N, int epi, const float* __restrict__ aux, const RowsOutD& Cd,
+                                                    float* __restrict__ P, int split, unsigned short* __restrict__ shadow,
+                                                    const unsigned short* __restrict__ mask16);
+
 template <int N>
 __device__ __forceinline__ void d16_wait_le() {
     sk_wait_vm<N>();
@@ -195,6 +202,25 @@ __global__ __launch_bounds__(256, OCC) void gemm16s_rows_dma_kernel(RowsH A, Row
         ++cur;
         if (cur == STAGES) cur = 0;
     }
+#ifndef LBX_D16_WIDE_EPI
+#define LBX_D16_WIDE_EPI 1
+#endif
+    // Epilogues that READ per element (ReLU mask, accumulate: the dgrads) take the 16-byte epilogue of the eight-wave tile
+    // (gemm16_pp.h: pp_store_tile) through a wave-private strip of the ring -- frame5 / frame4 dgrad 30.6 -> 28.8 / 15.4 -> 12.9 us at
+    // bs 256, 55.5 -> 49.2 / 26.7 -> 22.3 us at bs 512; store-only epilogues keep the row loop, which the other resident workgroups
+    // hide and which costs no LDS round trip (forward launches were 1-5 us slower on the strip: profiles/r05_bf16_wide_epilogue_ab.txt)
+    const bool reads = gridDim.y == 1 && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK || epi == LIDBOX_EPI_ACCUM ||
+                                          epi == LIDBOX_EPI_ACCUM_RELU);
+    if constexpr (LBX_D16_WIDE_EPI && NJ == 2 && STAGES * ST >= 4 * D16_EPI_BYTES) {
+        if (reads) {
+            // nobody reads the ring any more behind this barrier (the last step's DMAs were waited for before its own barrier)
+            __builtin_amdgcn_s_barrier();
+            d16_store_tile_wide<MI, NJ>(acc, reinterpret_cast<float*>(smem16d + wv * D16_EPI_BYTES), m0 + wm * (32 * MI), n0 + wn * (32 * NJ), lane,
+                                        m_beg, M, N, epi, aux, Cd, P, split, C16, mask16);
+            return;
+        }
+    }
+    (void)reads;
     store_rows_tile<MI, NJ, true>(acc, m0, n0, wm, wn, lane, m_beg, M, N, epi, aux, Cd, P, split, 0ull, false, C16, mask16);
 }
 

@@ -294,6 +294,16 @@ __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float
     }
 }
 
+// the same epilogue for the four-wave LDS-DMA tiles (gemm16_dma.h declares it ahead of its kernel)
+template <int MI, int NJ>
+__device__ __forceinline__ void d16_store_tile_wide(const f32x16 (&acc)[MI][NJ], float* __restrict__ wlds, long mrow0, int ncol0, int lane,
+                                                    long m_beg, long M, int N, int epi, const float* __restrict__ aux, const RowsOutD& Cd,
+                                                    float* __restrict__ P, int split, unsigned short* __restrict__ shadow,
+                                                    const unsigned short* __restrict__ mask16) {
+    const unsigned none[MI] = {};
+    pp_store_tile<MI, NJ>(acc, wlds, mrow0, ncol0, lane, m_beg, M, N, epi, aux, Cd, P, split, shadow, mask16, none, false);
+}
+
 // The ReLU mask of a dgrad epilogue, fetched DURING the K loop.  With one workgroup per CU every tile of a round reaches its
 // epilogue at the same time: 256 x (128 KB of mask + 128 KB of output) hit HBM in one burst (~6 us of a ~27 us K = 512 round for the
 // mask alone) while the memory system idles under the MFMA phases before it.  A lane's epilogue chunks (8 consecutive columns of a
