@@ -1008,7 +1008,7 @@ Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes, bool writes_fp32
         const long t256 = lbx_cdiv(M, 256L) * lbx_cdiv((long)N, 256L);
         const long r256 = lbx_cdiv(t256, (long)NUM_CU);
         static const bool no_pp = getenv("LIDBOX_GEMM16S_NO_PP") != nullptr;          // A/B aid
-        // (a launch that also writes the fp32 copy -- frame5's forward, 6 bytes per element -- pays a 256 x 256 epilogue twice over
+        // (a launch that writes fp32 -- frame5's forward, 4 or 6 bytes per element -- pays a 256 x 256 epilogue twice over
         // in a 1.5-round launch: bs 512 62 vs 57 us; it stays on the small tiles unless the contraction is long)
         if (!no_pp && !(writes_fp32 && K < 1024 && t256 > NUM_CU) &&
             ((K >= 512 && 4 * t256 >= 3 * r256 * NUM_CU) || (K >= 1500 && 2 * t256 >= r256 * NUM_CU))) {
@@ -1150,7 +1150,7 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
     const RowsH Ah_{(const __bf16*)A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch};
     const RowsH Bh_{(const __bf16*)B16, 0, ldb, 1, 0};
     {
-        const Dma16Choice dc = choose_dma16(M, N, K, ws ? ws_bytes : 0, Cd.base != nullptr && C16 != nullptr);
+        const Dma16Choice dc = choose_dma16(M, N, K, ws ? ws_bytes : 0, Cd.base != nullptr);
         // 32-bit byte offsets per lane inside the kernel: the operands' extents must fit
         const double a_ext = ((double)(A.batch - 1) * (double)A.batch_stride + (double)A.rows_per_batch * (double)A.row_stride + K) * 2.0;
         const double b_ext = ((double)N * (double)ldb + K) * 2.0;

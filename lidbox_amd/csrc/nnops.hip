@@ -797,18 +797,23 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
             const int yv1 = b1 + lane < B ? labels[b1 + lane] - l0 : -1;
             if (yv < 0 || yv >= nl) yv = -1;
             if (yv >= 0) atomicAdd(&cnt[yv], 1u);                     // examples per label (all thresholds share it)
-            const int nb = min(64, B - b0);
-            for (int j = 0; j < nb; ++j) {
+            // branch-free walk: an example that does not count (label outside the chunk, score below the threshold, lane past the
+            // batch: yv = -1) adds 0 to row 0 -- with branches an iteration cost ~145 cycles of exec-mask and scalar-branch traffic
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
                 const int y = __builtin_amdgcn_readlane(yv, j);       // wave-uniform
-                if (y < 0) continue;
                 const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), j));
-                if (sj >= thr) atomicAdd(mine + y * 64, 1u);           // metrics.py:60
+                const unsigned one = (y >= 0 && sj >= thr) ? 1u : 0u;  // metrics.py:60
+                atomicAdd(mine + max(y, 0) * 64, one);
             }
             sv = sv1;
             yv = yv1;
         }
         __syncthreads();
         if (th < Th) {
+            // every sum first, then every store: loads and stores retire through ONE in-order counter (vmcnt) on this chip, so a
+            // store issued between two uses of prefetched values makes the second use wait for the store's round trip (the
+            // first version of this loop: 25 dependent store round trips, 23 us for the kernel)
 #pragma unroll
             for (int u = 0; u < CAVG_BATCH; ++u) {
                 const int l = wv + u * CAVG_WAVES;
@@ -816,10 +821,18 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
                     unsigned pu = 0u;
 #pragma unroll
                     for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
+                    va[u] += (float)pu;
+                    vb[u] += (float)(cnt[l] - pu);                                     // s < thr  (:61)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CAVG_BATCH; ++u) {
+                const int l = wv + u * CAVG_WAVES;
+                if (l < nl) {
                     float *pa, *pb;
                     cells(l0 + l, pa, pb);
-                    *pa = va[u] + (float)pu;
-                    *pb = vb[u] + (float)(cnt[l] - pu);                                // s < thr  (:61)
+                    *pa = va[u];
+                    *pb = vb[u];
                 }
             }
             for (int l = wv + CAVG_BATCH * CAVG_WAVES; l < nl; l += CAVG_WAVES) {       // label chunks past 100: one by one
