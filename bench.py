@@ -240,6 +240,9 @@ class KernelTimer:
                         key = "gemm16s_rows_pp_kernel<%d, %d>" % (out3[1], out3[2])
                     elif out3[0]:
                         key = "gemm16s_rows_dma_kernel<%d, %d, %d>" % (out3[0], out3[1], out3[2])
+                elif self.ENTRY[_n] in (14, 16):
+                    if self.nv.lib.lidbox_gemm_bf16s_tn_last_pp() > 0:     # the ping-pong wgrad tile (gemm16_pp_tn.h)
+                        key = "gemm16s_tn_pp_kernel"
                 self.records.setdefault(key, []).append((e0, e1, work, nk))
                 return rc
             setattr(self.nv.lib, name, wrapper)

@@ -348,6 +348,11 @@ int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, long ldb, lid
                                int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
                                const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream);
 int lidbox_gemm_bf16s_last_carried(void);
+/* Kernel variant of the calling thread's most recent lidbox_gemm_bf16s_tn / _tn_partial (tests, profiling tools): the number of M
+ * slices of the 256 x 256 eight-wave ping-pong tile (gemm16_pp_tn.h) if that ran, 0 for the four-wave 128 x 128 kernel.  The tile
+ * is chosen for long slices of big layers (K1, N multiples of 256, >= 8 tiles, >= 2048 rows per slice: frame2's wgrad at 512
+ * utterances); LIDBOX_GEMM16_TN_PP=0 / 1 in the environment forces never / whenever the operands allow (tuning aid). */
+int lidbox_gemm_bf16s_tn_last_pp(void);
 /* All bf16 weight shadows of a model in ONE launch (once per train step, after the optimizer): flat16[i] = bf16(flat[i]) for
  * the n parameters, and for each listed row-major [rows][cols] matrix at flat + offset a bf16 image at dst with its own
  * leading dimension: transposed ([cols][rows]: a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand

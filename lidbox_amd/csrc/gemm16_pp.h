@@ -110,12 +110,13 @@ template <int MI, int NJ>
 __device__ __forceinline__ void pp_store_tile(const f32x16 (&acc)[MI][NJ], float* __restrict__ wlds, long mrow0, int ncol0, int lane, long m_beg,
                                               long M, int N, int epi, const float* __restrict__ aux, const RowsOutD& Cd, float* __restrict__ P,
                                               int split, unsigned short* __restrict__ shadow, const unsigned short* __restrict__ mask16,
-                                              const unsigned (&mbits_v)[MI], bool mbits) {
+                                              const unsigned (&mbits_v)[MI], bool mbits, int partial_override = -1) {
     // mbits: mbits_v holds the ReLU decisions of this lane's chunks, bit 8 c + j = element j of chunk c = 4 strip + 2 half + i,
     // collected during the K loop (pp_mask_prefetch below) -- the strips that take the vector path then load no mask
     static_assert(NJ == 2, "pp_store_tile: 64-column strips");
     const int h = lane >> 5, l = lane & 31;
-    const bool partial = gridDim.y > 1;
+    // partial_override: 0 / 1 from kernels whose splits are not grid.y (the wgrad tile: raw sums to P[split][row][n])
+    const bool partial = partial_override < 0 ? gridDim.y > 1 : partial_override != 0;
     const bool has_bias = !partial && (epi == LIDBOX_EPI_BIAS || epi == LIDBOX_EPI_BIAS_RELU);
     const bool do_relu = !partial && (epi == LIDBOX_EPI_BIAS_RELU || epi == LIDBOX_EPI_ACCUM_RELU || epi == LIDBOX_EPI_RELU);
     const bool has_mask = !partial && (epi == LIDBOX_EPI_RELU_MASK || epi == LIDBOX_EPI_ACCUM_RELU_MASK);

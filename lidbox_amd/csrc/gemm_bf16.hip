@@ -569,6 +569,7 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
 }  // namespace
 #include "gemm16_dma.h"
 #include "gemm16_pp.h"
+#include "gemm16_pp_tn.h"
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -917,6 +918,33 @@ Tn16Plan plan_tn16(long M, int K1, int N, int BK = 32) {
     return Tn16Plan{(int)lbx_cdiv(M, rps), rps};
 }
 
+// the 256 x 256 ping-pong wgrad tile (gemm16_pp_tn.h): one workgroup per CU, so the slices are cut for ONE round of the chip.
+// Shape part of the decision (the workspace query sees only this); the launch also needs descriptors it can address (below).
+struct TnPpPlan {
+    bool use;
+    int splits;
+    long rows_per_split;
+};
+
+TnPpPlan plan_tn16_pp(long M, int K1, int N) {
+    TnPpPlan pl{false, 1, M};
+    const long tiles = lbx_cdiv(K1, PPT_BT) * lbx_cdiv(N, PPT_BT);
+    int mode = -1;                                   // LIDBOX_GEMM16_TN_PP = 0 | 1: never | whenever it can run (tuning aid)
+    if (const char* e = getenv("LIDBOX_GEMM16_TN_PP")) mode = atoi(e);
+    if (mode == 0 || tiles > NUM_CU || M >= (1L << 31) - PPT_BM) return pl;
+    long s = NUM_CU / tiles;
+    const long max_s = lbx_cdiv(M, 4 * PPT_BM);      // at least four K steps per slice
+    if (s > max_s) s = max_s;
+    if (const char* e = getenv("LIDBOX_GEMM16_TN_PP_SPLITS")) { const long v = atol(e); if (v >= 1) s = v; }
+    if (s < 1) s = 1;
+    pl.rows_per_split = lbx_cdiv(lbx_cdiv(M, s), PPT_BM) * PPT_BM;
+    pl.splits = (int)lbx_cdiv(M, pl.rows_per_split);
+    // worth it where the tile is full and the slices are long: the big conv layers (measured: profiles/r05_bf16_pp_wgrad.txt)
+    const bool full = K1 % PPT_BT == 0 && N % PPT_BT == 0;
+    pl.use = mode == 1 || (full && tiles >= 8 && tiles * pl.splits >= (3 * NUM_CU) / 4 && pl.rows_per_split >= 2048);
+    return pl;
+}
+
 const char* const ALIGN_MSG =
     "bf16 path needs 16-byte aligned operands and K, N, leading dimensions and row strides that are multiples of 4";
 
@@ -1095,6 +1123,7 @@ int launch_rows16s_pp_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh,
 }
 
 thread_local int g16_last_carried = 0;                 // jobs the calling thread's last lidbox_gemm_bf16s_nt_carry ran inside its GEMM launch
+thread_local int g16_tn_last_pp = 0;                   // slices of the calling thread's last storage wgrad if the ping-pong tile ran it, else 0
 thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the calling thread's last lidbox_gemm_bf16s_nt (0: register-staged)
 
 int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
@@ -1260,6 +1289,7 @@ extern "C" int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, lo
 }
 
 extern "C" int lidbox_gemm_bf16s_last_carried(void) { return g16_last_carried; }
+extern "C" int lidbox_gemm_bf16s_tn_last_pp(void) { return g16_tn_last_pp; }
 
 extern "C" int lidbox_gemm_bf16s_last_variant(int* out3) {
     LBX_ARG(out3, "out3 != NULL");
@@ -1270,7 +1300,9 @@ extern "C" int lidbox_gemm_bf16s_last_variant(int* out3) {
 extern "C" size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N) {
     if (M <= 0 || K1 <= 0 || N <= 0) return 0;
     const Tn16Plan pl = plan_tn16(M, K1, N, BKT);
-    return ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
+    const TnPpPlan pp = plan_tn16_pp(M, K1, N);
+    const int splits = pp.use && pp.splits > pl.splits ? pp.splits : pl.splits;      // either kernel may run (descriptor checks at launch)
+    return ((size_t)splits * K1 * N + (size_t)splits * N) * sizeof(float);
 }
 
 extern "C" int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* Cm, long ldc, int K1, int N, int accumulate,
@@ -1308,10 +1340,49 @@ extern "C" int lidbox_gemm_bf16s_tn_partial(lidbox_rows_t A16, lidbox_rows_t B16
     LBX_ARG(ok16(A16) && ok16(B16) && width_ok(A16, K1) && width_ok(B16, N) && aligned16(workspace),
             "bf16-storage operands need 16-byte aligned bases, row and batch strides (in bf16 elements) that are multiples of 8, and "
             "K1 / N that are multiples of 8 or rows padded to one");
-    const Tn16Plan pl = plan_tn16(M, K1, N, BKT);
+    Tn16Plan pl = plan_tn16(M, K1, N, BKT);
+    TnPpPlan pp = plan_tn16_pp(M, K1, N);
+    // the ping-pong tile addresses a row as a 32-bit byte offset from the tile's first column and walks both operands with one
+    // (utterance, row) counter: same utterance length on both sides, everything within 4 GB of the base, whole 16-byte chunks
+    auto span_ok = [&](const lidbox_rows_t& r, int w) {
+        const double span = ((double)(r.batch - 1) * (double)r.batch_stride + (double)(r.rows_per_batch - 1) * (double)r.row_stride + w) * 2.0;
+        return r.batch_stride >= 0 && r.row_stride >= 0 && span < 4.0e9;
+    };
+    if (pp.use && !(span_ok(A16, K1) && span_ok(B16, N) && K1 % 8 == 0 && N % 8 == 0 &&
+                    ((A16.batch == 1 && B16.batch == 1) || (A16.batch == B16.batch && A16.rows_per_batch == B16.rows_per_batch))))
+        pp.use = false;
+    if (pp.use) pl = Tn16Plan{pp.splits, pp.rows_per_split};
+    g16_tn_last_pp = pp.use ? pp.splits : 0;
     const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
     LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_bf16s_tn_workspace)");
     hipStream_t st = (hipStream_t)stream;
+    if (pp.use) {
+        int dev = 0;
+        LBX_HIP(hipGetDevice(&dev));
+        static std::atomic<unsigned long long> attr_set{0};
+        if (dev < 64 && !((attr_set.load() >> dev) & 1ull)) {
+            LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PPT_LDS_BYTES));
+            attr_set.fetch_or(1ull << dev);
+        }
+        const int tiles_n = (int)lbx_cdiv(N, PPT_BT);
+        const int ntiles = (int)(lbx_cdiv(K1, PPT_BT) * tiles_n);
+        float* P = (float*)workspace;
+        float* Pc = bias_grad ? P + (size_t)pl.splits * K1 * N : nullptr;
+        const RowsH Ah{(const __bf16*)A16.base, A16.batch_stride, A16.row_stride, A16.batch, A16.rows_per_batch};
+        const RowsH Bh{(const __bf16*)B16.base, B16.batch_stride, B16.row_stride, B16.batch, B16.rows_per_batch};
+        hipLaunchKernelGGL(gemm16s_tn_pp_kernel, dim3((unsigned)(ntiles * pl.splits)), dim3(512), PPT_LDS_BYTES, st, Ah, Bh, P, Pc, M, K1, N,
+                           tiles_n, ntiles, pl.rows_per_split);
+        LBX_LAUNCH_OK();
+        const long n = (long)K1 * N;
+        if (reduce_job_vec_ok(P, Pc, pl.splits, n, N, Cm, ldc, bias_grad)) {
+            const ReduceJob j = make_reduce_job(P, Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad);
+            memcpy(job, &j, sizeof j);
+            return LIDBOX_OK;
+        }
+        launch_splitk_reduce((const float*)P, (const float*)Pc, pl.splits, n, N, Cm, ldc, accumulate, bias_grad, st);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    }
     const size_t lds_bytes = 4 * (size_t)TILE_T * sizeof(__bf16);
     static bool lds_attr_set = false;
     if (lds_bytes > 65536 && !lds_attr_set) {

@@ -424,6 +424,80 @@ def test_bf16_storage_gemm_tn_implicit_rows_and_errors(Bn, T, C, k, s_, Co):
         nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW), Co, K1, Co, 0, None, nv.ptr(ws), 8, st))
 
 
+@pytest.mark.parametrize("Bn,T,C,k,s_,Co", [(40, 99, 128, 3, 3, 256),      # utterances of 33 rows: a wrap inside most 32-row steps
+                                            (300, 7, 64, 2, 1, 256),       # 7-row utterances: several wraps per step and per piece
+                                            (6, 700, 256, 2, 2, 512),      # long utterances, 2 x 2 tiles
+                                            (9, 130, 40, 5, 1, 264),       # K1 = 200, N = 264: tiles that hang over both edges
+                                            (1, 5000, 512, 1, 1, 512)])    # flat rows, a slice that ends inside a step
+def test_bf16_storage_wgrad_pingpong_tile(Bn, T, C, k, s_, Co, monkeypatch):
+    """gemm16s_tn_pp_kernel (256 x 256 eight-wave tile of the storage wgrad, LDS-DMA rows + transpose reads), forced on shapes the
+    policy would leave to the four-wave kernel: the float64 product of the stored values, the bias gradient off the matrix
+    pipe, accumulate, run-to-run identical, and equal to round-off with the four-wave kernel's result"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(Bn * 1000 + T)
+    pad = k - 1
+    x = np.zeros((Bn, pad + T, C))
+    x[:, pad:] = rng.standard_normal((Bn, T, C))
+    To = (T - 1) // s_ + 1
+    dy = rng.standard_normal((Bn, To, Co)) * (1.0 + 0.01 * np.arange(Co))[None, None, :]
+    idx = np.arange(To)[:, None] * s_ + np.arange(k)[None, :]
+    col = _bf16(x)[:, idx, :].reshape(Bn * To, k * C)
+    ref = col.T @ _bf16(dy).reshape(Bn * To, Co)
+    st = nv.current_stream()
+    x16, dy16 = _dev(x).bfloat16(), _dev(dy).bfloat16()
+    M, K1 = Bn * To, k * C
+    ra = nv.Rows(x16.data_ptr(), (pad + T) * C, s_ * C, Bn, To)
+    rb = nv.Rows(dy16.data_ptr(), To * Co, Co, Bn, To)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LIDBOX_GEMM16_TN_PP", mode)
+        wsb = nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, Co)
+        ws = _ws(wsb)
+        dW = torch.full((K1, Co), -1.0, device="cuda")
+        db = torch.zeros(Co, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws), wsb, st))
+        assert (nv.lib.lidbox_gemm_bf16s_tn_last_pp() > 0) == (mode == "1")
+        _close(dW.cpu().numpy(), ref)
+        _close(db.cpu().numpy(), _bf16(dy).reshape(M, Co).sum(axis=0), 1e-5)
+        dW2 = dW.clone()
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW2), Co, K1, Co, 1, None, nv.ptr(ws), wsb, st))
+        _close(dW2.cpu().numpy(), 2 * ref)
+        dW3 = torch.empty_like(dW)
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW3), Co, K1, Co, 0, None, nv.ptr(ws), wsb, st))
+        assert torch.equal(dW, dW3)
+        out[mode] = dW.cpu().double().numpy()
+    _close(out["1"], out["0"], rel=1e-5)
+
+
+def test_bf16_storage_wgrad_pingpong_policy_and_fallback(monkeypatch):
+    """the ping-pong wgrad tile runs where it was measured faster (frame2's wgrad at 512 utterances: 12 tiles x 21 slices of 2 432
+    rows) and nowhere else by default; operands it cannot walk with one utterance counter fall back even when it is forced"""
+    from lidbox_amd import _native as nv
+    monkeypatch.delenv("LIDBOX_GEMM16_TN_PP", raising=False)
+    st = nv.current_stream()
+
+    def run(M, K1, N, batched_b=None):
+        a16 = torch.randn(M, K1, device="cuda").bfloat16()
+        b16 = torch.randn(M, N, device="cuda").bfloat16()
+        wsb = nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, N)
+        ws = _ws(wsb)
+        c = torch.empty(K1, N, device="cuda")
+        ra = nv.Rows(a16.data_ptr(), 0, K1, 1, M)
+        rb = nv.Rows(b16.data_ptr(), 0, N, 1, M) if batched_b is None else nv.Rows(b16.data_ptr(), batched_b * N, N, M // batched_b, batched_b)
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(c), N, K1, N, 0, None, nv.ptr(ws), wsb, st))
+        torch.cuda.synchronize()
+        ref = a16.double().T @ b16.double()
+        assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        return nv.lib.lidbox_gemm_bf16s_tn_last_pp()
+
+    assert run(512 * 99, 1536, 512) == 21
+    assert run(256 * 99, 1536, 512) == 0          # 1 216-row slices: the partial sums outweigh the faster loop
+    assert run(512 * 33, 512, 512) == 0           # 4 tiles
+    monkeypatch.setenv("LIDBOX_GEMM16_TN_PP", "1")
+    assert run(8448, 512, 512) > 0
+    assert run(8448, 512, 512, batched_b=33) == 0  # A flat, B in utterances of 33 rows: the four-wave kernel
+
+
 def test_refresh_bf16_weights_one_launch():
     """flat -> flat16 plus bf16 images of listed matrices inside it (the per-step weight-shadow refresh): transposed,
     row-padded, and blocks side by side in one destination"""
