@@ -393,6 +393,12 @@ int lidbox_colsum(lidbox_rows_t A, int N, float* out, int accumulate, void* work
  * CSR) give each utterance's first one.  All entry points are stream-ordered; data-dependent sizes come back as
  * counters for the caller to size the next buffer (the reference's eager tensors do the same). */
 
+/* features/audio.py:17-23 (tf.audio.decode_wav + reduce_mean over the channel axis) for 16-bit PCM already in device memory:
+ * pcm = frames x channels interleaved int16 (a ragged batch of utterances with the same channel count is one flat call),
+ * out[f] = (sum_c pcm[f][c] / 32768) / channels in fp32 -- bit-identical to the reference's float32 arithmetic (the scaled
+ * samples and their sums are exact, the division rounds once).  Halves the bytes an ingest pipeline moves over PCIe. */
+int lidbox_pcm16_to_f32(const int16_t* pcm, long frames, int channels, float* out, lidbox_stream_t stream);
+
 /* data/steps.py:586-588,604-614 in float32 like the reference's tf.cast chain:
  * out4 = {chunk_length, chunk_step, padded signal length, number of chunks} (host only) */
 int lidbox_signal_chunk_plan(long num_samples, int sample_rate, int length_ms, int step_ms, int max_pad_ms,

@@ -124,6 +124,7 @@ _SIGS = {
     "lidbox_vad_decisions": (_i, [_vp, _vp, _i, _l, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "lidbox_vad_scan": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "lidbox_segment_mean": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "lidbox_pcm16_to_f32": (_i, [_vp, _l, _i, _vp, _vp]),
     "lidbox_apply_vad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp, _vp]),
     "lidbox_signal_chunks": (_i, [_vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp, _vp]),
     "lidbox_peak_normalize": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp]),

@@ -851,26 +851,40 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
 
 __device__ __forceinline__ float div_no_nan(float a, float b) { return b != 0.f ? a / b : 0.f; }
 
-__global__ __launch_bounds__(256) void cavg_result_kernel(const float* __restrict__ tp,
-                                                          const float* __restrict__ fn,
-                                                          const float* __restrict__ fp,
-                                                          const float* __restrict__ tn, int N, int Th,
-                                                          float C_miss, float C_fa, float P_tar,
-                                                          float* __restrict__ c_avg_out,
-                                                          float* __restrict__ out) {
-    __shared__ float red[4];
+// One workgroup (the result is a min over thresholds of sums over languages: a few million divisions, once per evaluation).
+// G = 1024 / Th groups of Th threads: group g computes the inner false-alarm sums of languages g, g + G, ... into LDS
+// (`lds_pf` = N x Th floats; 0 when that does not fit: every thread then walks all languages itself), then thread th adds them
+// up in language order -- the same order, hence the same bits, with or without the LDS pass.
+__global__ __launch_bounds__(1024) void cavg_result_kernel(const float* __restrict__ tp,
+                                                           const float* __restrict__ fn,
+                                                           const float* __restrict__ fp,
+                                                           const float* __restrict__ tn, int N, int Th,
+                                                           float C_miss, float C_fa, float P_tar, int lds_pf,
+                                                           float* __restrict__ c_avg_out,
+                                                           float* __restrict__ out) {
+    extern __shared__ float pf_l[];
+    __shared__ float red[16];
+    auto inner_of = [&](int l, int th) {
+        float inner = 0.f;
+        for (int m = 0; m < N; ++m) {
+            const float f = fp[((long)l * N + m) * Th + th], t = tn[((long)l * N + m) * Th + th];
+            inner += div_no_nan(f, f + t);                                      // metrics.py:89-95
+        }
+        return div_no_nan(inner, (float)(N - 1));
+    };
+    if (lds_pf) {
+        const int G = 1024 / Th, g = threadIdx.x / Th, th = threadIdx.x % Th;
+        if (g < G)
+            for (int l = g; l < N; l += G) pf_l[l * Th + th] = inner_of(l, th);
+        __syncthreads();
+    }
     float best = FLT_MAX;
-    for (int th = threadIdx.x; th < Th; th += 256) {
+    for (int th = threadIdx.x; th < Th; th += 1024) {
         float pm = 0.f, pf = 0.f;
         for (int l = 0; l < N; ++l) {
             const float a = fn[(long)l * Th + th], b = tp[(long)l * Th + th];
             pm += div_no_nan(a, a + b);                                         // metrics.py:80-85
-            float inner = 0.f;
-            for (int m = 0; m < N; ++m) {
-                const float f = fp[((long)l * N + m) * Th + th], t = tn[((long)l * N + m) * Th + th];
-                inner += div_no_nan(f, f + t);                                  // :89-95
-            }
-            pf += div_no_nan(inner, (float)(N - 1));
+            pf += lds_pf ? pf_l[l * Th + th] : inner_of(l, th);
         }
         pm /= (float)N;
         pf /= (float)N;
@@ -881,7 +895,11 @@ __global__ __launch_bounds__(256) void cavg_result_kernel(const float* __restric
     best = wave_min(best);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));   // :103
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < 16; ++w) m = fminf(m, red[w]);
+        out[0] = m;                                                             // :103
+    }
 }
 
 struct AdamState {
@@ -1264,8 +1282,10 @@ extern "C" int lidbox_cavg_result(const float* tp, const float* fn, const float*
                                   float* c_avg_out, float* out, lidbox_stream_t stream) {
     LBX_ARG(tp && fn && fp_pairs && tn_pairs && out, "pointers != NULL");
     LBX_ARG(N >= 2 && Th >= 1, "N >= 2, Th >= 1");
-    hipLaunchKernelGGL(cavg_result_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tp, fn, fp_pairs,
-                       tn_pairs, N, Th, C_miss, C_fa, P_tar, c_avg_out, out);
+    const size_t lds = (size_t)N * Th * sizeof(float);
+    const int lds_pf = Th <= 512 && lds <= 48 * 1024;               // at least two language groups, inside the default LDS limit
+    hipLaunchKernelGGL(cavg_result_kernel, dim3(1), dim3(1024), lds_pf ? lds : 0, (hipStream_t)stream, tp, fn, fp_pairs,
+                       tn_pairs, N, Th, C_miss, C_fa, P_tar, lds_pf, c_avg_out, out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

@@ -398,7 +398,53 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
     out[(int64_t)s * D + d] = acc / (float)(r1 - r0);
 }
 
+// ---- 16-bit PCM ingest: out[f] = mean over channels of pcm[f][c] / 32768  (features/audio.py:17-23) ----
+// tf.audio.decode_wav scales int16 by 2^-15 (exact in fp32), reduce_mean sums the channels of a frame (exact: a few 16-bit values)
+// and divides by their number once.  Mono with 8 frames per thread: one 16-byte load, two 16-byte stores.
+__global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const int16_t* __restrict__ pcm, int64_t frames, int channels,
+                                                           float* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (channels == 1) {
+        const bool vec = ((((uintptr_t)pcm) | ((uintptr_t)out)) & 15) == 0;
+        const int64_t n8 = vec ? frames >> 3 : 0;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+            const int4 v = *reinterpret_cast<const int4*>(pcm + 8 * i);
+            const int w[4] = {v.x, v.y, v.z, v.w};
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[2 * j] = (float)(short)(w[j] & 0xffff) * (1.0f / 32768.0f);
+                x[2 * j + 1] = (float)(w[j] >> 16) * (1.0f / 32768.0f);
+            }
+            const float4 lo = make_float4(x[0], x[1], x[2], x[3]), hi = make_float4(x[4], x[5], x[6], x[7]);
+            *reinterpret_cast<float4*>(out + 8 * i) = lo;
+            *reinterpret_cast<float4*>(out + 8 * i + 4) = hi;
+        }
+        for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += stride)
+            out[i] = (float)pcm[i] * (1.0f / 32768.0f);
+        return;
+    }
+    const float nch = (float)channels;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < frames; i += stride) {
+        const int16_t* p = pcm + i * channels;
+        float acc = 0.f;
+        for (int c = 0; c < channels; ++c) acc += (float)p[c] * (1.0f / 32768.0f);
+        out[i] = acc / nch;
+    }
+}
+
 }  // namespace
+
+extern "C" int lidbox_pcm16_to_f32(const int16_t* pcm, long frames, int channels, float* out, lidbox_stream_t stream) {
+    LBX_ARG(frames >= 0 && channels >= 1 && channels <= 256, "frames >= 0, 1 <= channels <= 256");
+    if (frames == 0) return LIDBOX_OK;
+    LBX_ARG(pcm && out, "pcm, out != NULL");
+    long g = lbx_cdiv(channels == 1 ? lbx_cdiv(frames, 8) : frames, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pcm, (int64_t)frames, channels, out);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
 
 extern "C" int lidbox_signal_chunk_plan(long num_samples, int sample_rate, int length_ms, int step_ms,
                                         int max_pad_ms, long* out4) {

@@ -3,8 +3,9 @@ Counterpart of lidbox/features/audio.py for the hot path: the same function name
 names and defaults as the reference (cited per function, file:line relative to the lidbox
 checkout), over torch tensors on the HIP device.  All arithmetic runs in liblidbox_hip.so.
 The energy VAD, silence removal, peak normalisation, RMS and SNR-mixer helpers run on the
-ragged-batch kernels of csrc/signal.hip through `signal_ops`; file decoding, resampling, WebRTC VAD and the
-random FIR augmentation stay out of scope (host libraries).
+ragged-batch kernels of csrc/signal.hip through `signal_ops`; 16-bit PCM is scaled and channel-averaged on the device
+(`pcm16_to_float`, `read_wav`: the RIFF header is parsed on the host, the samples cross PCIe as int16); MP3 decoding,
+resampling, WebRTC VAD and the random FIR augmentation stay out of scope (host libraries).
 """
 import math
 import threading
@@ -158,6 +159,72 @@ def db_to_power(S):
 def fft_frequencies(sample_rate, n_fft):
     """reference lidbox/features/audio.py:151-159 (host constant)."""
     return torch.linspace(0.0, float(int(sample_rate) // 2), 1 + int(n_fft) // 2)
+
+
+# ------------------------------------------------------------------ 16-bit PCM ingest (reference audio.py:17-23)
+def pcm16_to_float(pcm, channels=1, device=None):
+    """tf.audio.decode_wav's sample arithmetic + the channel average of reference lidbox/features/audio.py:20-22 on the device:
+    `pcm` = int16 samples, frames x channels interleaved (torch tensor on any device, or anything numpy can view as int16);
+    returns the float32 signal [frames] on the HIP device, bit-identical to (pcm / 32768).mean(axis=1) in float32."""
+    import numpy as np
+    channels = int(channels)
+    if not isinstance(pcm, torch.Tensor):
+        pcm = torch.from_numpy(np.ascontiguousarray(np.asarray(pcm, dtype=np.int16)))
+    if pcm.dtype != torch.int16:
+        raise TypeError("pcm must be int16, got %s" % pcm.dtype)
+    dev = torch.device(device) if device is not None else (pcm.device if pcm.is_cuda else torch.device("cuda"))
+    pcm = pcm.reshape(-1).to(dev, non_blocking=True).contiguous()
+    if channels < 1 or pcm.numel() % channels:
+        raise ValueError("%d samples are not whole frames of %d channels" % (pcm.numel(), channels))
+    frames = pcm.numel() // channels
+    out = torch.empty(frames, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nv.check(nv.lib.lidbox_pcm16_to_f32(nv.ptr(pcm), frames, channels, nv.ptr(out), nv.current_stream()))
+    return out
+
+
+def parse_wav_pcm16(data):
+    """RIFF/WAVE container -> (int16 samples as a numpy view of `data`, channels, sample_rate).  16-bit PCM only, like
+    tf.audio.decode_wav (format tag 1, or WAVE_FORMAT_EXTENSIBLE with the PCM subformat); chunks other than `fmt ` / `data` are
+    skipped; a `data` size that runs past the end of the file is cut to whole frames."""
+    import struct
+    import numpy as np
+    mv = memoryview(data)
+    if len(mv) < 12 or bytes(mv[0:4]) != b"RIFF" or bytes(mv[8:12]) != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file")
+    pos, fmt = 12, None
+    while pos + 8 <= len(mv):
+        cid, size = bytes(mv[pos:pos + 4]), struct.unpack_from("<I", mv, pos + 4)[0]
+        body = pos + 8
+        if cid == b"fmt ":
+            if size < 16:
+                raise ValueError("short fmt chunk")
+            tag, nch, rate, _, _, bits = struct.unpack_from("<HHIIHH", mv, body)
+            if tag == 0xFFFE and size >= 26:
+                tag = struct.unpack_from("<H", mv, body + 24)[0]
+            fmt = (tag, nch, rate, bits)
+        elif cid == b"data":
+            if fmt is None:
+                raise ValueError("data chunk before fmt chunk")
+            tag, nch, rate, bits = fmt
+            if tag != 1 or bits != 16 or nch < 1:
+                raise ValueError("only 16-bit PCM is supported (format tag %d, %d bits)" % (tag, bits))
+            size = min(size, len(mv) - body)
+            size -= size % (2 * nch)
+            return np.frombuffer(mv[body:body + size], dtype="<i2"), nch, rate
+        pos = body + size + (size & 1)
+    raise ValueError("no data chunk")
+
+
+def read_wav(path, device=None):
+    """reference lidbox/features/audio.py:17-23: (signal [frames] float32 on the HIP device, sample_rate).  The file is read and
+    its header parsed on the host; scaling and the channel average run in lidbox_pcm16_to_f32."""
+    if isinstance(path, bytes):
+        path = path.decode("utf-8")
+    with open(path, "rb") as f:
+        data = f.read()
+    pcm, nch, rate = parse_wav_pcm16(data)
+    return pcm16_to_float(torch.from_numpy(pcm.copy()), nch, device=device), rate
 
 
 # ------------------------------------------------------------------ signal helpers (SURVEY 8f.3)

@@ -1,7 +1,7 @@
 """
-Counterpart of lidbox/models/cnn.py (MGB-3 CNN, reference cnn.py:25-45): four causal Conv1D+ReLU,
-global average pooling over time, Dense 1500, Dense 600, Dense num_outputs, log_softmax.
-Same GEMM kernels as the x-vector; only the pooling differs.
+Counterpart of lidbox/models/cnn.py (MGB-3 CNN, reference cnn.py:25-45): four Conv1D+ReLU (padding "causal" by
+default, "valid" / "same" as Keras Conv1D takes them), global average pooling over time, Dense 1500, Dense 600,
+Dense num_outputs, log_softmax.  Same GEMM kernels as the x-vector; only the pooling differs.
 """
 from .tdnn import ConvSpec, DenseSpec, EmbeddingExtractor, SequentialTDNN
 
@@ -9,13 +9,11 @@ from .tdnn import ConvSpec, DenseSpec, EmbeddingExtractor, SequentialTDNN
 def create(input_shape, num_outputs, output_activation="log_softmax", padding="causal", channel_dropout_rate=0,
            seed=None, device=None, compute_dtype="float32"):
     """reference cnn.py:25-45"""
-    if padding != "causal":
-        raise ValueError("only padding='causal' is supported")
     convs = [
-        ConvSpec("conv_1", 500, 5, 1),
-        ConvSpec("conv_2", 500, 7, 2),
-        ConvSpec("conv_3", 500, 1, 1),
-        ConvSpec("conv_4", 3000, 1, 1),
+        ConvSpec("conv_1", 500, 5, 1, padding=padding),
+        ConvSpec("conv_2", 500, 7, 2, padding=padding),
+        ConvSpec("conv_3", 500, 1, 1, padding=padding),
+        ConvSpec("conv_4", 3000, 1, 1, padding=padding),
     ]
     denses = [DenseSpec("fc_1", 1500), DenseSpec("fc_2", 600), DenseSpec("output", num_outputs, relu=False)]
     return SequentialTDNN(input_shape, convs, "avg", denses, name="MGB-3_CNN", output_activation=output_activation,

@@ -27,12 +27,18 @@ from .. import _native as nv
 
 
 class ConvSpec:
-    """Keras Conv1D(filters, kernel_size, strides, padding="causal", dilation_rate).  The reference only ever sets
-    strides (xvector.py:38-39); dilation_rate is this build's opt-in and, as in Keras, excludes
-    strides > 1.  A dilated layer runs as k accumulating single-tap GEMMs over row-shifted views."""
+    """Keras Conv1D(filters, kernel_size, strides, padding, dilation_rate).  The x-vector family only ever sets strides
+    (xvector.py:38-39) with padding="causal"; cnn.create passes its `padding` argument through (cnn.py:25,33-36: "causal",
+    "valid" or "same"); dilation_rate is this build's opt-in and, as in Keras, excludes strides > 1.  A dilated
+    layer runs as k accumulating single-tap GEMMs over row-shifted views."""
 
-    def __init__(self, name, filters, kernel_size, strides, relu=True, dilation_rate=1, dense_kernel=False):
+    PADDINGS = ("causal", "valid", "same")
+
+    def __init__(self, name, filters, kernel_size, strides, relu=True, dilation_rate=1, dense_kernel=False, padding="causal"):
         self.name, self.filters, self.k, self.s, self.relu = name, int(filters), int(kernel_size), int(strides), relu
+        self.padding = str(padding).lower()
+        if self.padding not in self.PADDINGS:
+            raise ValueError("padding must be one of %s, got %r" % (self.PADDINGS, padding))
         # a Keras Dense applied to [B, T, C] is a pointwise conv; dense_kernel keeps its kernel shape [in, out]
         self.dense_kernel = bool(dense_kernel) and int(kernel_size) == 1
         self.d = int(dilation_rate) if int(kernel_size) > 1 else 1      # a single tap has nothing to dilate
@@ -45,6 +51,21 @@ class ConvSpec:
     def pad(self):
         """causal left padding in rows"""
         return (self.k - 1) * self.d
+
+    def geometry(self, T):
+        """(zero rows ahead of the T input frames, zero rows behind them, output frames): output t reads the padded rows
+        t*s + j*d, j < k.  TensorFlow's conventions: causal = k_eff - 1 rows ahead, then VALID; valid = no padding,
+        floor((T - k_eff) / s) + 1 outputs; same = ceil(T / s) outputs, the missing rows split with the odd one behind."""
+        ke = (self.k - 1) * self.d + 1
+        if T <= 0:
+            return (ke - 1 if self.padding == "causal" else 0), 0, 0
+        if self.padding == "causal":
+            return ke - 1, 0, (T - 1) // self.s + 1
+        if self.padding == "valid":
+            return 0, 0, ((T - ke) // self.s + 1 if T >= ke else 0)
+        To = -(-T // self.s)
+        total = max((To - 1) * self.s + ke - T, 0)
+        return total // 2, total - total // 2, To
 
 
 class FreqAttentionSpec:
@@ -128,10 +149,15 @@ class _Workspace:
         f32 = dict(dtype=torch.float32, device=dev)
         convs = model.convs
         self.Ts = [T]
+        self.pads, self.rpads = [], []       # zero rows ahead of / behind the frames of act[i], for the conv that reads it
         for c in convs:
-            self.Ts.append(conv_out_len(self.Ts[-1], c.s))
+            pl, pr, To = c.geometry(self.Ts[-1])
+            self.pads.append(pl)
+            self.rpads.append(pr)
+            self.Ts.append(To)
+        self.pads.append(0)
+        self.rpads.append(0)
         chans = [model.input_dim] + [c.filters for c in convs]
-        self.pads = [c.pad for c in convs] + [0]
         # zero rows BEHIND an utterance's frames (bf16-storage path only): the output-stationary dgrad of a conv with k > s
         # reads its output gradient through windows that run up to `trail` rows past the last frame (SequentialTDNN._dgrad_residues)
         self.trail = [0] * len(chans)
@@ -139,7 +165,7 @@ class _Workspace:
             for i in range(1, len(convs) - 1):               # not the last conv: the pooling reads act[-1] as [B, T, C]
                 self.trail[i + 1] = model._dgrad_trail(i, self.Ts[i])
         # activations (zero-initialised once: the pad / trail rows stay zero forever)
-        self.act = [torch.zeros((B, self.pads[i] + self.Ts[i] + self.trail[i], chans[i]), **f32) for i in range(len(chans))]
+        self.act = [torch.zeros((B, self.pads[i] + self.Ts[i] + self.rpads[i] + self.trail[i], chans[i]), **f32) for i in range(len(chans))]
         self.dact = [None] + [torch.zeros_like(a) for a in self.act[1:]]
         # bf16-storage GEMMs (compute_dtype "bfloat16"): bf16 shadows of the conv inputs (A of forward) and of the conv output
         # gradients (A of dgrad), same element layout as the fp32 buffers; written by the producing GEMM's epilogue.
@@ -353,8 +379,9 @@ class SequentialTDNN:
         # `_flat16_live` are refreshed (`_refresh_bf16_weights`); every other element stays zero and `_p16` refuses to hand
         # it out.  `w16t[i]` is conv i's kernel transposed to [C_out, k*C_in] (forward's [N][K] operand)
         import os as _os
+        # (the storage path's output-stationary dgrad and its trail rows are laid out for causal windows)
         self.bf16_storage = self.compute_dtype == "bfloat16" and _os.environ.get("LIDBOX_BF16_STORAGE", "1") != "0" \
-            and attention is None and not self.frontend
+            and attention is None and not self.frontend and all(c.padding == "causal" for c in self.convs)
         if self.bf16_storage and not any(self.shadow_fwd_ok(i) for i in range(len(self.convs))):
             self.bf16_storage = False                    # no layer qualifies (e.g. the CNN's 12- / 500-channel layers): nothing to shadow
         if self.bf16_storage:

@@ -28,44 +28,63 @@ def conv1d_out_len(T, stride):
     return (T - 1) // stride + 1 if T > 0 else 0
 
 
-def im2col_causal(x, k, s, d=1):
+def conv1d_padding(T, k, s, d=1, padding="causal"):
+    """(zero rows ahead, zero rows behind, output length) of Keras Conv1D(padding=...), which lidbox/models/cnn.py:25,33-36
+    passes through from its `padding` argument.  TensorFlow's rules with k_eff = (k-1)*d + 1: "causal" pads k_eff - 1 rows
+    ahead and runs VALID; "valid": ceil((T - k_eff + 1) / s) outputs, no padding; "same": ceil(T / s) outputs,
+    pad_total = max((out - 1)*s + k_eff - T, 0), pad_before = pad_total // 2 (the odd row goes behind)."""
+    ke = (k - 1) * d + 1
+    if T <= 0:
+        return (ke - 1 if padding == "causal" else 0), 0, 0
+    if padding == "causal":
+        return ke - 1, 0, conv1d_out_len(T, s)
+    if padding == "valid":
+        return 0, 0, max(0, -(-(T - ke + 1) // s))
+    assert padding == "same", padding
+    out = -(-T // s)
+    total = max((out - 1) * s + ke - T, 0)
+    return total // 2, total - total // 2, out
+
+
+def im2col_causal(x, k, s, d=1, padding="causal"):
     """x [B,T,C] -> col [B,T_out,k*C] with col[b,t,j*C+c] = xpad[b, t*s+j*d, c],
     xpad = (k-1)*d zero rows then x.  (Keras causal padding, lidbox/models/xvector.py:38-39;
     d = Conv1D dilation_rate -- the reference never sets it (SURVEY 8f.1 "opt-in dilation"), Keras
-    requires s == 1 when d > 1.)"""
+    requires s == 1 when d > 1.)  Other paddings (cnn.py:25): xpad per conv1d_padding."""
     B, T, C = x.shape
     assert d == 1 or s == 1, "Keras Conv1D: strides > 1 not supported together with dilation_rate > 1"
-    To = conv1d_out_len(T, s)
-    xp = np.concatenate([np.zeros((B, (k - 1) * d, C), x.dtype), x], axis=1)
+    pl, pr, To = conv1d_padding(T, k, s, d, padding)
+    xp = np.concatenate([np.zeros((B, pl, C), x.dtype), x, np.zeros((B, pr, C), x.dtype)], axis=1)
     idx = np.arange(To)[:, None] * s + np.arange(k)[None, :] * d
     return xp[:, idx, :].reshape(B, To, k * C)
 
 
-def conv1d_causal_fwd(x, W, b, s, relu=True, d=1):
+def conv1d_causal_fwd(x, W, b, s, relu=True, d=1, padding="causal"):
     """W [k,C_in,C_out] (Keras kernel layout), b [C_out]."""
     k, Ci, Co = W.shape
-    col = im2col_causal(x, k, s, d)
+    col = im2col_causal(x, k, s, d, padding)
     y = col @ W.reshape(k * Ci, Co) + b
     return np.maximum(y, 0) if relu else y
 
 
-def conv1d_causal_bwd(x, W, y, dy, s, relu=True, need_dx=True, d=1):
+def conv1d_causal_bwd(x, W, y, dy, s, relu=True, need_dx=True, d=1, padding="causal"):
     """Returns (dx, dW, db).  y is the post-activation output."""
     k, Ci, Co = W.shape
     B, T, _ = x.shape
     if relu:
         dy = dy * (y > 0)
-    col = im2col_causal(x, k, s, d)
+    col = im2col_causal(x, k, s, d, padding)
     To = col.shape[1]
     dW = (col.reshape(-1, k * Ci).T @ dy.reshape(-1, Co)).reshape(k, Ci, Co)
     db = dy.reshape(-1, Co).sum(axis=0)
     dx = None
     if need_dx:
+        pl, pr, _ = conv1d_padding(T, k, s, d, padding)
         dcol = (dy @ W.reshape(k * Ci, Co).T).reshape(B, To, k, Ci)
-        dxp = np.zeros((B, T + (k - 1) * d, Ci), x.dtype)
+        dxp = np.zeros((B, pl + T + pr, Ci), x.dtype)
         for j in range(k):
             dxp[:, np.arange(To) * s + j * d, :] += dcol[:, :, j, :]
-        dx = dxp[:, (k - 1) * d:, :]
+        dx = dxp[:, pl:pl + T, :]
     return dx, dW, db
 
 
@@ -214,11 +233,11 @@ def cnn_init(input_dim, num_outputs, seed=0, dtype=np.float32):
     return p
 
 
-def cnn_fwd(p, x, embedding=False):
-    """lidbox/models/cnn.py:25-45 with output_activation="log_softmax", padding="causal"."""
+def cnn_fwd(p, x, embedding=False, padding="causal"):
+    """lidbox/models/cnn.py:25-45 with output_activation="log_softmax"."""
     h = x
     for name, f, k, s in CNN_CONVS:
-        h = conv1d_causal_fwd(h, p[name + ".W"], p[name + ".b"], s)
+        h = conv1d_causal_fwd(h, p[name + ".W"], p[name + ".b"], s, padding=padding)
     h = global_avg_pool_fwd(h)
     if embedding:                                          # cnn.py:19-22
         return dense_fwd(h, p["fc_1.W"], p["fc_1.b"], relu=False)

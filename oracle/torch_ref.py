@@ -40,10 +40,13 @@ class LogMelCPU:
 
 
 # ---------------------------------------------------------------- model
-def conv1d_causal(x, W, b, s, relu=True):
-    """x [B,T,C]; W Keras layout [k,C_in,C_out]."""
+def conv1d_causal(x, W, b, s, relu=True, padding="causal"):
+    """x [B,T,C]; W Keras layout [k,C_in,C_out]; zero rows per model_np.conv1d_padding."""
     k = W.shape[0]
-    y = F.conv1d(F.pad(x.transpose(1, 2), (k - 1, 0)), W.permute(2, 1, 0), b, stride=s)
+    pl, pr, To = model_np.conv1d_padding(x.shape[1], k, s, 1, padding)
+    if To == 0:
+        return x.new_zeros((x.shape[0], 0, W.shape[2]))
+    y = F.conv1d(F.pad(x.transpose(1, 2), (pl, pr)), W.permute(2, 1, 0), b, stride=s)
     y = y.transpose(1, 2)
     return F.relu(y) if relu else y
 
@@ -69,10 +72,10 @@ def xvector_fwd(p, x, embedding=False):
     return F.log_softmax(z, dim=-1)
 
 
-def cnn_fwd(p, x):
+def cnn_fwd(p, x, padding="causal"):
     h = x
     for name, f, k, s in model_np.CNN_CONVS:
-        h = conv1d_causal(h, p[name + ".W"], p[name + ".b"], s)
+        h = conv1d_causal(h, p[name + ".W"], p[name + ".b"], s, padding=padding)
     h = h.mean(dim=1)
     h = F.relu(h @ p["fc_1.W"] + p["fc_1.b"])
     h = F.relu(h @ p["fc_2.W"] + p["fc_2.b"])

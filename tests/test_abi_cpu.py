@@ -273,6 +273,24 @@ def test_host_signal_chunk_plan_matches_oracle(nv):
         nv.check(nv.lib.lidbox_signal_chunk_plan(100, 16000, 0, 10, 0, out))      # zero-length chunks
 
 
+def test_wav_header_parser_is_host_logic():
+    """audio.parse_wav_pcm16 (the host half of read_wav, reference audio.py:17-19) on the reference's WAV fixtures: the samples
+    the oracle's reader sees, as int16"""
+    import glob
+    import os
+    from oracle import features_np as fo
+    from lidbox_amd.features import audio
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "audio", "*.wav")))
+    assert paths
+    for p in paths:
+        pcm, nch, rate = audio.parse_wav_pcm16(open(p, "rb").read())
+        sig, r = fo.read_wav_pcm16(p)
+        assert rate == r and pcm.dtype == np.int16
+        assert np.array_equal((pcm.astype(np.float32) / np.float32(32768.0)).reshape(-1, nch).mean(axis=1, dtype=np.float32), sig)
+    with pytest.raises(ValueError):
+        audio.parse_wav_pcm16(b"RIFFxxxxWAVE")
+
+
 def test_gemm_plans_tuned_table_and_model(nv):
     """lidbox_gemm_plan_query is host logic: shapes listed in csrc/gemm_tuned.h (measured by tools/gemm_sweep.py) return
     the measured decomposition, every other shape the cost model's; the workspace queries cover whatever is chosen."""

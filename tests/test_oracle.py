@@ -530,3 +530,27 @@ def test_optimizer_restatements_against_torch_and_closed_forms():
     zs = np.array([[50.0, 0, 0]])
     ls, dzs = mo.sparse_ce_from_probs(zs, np.array([0]))
     assert 0 <= ls < 3e-7 and np.abs(dzs).max() == 0.0
+
+
+def test_conv1d_padding_rules_follow_tensorflow():
+    """model_np.conv1d_padding (Keras Conv1D padding as lidbox/models/cnn.py:25,33-36 passes it on): TensorFlow's documented
+    example -- 13 inputs, filter 6, stride 5: VALID gives 2 outputs and drops the last two inputs, SAME gives 3 with one zero
+    ahead and two behind -- plus the causal rule the x-vector uses, and the identities out_same = ceil(T / s),
+    out_valid = ceil((T - k + 1) / s)"""
+    from oracle import model_np as mo
+    assert mo.conv1d_padding(13, 6, 5, 1, "valid") == (0, 0, 2)
+    assert mo.conv1d_padding(13, 6, 5, 1, "same") == (1, 2, 3)
+    assert mo.conv1d_padding(13, 6, 5, 1, "causal") == (5, 0, 3)
+    assert mo.conv1d_padding(61, 7, 2, 1, "same") == (3, 3, 31)       # cnn.py conv_2 on an odd length
+    assert mo.conv1d_padding(62, 7, 2, 1, "same") == (2, 3, 31)       # ... and an even one: one row less, the odd row behind
+    assert mo.conv1d_padding(4, 7, 2, 1, "valid") == (0, 0, 0)
+    for T in range(1, 40):
+        for k in (1, 2, 5, 7):
+            for s in (1, 2, 3):
+                pl, pr, out = mo.conv1d_padding(T, k, s, 1, "same")
+                assert out == -(-T // s) and pl + T + pr >= (out - 1) * s + k and pr - pl in (0, 1)
+                assert mo.conv1d_padding(T, k, s, 1, "valid")[2] == max(0, -(-(T - k + 1) // s))
+    x = np.arange(13, dtype=np.float64).reshape(1, 13, 1) + 1
+    col = mo.im2col_causal(x, 6, 5, padding="same")[0]
+    assert col[0].tolist() == [0, 1, 2, 3, 4, 5] and col[2].tolist() == [10, 11, 12, 13, 0, 0]
+    assert mo.im2col_causal(x, 6, 5, padding="valid")[0, 1].tolist() == [6, 7, 8, 9, 10, 11]

@@ -224,3 +224,53 @@ def test_merge_chunk_predictions_and_classification_report():
     assert (rep["confusion_matrix"] == sklearn.metrics.confusion_matrix(true, pred.argmax(1))).all()
     assert 0.0 <= rep["avg_equal_error_rate"] <= 0.5 and "equal_error_rate" in rep["lang2"]
     assert abs(rep["accuracy"] - (pred.argmax(1) == true).mean()) < 1e-12
+
+
+@pytest.mark.parametrize("frames,channels", [(0, 1), (1, 1), (7, 1), (48000, 1), (100003, 1), (48000, 2), (1001, 3), (513, 6)])
+def test_pcm16_ingest_is_bit_exact(frames, channels):
+    """lidbox_pcm16_to_f32 (reference audio.py:17-23: decode_wav's int16 / 32768, then the channel mean) against the float32
+    arithmetic restated in numpy -- every sample value incl. -32768 / 32767, odd lengths, unaligned views, several channels"""
+    from lidbox_amd.features import audio
+    rng = np.random.default_rng(frames + channels)
+    pcm = rng.integers(-32768, 32768, size=(frames, channels)).astype(np.int16)
+    if frames >= 2:
+        pcm[0, :] = -32768
+        pcm[1, :] = 32767
+    ref = (pcm.astype(np.float32) / np.float32(32768.0)).mean(axis=1, dtype=np.float32) if frames else np.zeros(0, np.float32)
+    got = audio.pcm16_to_float(pcm, channels)
+    assert got.dtype == torch.float32 and got.shape == (frames,)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    if channels == 1 and frames > 16:                          # a view that starts 2 bytes off a 16-byte boundary
+        buf = torch.from_numpy(np.concatenate([[0], pcm[:, 0]]).astype(np.int16)).cuda()
+        assert np.array_equal(audio.pcm16_to_float(buf[1:], 1).cpu().numpy(), ref)
+
+
+def test_read_wav_matches_oracle_on_reference_fixtures(tmp_path):
+    """audio.read_wav (host RIFF parse + device ingest) == the oracle's decode_wav restatement on the reference's own WAV files, a
+    stereo file written here, and a file with an extra chunk ahead of `data`"""
+    import struct
+    import wave
+    from lidbox_amd.features import audio
+    for p in AUDIO:
+        s, r = audio.read_wav(p)
+        so_, ro = fo.read_wav_pcm16(p)
+        assert r == ro and np.array_equal(s.cpu().numpy(), so_)
+    rng = np.random.default_rng(5)
+    st = rng.integers(-32768, 32768, size=(12345, 2)).astype("<i2")
+    p2 = str(tmp_path / "stereo.wav")
+    with wave.open(p2, "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(22050); f.writeframes(st.tobytes())
+    s, r = audio.read_wav(p2.encode("utf-8"))
+    so_, ro = fo.read_wav_pcm16(p2)
+    assert r == ro == 22050 and np.array_equal(s.cpu().numpy(), so_)
+    raw = open(p2, "rb").read()
+    extra = b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"             # odd-sized chunk + its pad byte
+    i = raw.index(b"data")
+    p3 = str(tmp_path / "list.wav")
+    open(p3, "wb").write(raw[:i] + extra + raw[i:])
+    s3, _ = audio.read_wav(p3)
+    assert torch.equal(s3, s)
+    with pytest.raises(ValueError):
+        audio.parse_wav_pcm16(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    with pytest.raises(ValueError):
+        audio.parse_wav_pcm16(b"not a wav file at all")
