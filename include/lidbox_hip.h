@@ -463,6 +463,14 @@ int lidbox_stats_pool_bwd(const float* x, const float* pooled, const float* dout
 int lidbox_stats_pool_bwd_shadow(const float* x, const float* pooled, const float* dout, int B, int T, int C,
                                  long batch_stride, long row_stride, int relu_mask, float* dx,
                                  void* dx16, long batch_stride16, long row_stride16, lidbox_stream_t stream);
+/* The statistics pooling of the bf16 policy's all-shadow mode: x16 = the bfloat16 shadow of the last frame layer's output
+ * ([B][T][C] at batch / row strides bs / rs in bf16 elements, e.g. 1500 channels in 1504-wide rows), which that layer's GEMM then
+ * writes INSTEAD of an fp32 copy.  Same fp32 arithmetic as lidbox_stats_pool_fwd / _bwd_shadow on the shadow's values
+ * (xvector.py:30-35); the backward writes only the gradient's shadow dx16.  T <= 40 (the register kernels), C and strides
+ * multiples of 4, 8-byte aligned shadows; anything else is refused. */
+int lidbox_stats_pool_fwd_bf16(const void* x16, int B, int T, int C, long bs, long rs, float* out, lidbox_stream_t stream);
+int lidbox_stats_pool_bwd_bf16(const void* x16, const float* pooled, const float* dout, int B, int T, int C, long bs, long rs,
+                               int relu_mask, void* dx16, long bs16, long rs16, lidbox_stream_t stream);
 /* Keras GlobalAveragePooling1D (cnn.py:37) */
 int lidbox_avg_pool_fwd(const float* x, int B, int T, int C, long batch_stride, long row_stride,
                         float* out, lidbox_stream_t stream);

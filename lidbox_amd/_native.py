@@ -117,6 +117,8 @@ _SIGS = {
     "lidbox_softmax_head_supported": (_i, [_i, _i]),
     "lidbox_softmax_head_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "lidbox_stats_pool_bwd_shadow": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp, _l, _l, _vp]),
+    "lidbox_stats_pool_fwd_bf16": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
+    "lidbox_stats_pool_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _l, _l, _vp]),
     "lidbox_avg_pool_fwd": (_i, [_vp, _i, _i, _i, _l, _l, _vp, _vp]),
     "lidbox_avg_pool_bwd": (_i, [_vp, _vp, _i, _i, _i, _l, _l, _i, _vp, _vp]),
     "lidbox_signal_chunk_plan": (_i, [_l, _i, _i, _i, _i, _vp]),

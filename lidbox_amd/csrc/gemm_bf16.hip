@@ -1035,7 +1035,11 @@ Dma16Choice choose_dma16(long M, int N, int K, size_t ws_bytes, bool writes_fp32
         // contractions (frame1: K = 200, four steps under a 256 x 256 epilogue) and on launches of a quarter round (M = 8 448).
         const long t256 = lbx_cdiv(M, 256L) * lbx_cdiv((long)N, 256L);
         const long r256 = lbx_cdiv(t256, (long)NUM_CU);
-        static const bool no_pp = getenv("LIDBOX_GEMM16S_NO_PP") != nullptr;          // A/B aid
+        bool no_pp = getenv("LIDBOX_GEMM16S_NO_PP") != nullptr;                       // A/B aid
+        if (const char* e = getenv("LIDBOX_GEMM16S_NO_PP_SHAPE")) {                   // A/B aid: "M,N,K" of one launch to keep off the tile
+            long em = 0; int en = 0, ek = 0;
+            if (sscanf(e, "%ld,%d,%d", &em, &en, &ek) == 3 && em == M && en == N && ek == K) no_pp = true;
+        }
         // (a launch that writes fp32 -- frame5's forward, 4 or 6 bytes per element -- pays a 256 x 256 epilogue twice over
         // in a 1.5-round launch: bs 512 62 vs 57 us; it stays on the small tiles unless the contraction is long)
         if (!no_pp && !(writes_fp32 && K < 1024 && t256 > NUM_CU) &&

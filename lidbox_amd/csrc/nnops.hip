@@ -105,16 +105,25 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 // consecutive channels and keeps all T rows of them in registers -- every load is issued before the first use, the second
 // pass of the two-pass variance reads registers instead of memory, and there is no LDS or barrier.  Rows t >= T re-read row
 // T-1 (no control flow between the loads) and are left out of the sums.  Sums run over t in order (deterministic).
-template <bool STATS, int TMAX>
-__global__ __launch_bounds__(64) void pool_fwd_reg_kernel(const float* __restrict__ x, int T, int C, long bs, long rs,
+// four consecutive channels as fp32: a 16-byte load of floats, or an 8-byte load of bfloat16 (the bf16 policy's shadow of the
+// last frame layer's output: a bf16 value IS the fp32 value with a zero low half)
+__device__ __forceinline__ float4 pool_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 pool_load4(const unsigned short* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <bool STATS, int TMAX, typename XT>
+__global__ __launch_bounds__(64) void pool_fwd_reg_kernel(const XT* __restrict__ x, int T, int C, long bs, long rs,
                                                           float* __restrict__ out) {
     const int c = (blockIdx.x * 64 + threadIdx.x) * 4;
     if (c >= C) return;
     const long b = blockIdx.y;
-    const float* xp = x + b * bs + c;
+    const XT* xp = x + b * bs + c;
     float4 v[TMAX];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) v[t] = *reinterpret_cast<const float4*>(xp + (long)(t < T ? t : T - 1) * rs);
+    for (int t = 0; t < TMAX; ++t) v[t] = pool_load4(xp + (long)(t < T ? t : T - 1) * rs);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
@@ -140,22 +149,28 @@ __global__ __launch_bounds__(64) void pool_fwd_reg_kernel(const float* __restric
     *reinterpret_cast<float4*>(out + b * 2 * C + C + c) = make_float4(sd(q.x), sd(q.y), sd(q.z), sd(q.w));
 }
 
-template <bool STATS, int TMAX>
-void launch_pool_fwd_reg(const float* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
-    hipLaunchKernelGGL((pool_fwd_reg_kernel<STATS, TMAX>), dim3((unsigned)lbx_cdiv(C, 256), (unsigned)B), dim3(64), 0, st, x, T, C,
+template <bool STATS, int TMAX, typename XT>
+void launch_pool_fwd_reg(const XT* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
+    hipLaunchKernelGGL((pool_fwd_reg_kernel<STATS, TMAX, XT>), dim3((unsigned)lbx_cdiv(C, 256), (unsigned)B), dim3(64), 0, st, x, T, C,
                        bs, rs, out);
+}
+
+// the register kernel for every T it covers (1 .. 40)
+template <bool STATS, typename XT>
+void launch_pool_fwd_short(const XT* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
+    if (T <= 8) launch_pool_fwd_reg<STATS, 8>(x, B, T, C, bs, rs, out, st);
+    else if (T <= 16) launch_pool_fwd_reg<STATS, 16>(x, B, T, C, bs, rs, out, st);
+    else if (T <= 24) launch_pool_fwd_reg<STATS, 24>(x, B, T, C, bs, rs, out, st);
+    else if (T <= 32) launch_pool_fwd_reg<STATS, 32>(x, B, T, C, bs, rs, out, st);
+    else if (T <= 36) launch_pool_fwd_reg<STATS, 36>(x, B, T, C, bs, rs, out, st);
+    else launch_pool_fwd_reg<STATS, 40>(x, B, T, C, bs, rs, out, st);
 }
 
 template <bool STATS>
 void launch_pool_fwd(const float* x, int B, int T, int C, long bs, long rs, float* out, hipStream_t st) {
     const bool vec = C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && (((uintptr_t)x) & 15) == 0;
     if (vec && T >= 1 && T <= 40 && (((uintptr_t)out) & 15) == 0) {
-        if (T <= 8) launch_pool_fwd_reg<STATS, 8>(x, B, T, C, bs, rs, out, st);
-        else if (T <= 16) launch_pool_fwd_reg<STATS, 16>(x, B, T, C, bs, rs, out, st);
-        else if (T <= 24) launch_pool_fwd_reg<STATS, 24>(x, B, T, C, bs, rs, out, st);
-        else if (T <= 32) launch_pool_fwd_reg<STATS, 32>(x, B, T, C, bs, rs, out, st);
-        else if (T <= 36) launch_pool_fwd_reg<STATS, 36>(x, B, T, C, bs, rs, out, st);
-        else launch_pool_fwd_reg<STATS, 40>(x, B, T, C, bs, rs, out, st);
+        launch_pool_fwd_short<STATS>(x, B, T, C, bs, rs, out, st);
         return;
     }
     if (vec)
@@ -228,8 +243,8 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 // 16-byte variant with the loads batched: a wave handles R consecutive rows of (utterance, 256 channels); the statistics come
 // in as four float4 and all R row loads are issued before the first store (rows >= T re-read row T-1, only their store is
 // predicated), so the wave pays one memory round trip instead of one per row.
-template <bool STATS, int R>
-__global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ pooled,
+template <bool STATS, int R, typename XT>
+__global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const XT* __restrict__ x, const float* __restrict__ pooled,
                                                            const float* __restrict__ dout, int T, int C, long bs, long rs,
                                                            int relu_mask, float* __restrict__ dx, unsigned short* __restrict__ dx16,
                                                            long bs16, long rs16) {
@@ -237,10 +252,10 @@ __global__ __launch_bounds__(64) void pool_bwd_rows_kernel(const float* __restri
     if (c >= C) return;
     const long b = blockIdx.y;
     const int t0 = blockIdx.z * R;
-    const float* xp = x + b * bs + c;
+    const XT* xp = x + b * bs + c;
     float4 v[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i) v[i] = *reinterpret_cast<const float4*>(xp + (long)(t0 + i < T ? t0 + i : T - 1) * rs);
+    for (int i = 0; i < R; ++i) v[i] = pool_load4(xp + (long)(t0 + i < T ? t0 + i : T - 1) * rs);
     const float invT = 1.f / (float)T;
     float a[4], k[4], mean[4];
     if (STATS) {
@@ -294,7 +309,7 @@ void launch_pool_bwd(const float* x, const float* pooled, const float* dout, int
     if (vec && T >= 1 && T <= 48 && ((((uintptr_t)pooled) | ((uintptr_t)dout)) & 15) == 0) {
         constexpr int R = 12;
         dim3 grid((unsigned)lbx_cdiv(C, 256), (unsigned)B, (unsigned)lbx_cdiv(T, R));
-        hipLaunchKernelGGL((pool_bwd_rows_kernel<STATS, R>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx, dx16, bs16, rs16);
+        hipLaunchKernelGGL((pool_bwd_rows_kernel<STATS, R, float>), grid, dim3(64), 0, st, x, pooled, dout, T, C, bs, rs, relu_mask, dx, dx16, bs16, rs16);
         return;
     }
     const int V = vec ? 4 : 1;
@@ -1142,6 +1157,36 @@ extern "C" int lidbox_stats_pool_bwd_shadow(const float* x, const float* pooled,
     if (total == 0) return LIDBOX_OK;
     LBX_ARG(B <= 65535, "B <= 65535");
     launch_pool_bwd<true>(x, pooled, dout, B, T, C, bs, rs, relu_mask, dx, (hipStream_t)stream, (unsigned short*)dx16, bs16, rs16);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+// The two pooling passes over the bf16 shadow of the last frame layer's output (the bf16 policy's all-shadow mode: that layer then
+// writes no fp32 copy at all).  Same kernels, same fp32 arithmetic, on the shadow's values; short utterances only (the register
+// kernels: T <= 40), channel counts and strides that are multiples of 4, 8-byte aligned shadows.
+extern "C" int lidbox_stats_pool_fwd_bf16(const void* x16, int B, int T, int C, long bs, long rs, float* out, lidbox_stream_t stream) {
+    LBX_ARG(x16 && out && B >= 0 && T >= 1 && C >= 1, "x16, out != NULL; T, C >= 1");
+    LBX_ARG(T <= 40 && C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && rs >= C && (((uintptr_t)x16) & 7) == 0 && (((uintptr_t)out) & 15) == 0,
+            "the bf16 pooling kernels take T <= 40, C and strides that are multiples of 4, an 8-byte aligned shadow and a 16-byte aligned output");
+    if (B == 0) return LIDBOX_OK;
+    LBX_ARG(B <= 65535, "B <= 65535");
+    launch_pool_fwd_short<true>((const unsigned short*)x16, B, T, C, bs, rs, out, (hipStream_t)stream);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+extern "C" int lidbox_stats_pool_bwd_bf16(const void* x16, const float* pooled, const float* dout, int B, int T, int C, long bs, long rs,
+                                          int relu_mask, void* dx16, long bs16, long rs16, lidbox_stream_t stream) {
+    LBX_ARG(x16 && pooled && dout && dx16 && T >= 1 && C >= 1, "x16, pooled, dout, dx16 != NULL; T, C >= 1");
+    LBX_ARG(T <= 40 && C % 4 == 0 && bs % 4 == 0 && rs % 4 == 0 && rs >= C && bs16 % 4 == 0 && rs16 % 4 == 0 && rs16 >= C &&
+                ((((uintptr_t)x16) | ((uintptr_t)dx16)) & 7) == 0 && ((((uintptr_t)pooled) | ((uintptr_t)dout)) & 15) == 0,
+            "the bf16 pooling kernels take T <= 40, C and strides that are multiples of 4, 8-byte aligned shadows and 16-byte aligned statistics");
+    if ((long)B * T * C == 0) return LIDBOX_OK;
+    LBX_ARG(B <= 65535, "B <= 65535");
+    constexpr int R = 12;
+    dim3 grid((unsigned)lbx_cdiv(C, 256), (unsigned)B, (unsigned)lbx_cdiv(T, R));
+    hipLaunchKernelGGL((pool_bwd_rows_kernel<true, R, unsigned short>), grid, dim3(64), 0, (hipStream_t)stream, (const unsigned short*)x16,
+                       pooled, dout, T, C, bs, rs, relu_mask, (float*)nullptr, (unsigned short*)dx16, bs16, rs16);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
 }

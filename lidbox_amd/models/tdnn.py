@@ -18,6 +18,7 @@ HBM layout
     d_act[i] share the layout (the pad rows just absorb unused dgrad output).
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -182,6 +183,14 @@ class _Workspace:
                     # whole 16-byte pieces; the pad columns stay zero
                     shp = self.act[i + 1].shape
                     self.dact16[i + 1] = torch.zeros((shp[0], shp[1], (shp[2] + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
+        # all-shadow mode with statistics pooling over short utterances: the last conv writes ONLY a bf16 shadow of its output
+        # (rows padded to 8 channels) and both pooling passes read that (lidbox_stats_pool_*_bf16): no fp32 copy of the widest
+        # activation is written or read.  LIDBOX_BF16_POOL_FP32=1 keeps the fp32 copy (tests, A/B).
+        self.last16 = None
+        if (model.bf16_storage and model.bf16_only and model.pool == "stats" and model.attention is None and 1 <= self.Ts[-1] <= 40
+                and chans[-1] % 4 == 0 and model.shadow_fwd_ok(len(convs) - 1) and convs[-1].d == 1
+                and os.environ.get("LIDBOX_BF16_POOL_FP32", "0") != "1"):
+            self.last16 = torch.zeros((B, self.Ts[-1], (chans[-1] + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
         fe = model.frontend
         if fe:
             # 2-D front-end (xvector_2d.py:69-73): model input [B, T, F]; layer i: a = relu(conv) [B*T*F_i+1, C_i+1] dense,
@@ -732,6 +741,11 @@ class SequentialTDNN:
                 sh = None if nxt is None else ctypes.c_void_p(nxt.data_ptr() + (out_rows.base - ws.act[i + 1].data_ptr()) // 2)
                 if self.bf16_only and nxt is not None and i + 1 < len(self.convs):
                     out_rows = nv.Rows(None, out_rows.batch_stride, out_rows.row_stride, out_rows.batch, out_rows.rows_per_batch)
+                elif ws.last16 is not None and i + 1 == len(self.convs):
+                    # the pooling reads the shadow: no fp32 output, the shadow at its own (8-channel padded) strides
+                    l16 = ws.last16
+                    out_rows = nv.Rows(None, l16.shape[1] * l16.shape[2], l16.shape[2], out_rows.batch, out_rows.rows_per_batch)
+                    sh = nv.ptr(l16)
                 nv.check(lib.lidbox_gemm_bf16s_nt(self._rows16(self._conv_rows_in(ws, i), ws.act[i], ws.act16[i]),
                                                   nv.ptr(self.w16t[i]), c.k * cin, out_rows, sh, c.k * cin, c.filters,
                                                   nv.EPI_BIAS_RELU if c.relu else nv.EPI_BIAS, self._p(c.name + ".b"),
@@ -770,8 +784,12 @@ class SequentialTDNN:
             nv.check(lib.lidbox_freq_attention_fwd(nv.ptr(last), nv.ptr(ws.fa_F), n, C, att.d_f, nv.ptr(ws.fa_F),
                                                    nv.ptr(ws.hw), st))
             last = ws.hw
-        fn = lib.lidbox_stats_pool_fwd if self.pool == "stats" else lib.lidbox_avg_pool_fwd
-        nv.check(fn(nv.ptr(last), ws.B, T, C, T * C, C, nv.ptr(ws.pooled), st))
+        if ws.last16 is not None:
+            C16 = ws.last16.shape[2]
+            nv.check(lib.lidbox_stats_pool_fwd_bf16(nv.ptr(ws.last16), ws.B, T, C, T * C16, C16, nv.ptr(ws.pooled), st))
+        else:
+            fn = lib.lidbox_stats_pool_fwd if self.pool == "stats" else lib.lidbox_avg_pool_fwd
+            nv.check(fn(nv.ptr(last), ws.B, T, C, T * C, C, nv.ptr(ws.pooled), st))
         x, din = ws.pooled, ws.pooled.shape[1]
         for j, d in enumerate(self.denses):
             if stop_before_output and j == len(self.denses) - 1:
@@ -910,7 +928,12 @@ class SequentialTDNN:
         relu_last = 1 if self.convs[-1].relu else 0
         pool_mask = relu_last if att is None else 0          # with attention the pooling input is not a ReLU output
         d16 = ws.dact16[-1] if att is None else None
-        if self.pool == "stats" and d16 is not None and B * T > 0:
+        if ws.last16 is not None and d16 is not None and B * T > 0:
+            C16 = ws.last16.shape[2]
+            nv.check(lib.lidbox_stats_pool_bwd_bf16(nv.ptr(ws.last16), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C16, C16,
+                                                    pool_mask, nv.ptr(d16), T * d16.shape[2], d16.shape[2], st))
+            ws.d16_fresh.add(len(self.convs))
+        elif self.pool == "stats" and d16 is not None and B * T > 0:
             # the last conv's output gradient and its bf16 shadow (rows possibly padded) in one pass
             nv.check(lib.lidbox_stats_pool_bwd_shadow(nv.ptr(last), nv.ptr(ws.pooled), nv.ptr(ws.dpooled), B, T, C, T * C, C,
                                                       pool_mask, None if self.bf16_only else nv.ptr(dlast), nv.ptr(d16),

@@ -146,8 +146,9 @@ def test_config5_bf16_train_step_tracks_fp32(use_graph):
 def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
     """the bf16-storage GEMMs (bf16 shadows of activations / gradients / weights: lidbox_gemm_bf16s_nt / _tn) compute what the
     fp32-source bf16 kernels compute: rounding happens where a shadow is written instead of where an operand is read.
-    Three builds of the same model: shadows next to fp32 copies (LIDBOX_BF16_FP32_COPIES=1), shadows only (the default: the
-    fp32 copies of the intermediates have no reader and are not written), and the fp32-source kernels."""
+    Four builds of the same model: shadows next to fp32 copies (LIDBOX_BF16_FP32_COPIES=1), shadows only with an fp32 copy of
+    the last frame layer's output for the pooling (LIDBOX_BF16_POOL_FP32=1), shadows only (the default: no fp32 copy of any
+    intermediate is written, the pooling reads the last layer's shadow), and the fp32-source kernels."""
     from lidbox_amd import _native as nv
     from lidbox_amd.features import audio
     from lidbox_amd.models import xvector
@@ -158,11 +159,12 @@ def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
     yd = torch.from_numpy(y.astype(np.int32)).cuda()
     plan = audio.get_plan(16000, 400, 160)
     res = {}
-    for tag, storage, copies in (("copies", "1", "1"), ("only", "1", "0"), ("source", "0", "0")):
+    for tag, storage, copies, pool32 in (("copies", "1", "1", "0"), ("only32", "1", "0", "1"), ("only", "1", "0", "0"), ("source", "0", "0", "0")):
         monkeypatch.setenv("LIDBOX_BF16_STORAGE", storage)
         monkeypatch.setenv("LIDBOX_BF16_FP32_COPIES", copies)
+        monkeypatch.setenv("LIDBOX_BF16_POOL_FP32", pool32)
         m = xvector.create((98, 40), 4, seed=0, compute_dtype="bfloat16")
-        assert m.bf16_storage == (storage == "1") and m.bf16_only == (tag == "only")
+        assert m.bf16_storage == (storage == "1") and m.bf16_only == (tag in ("only", "only32"))
         t = Trainer(m, feature=dict(plan=plan, kind=nv.FEAT_LOGMEL), use_graph=(tag != "source"))
         loss, g = t.loss_and_grads(sd, yd)
         res[tag] = (float(loss), g.clone())
@@ -182,14 +184,27 @@ def test_bf16_storage_path_equals_fp32_source_path(monkeypatch):
             # frame2 (k = 3 > s = 2) takes the output-stationary dgrad: its output gradient carries one zero trail row per
             # utterance, and the causal pad rows of dact[1] are never written
             assert ws.trail == [0, 0, 1, 0, 0, 0] and not ws.dact[2][:, -1, :].any() and not ws.dact[1][:, :2, :].any()
+            assert ws.last16 is None
             shadows = [a.clone() for a in ws.act16[:5]] + [d.clone() for d in ws.dact16[1:]]
-        elif tag == "only":
+            last32 = ws.act[5].clone()
+        elif tag == "only32":
             # same shadows bit for bit, and the fp32 copies of the intermediates were never touched
             now = list(ws.act16[:5]) + list(ws.dact16[1:])
-            assert all(torch.equal(a, b) for a, b in zip(shadows, now))
+            assert ws.last16 is None and all(torch.equal(a, b) for a, b in zip(shadows, now))
             assert all(not ws.act[j].any() for j in range(1, 5)) and all(not ws.dact[j].any() for j in range(1, 6))
+        elif tag == "only":
+            # the pooling reads frame5's shadow (1500 channels in 1504-wide rows) = bf16 of what the fp32 copy held; no fp32
+            # activation behind the model input is written at all
+            assert ws.last16 is not None and ws.last16.shape == (16, ws.Ts[-1], 1504)
+            assert torch.equal(ws.last16[:, :, :1500], last32.bfloat16()) and not ws.last16[:, :, 1500:].any()
+            assert all(not ws.act[j].any() for j in range(1, 6)) and all(not ws.dact[j].any() for j in range(1, 6))
+            assert all(torch.equal(a, b) for a, b in zip(shadows[:5], ws.act16[:5]))
     # shadows-only changes where the ReLU masks are read (signs of the bf16 values): nothing else
-    assert res["only"][0] == res["copies"][0] and torch.equal(res["only"][1], res["copies"][1])
+    assert res["only32"][0] == res["copies"][0] and torch.equal(res["only32"][1], res["copies"][1])
+    # the pooling over the shadow sees frame5's output rounded to bf16 -- as a Keras mixed_bfloat16 layer output is: one more
+    # rounding of relative size 2^-9 per element ahead of a 33-frame mean
+    assert abs(res["only"][0] - res["only32"][0]) <= 2e-4 * abs(res["only32"][0])
+    assert float(torch.linalg.norm(res["only"][1] - res["only32"][1]) / torch.linalg.norm(res["only32"][1])) <= 1e-2
     # the storage and fp32-source paths accumulate K in different chunk orders (64- vs 32-deep tiles), so an activation can
     # land on the other side of a bf16 rounding boundary here and there: agreement far below one bf16 step (4e-3), not bit
     # equality; the bias gradients of the storage path are summed from the shadows

@@ -242,6 +242,37 @@ def test_stats_and_avg_pool():
     assert np.allclose(out[:, 5:].cpu().numpy(), 1e-5, rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,T,C", [(3, 33, 1500), (2, 1, 8), (5, 40, 64), (4, 12, 260)])
+def test_stats_pool_over_a_bf16_shadow(B, T, C):
+    """lidbox_stats_pool_fwd_bf16 / _bwd_bf16 (the bf16 policy's all-shadow mode: the pooling reads the last frame layer's bfloat16
+    shadow, rows padded to 8 channels): bit-identical to the fp32 kernels fed the shadow's values, hence within the fp32 kernels'
+    tolerance of the oracle on those values; shapes the register kernels do not cover are refused"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(B * 100 + T)
+    Cp = (C + 7) // 8 * 8
+    x16 = torch.zeros((B, T, Cp), dtype=torch.bfloat16, device="cuda")
+    x16[:, :, :C] = _dev(rng.standard_normal((B, T, C)) * 2 + 0.3).bfloat16()
+    x32 = x16[:, :, :C].float().contiguous()
+    st = nv.current_stream()
+    out, ref = torch.zeros((B, 2 * C), device="cuda"), torch.zeros((B, 2 * C), device="cuda")
+    nv.check(nv.lib.lidbox_stats_pool_fwd_bf16(nv.ptr(x16), B, T, C, T * Cp, Cp, nv.ptr(out), st))
+    nv.check(nv.lib.lidbox_stats_pool_fwd(nv.ptr(x32), B, T, C, T * C, C, nv.ptr(ref), st))
+    assert torch.equal(out, ref)
+    _close(out.cpu().numpy(), mo.stats_pool_fwd(x32.cpu().double().numpy()), 1e-5)
+    dout = _dev(rng.standard_normal((B, 2 * C)))
+    for mask in (0, 1):
+        sh = torch.full((B, T, Cp), 3.0, dtype=torch.bfloat16, device="cuda")
+        sh_ref = torch.full((B, T, Cp), 3.0, dtype=torch.bfloat16, device="cuda")
+        nv.check(nv.lib.lidbox_stats_pool_bwd_bf16(nv.ptr(x16), nv.ptr(out), nv.ptr(dout), B, T, C, T * Cp, Cp, mask, nv.ptr(sh), T * Cp, Cp, st))
+        nv.check(nv.lib.lidbox_stats_pool_bwd_shadow(nv.ptr(x32), nv.ptr(out), nv.ptr(dout), B, T, C, T * C, C, mask, None, nv.ptr(sh_ref),
+                                                     T * Cp, Cp, st))
+        assert torch.equal(sh, sh_ref)                              # pad columns untouched by both
+    with pytest.raises(ValueError):                                 # 41 frames: not a register-kernel shape
+        nv.check(nv.lib.lidbox_stats_pool_fwd_bf16(nv.ptr(x16), B, 41, C, T * Cp, Cp, nv.ptr(out), st))
+    with pytest.raises(ValueError):                                 # odd row stride
+        nv.check(nv.lib.lidbox_stats_pool_fwd_bf16(nv.ptr(x16), B, T, C, T * Cp, Cp + 2, nv.ptr(out), st))
+
+
 def test_log_softmax_nll():
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(6)

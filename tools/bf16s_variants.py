@@ -17,6 +17,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
              ("frame4 fwd", 33 * B, 512, 512, False, False), ("frame5 fwd", 33 * B, 512, 1504, True, False),
              ("frame5 dgrad", 33 * B, 1504, 512, False, True), ("frame4 dgrad", 33 * B, 512, 512, False, True), ("frame3 dgrad", 33 * B, 512, 1536, False, True),
              ("frame2 dgrad r0", 99 * B, 1024, 512, False, True), ("frame2 dgrad r1", 99 * B, 512, 512, False, True)]
+    if os.environ.get("BF16S_FRAME5_SHADOW_ONLY", "1") == "1":      # the all-shadow mode's pooling reads frame5's shadow (round 5)
+        CALLS = [(n, M, K, N, False, m) for n, M, K, N, _, m in CALLS]
+    if os.environ.get("BF16S_CALLS"):
+        CALLS = [c for c in CALLS if c[0] in os.environ["BF16S_CALLS"].split(";")]
     st = nv.current_stream()
     for name, M, K, N, keep32, mask in CALLS:
         a = torch.randn(M, K, device="cuda").bfloat16(); b = torch.randn(N, K, device="cuda").bfloat16()
