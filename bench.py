@@ -238,6 +238,8 @@ class KernelTimer:
                     self.nv.check(self.nv.lib.lidbox_gemm_bf16s_last_variant(out3))
                     if out3[0] == 256:     # the eight-wave ping-pong tile (gemm16_pp.h): <BN, SUB>
                         key = "gemm16s_rows_pp_kernel<%d, %d>" % (out3[1], out3[2])
+                    elif out3[0] == 1:     # the K-resident short-contraction kernel (gemm16_kres.h)
+                        key = "gemm16s_rows_kres_kernel"
                     elif out3[0]:
                         key = "gemm16s_rows_dma_kernel<%d, %d, %d>" % (out3[0], out3[1], out3[2])
                 elif self.ENTRY[_n] in (14, 16):

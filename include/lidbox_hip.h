@@ -330,7 +330,10 @@ int lidbox_gemm_bf16s_nt(lidbox_rows_t A16, const void* B16, long ldb, lidbox_ro
  * values.  Needs 16-byte aligned bases, row / batch strides % 8 == 0, and K1 / N % 8 == 0 or rows padded to a multiple
  * of 8 elements (row_stride >= the width rounded up to 8: a 1500-channel gradient lives in a 1504-wide shadow). */
 /* Kernel variant of the calling thread's most recent lidbox_gemm_bf16s_nt (profiling tools): out3 = {tile rows, tile columns,
- * LDS ring stages} of the LDS-DMA instantiation gemm16s_rows_dma_kernel, or zeros for the register-staged 128 x 128 kernel. */
+ * LDS ring stages} of the LDS-DMA instantiation gemm16s_rows_dma_kernel; {256, tile columns, sub-steps} for the eight-wave
+ * ping-pong tile (gemm16_pp.h); {1, 64, 1} for the K-resident short-contraction kernel (gemm16_kres.h: K <= 208 over windows of
+ * utterances whose 32-row frame image fits 3 KB -- the x-vector's first frame layer; LIDBOX_GEMM16S_KRES=0 / 1 forces never /
+ * whenever it can run); zeros for the register-staged 128 x 128 kernel. */
 int lidbox_gemm_bf16s_last_variant(int* out3);
 size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N);
 int lidbox_gemm_bf16s_tn(lidbox_rows_t A16, lidbox_rows_t B16, float* C, long ldc, int K1, int N,

@@ -570,6 +570,7 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
 #include "gemm16_dma.h"
 #include "gemm16_pp.h"
 #include "gemm16_pp_tn.h"
+#include "gemm16_kres.h"
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -1183,6 +1184,50 @@ int launch_rows16s(const char* fn, lidbox_rows_t A, const void* B16, long ldb, l
     const RowsH Ah_{(const __bf16*)A.base, A.batch_stride, A.row_stride, A.batch, A.rows_per_batch};
     const RowsH Bh_{(const __bf16*)B16, 0, ldb, 1, 0};
     {
+        // short contraction over overlapping windows of short utterances (frame1's forward): both operands resident in LDS
+        // (gemm16_kres.h).  LIDBOX_GEMM16S_KRES=0 | 1: never | whenever it can run (tuning aid)
+        {
+            int mode = -1;
+            if (const char* e = getenv("LIDBOX_GEMM16S_KRES")) mode = atoi(e);
+            const int base_epi = epi & ~LIDBOX_EPI_MASK_BF16;
+            const bool epi_ok = base_epi == LIDBOX_EPI_NONE || base_epi == LIDBOX_EPI_BIAS || base_epi == LIDBOX_EPI_BIAS_RELU || base_epi == LIDBOX_EPI_RELU;
+            // vector stores: whole 8-column chunks on 16-byte (fp32) / 8-byte (shadow) boundaries
+            const bool c_ok = ((Cd.batch == A.batch && Cd.rows_per_batch == A.rows_per_batch) || Cd.batch == 1) && N % 8 == 0 &&
+                              Cd.row_stride % 4 == 0 && (Cd.batch == 1 || Cd.batch_stride % 4 == 0) && aligned16(Cd.base) &&
+                              (((uintptr_t)C16) & 7) == 0;
+            const int tiles_n = (int)lbx_cdiv(N, KRES_BN);
+            const double a_span = ((double)(A.batch - 1) * (double)A.batch_stride + (double)A.rows_per_batch * (double)A.row_stride + K) * 2.0;
+            const bool can = mode != 0 && rj.total == 0 && epi_ok && c_ok && mask16 == nullptr && kres_applies(A, K, N) && A.batch_stride >= 0 &&
+                             a_span < 4.0e9 && tiles_n <= NUM_CU &&
+                             ((double)(A.rows_per_batch - 1) * (double)A.row_stride + K) * 2.0 < 2.0e9;
+            // worth it when the launch is a store stream: windows that overlap (row stride < K) and enough utterances to keep every
+            // CU's workgroup busy for a few tiles
+            if (can && (mode == 1 || (A.row_stride * 2 <= K && (long)A.batch * tiles_n >= 2 * NUM_CU))) {
+                int dev = 0;
+                LBX_HIP(hipGetDevice(&dev));
+                static std::atomic<unsigned long long> kres_attr{0};
+                if (dev < 64 && !((kres_attr.load() >> dev) & 1ull)) {
+                    LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_kres_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, KRES_LDS_BYTES));
+                    LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_kres_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, KRES_LDS_BYTES));
+                    kres_attr.fetch_or(1ull << dev);
+                }
+                const int blocks = (int)lbx_cdiv(A.rows_per_batch, KRES_ROWS);
+                const long nunits = (long)A.batch * blocks;
+                long nstreams = NUM_CU / tiles_n;                               // one workgroup per CU (146 KB of LDS)
+                if (nstreams > lbx_cdiv(nunits, (long)KRES_WAVES)) nstreams = lbx_cdiv(nunits, (long)KRES_WAVES);
+                if (nstreams < 1) nstreams = 1;
+                if (const char* e = getenv("LIDBOX_GEMM16S_KRES_STREAMS")) { const long q = atol(e); if (q >= 1) nstreams = q; }   // tuning aid
+                g16_last_variant[0] = 1; g16_last_variant[1] = KRES_BN; g16_last_variant[2] = 1;      // {1, 64, 1}: the K-resident kernel
+                if ((K + 15) / 16 == 13)                                        // frame1 of the x-vector: K = 200
+                    hipLaunchKernelGGL(gemm16s_rows_kres_kernel<13>, dim3((unsigned)(tiles_n * nstreams)), dim3(64 * KRES_WAVES), KRES_LDS_BYTES, st, Ah_,
+                                       Bh_, Co_, (unsigned short*)C16, K, N, base_epi, aux, tiles_n, (int)nstreams, blocks, nunits);
+                else
+                    hipLaunchKernelGGL(gemm16s_rows_kres_kernel<0>, dim3((unsigned)(tiles_n * nstreams)), dim3(64 * KRES_WAVES), KRES_LDS_BYTES, st, Ah_,
+                                       Bh_, Co_, (unsigned short*)C16, K, N, base_epi, aux, tiles_n, (int)nstreams, blocks, nunits);
+                LBX_LAUNCH_OK();
+                return LIDBOX_OK;
+            }
+        }
         const Dma16Choice dc = choose_dma16(M, N, K, ws ? ws_bytes : 0, Cd.base != nullptr);
         // 32-bit byte offsets per lane inside the kernel: the operands' extents must fit
         const double a_ext = ((double)(A.batch - 1) * (double)A.batch_stride + (double)A.rows_per_batch * (double)A.row_stride + K) * 2.0;

@@ -498,6 +498,99 @@ def test_bf16_storage_wgrad_pingpong_policy_and_fallback(monkeypatch):
     assert run(8448, 512, 512, batched_b=33) == 0  # A flat, B in utterances of 33 rows: the four-wave kernel
 
 
+@pytest.mark.parametrize("Bn,T,C,k,s_,N", [(6, 198, 40, 5, 1, 512),      # frame1 of the x-vector
+                                           (3, 33, 16, 3, 1, 136),        # a column tile that hangs over N, 33-row utterances
+                                           (5, 256, 8, 5, 1, 128),        # utterances as long as the tile
+                                           (4, 100, 8, 5, 2, 264),        # strided windows: K = 40, 50 rows per utterance
+                                           (2, 70, 24, 3, 1, 128)])       # K = 72: a half k slice at the end
+def test_bf16_storage_short_contraction_resident_kernel(Bn, T, C, k, s_, N, monkeypatch):
+    """gemm16s_rows_kres_kernel (gemm16_kres.h: a 64-column weight panel and, per wave, the frames of 32 rows resident in LDS,
+    implicit rows read out of the frame image), forced on: float64 product of the stored values + bias + ReLU, fp32 output and shadow, shadow only, epilogue
+    variants; equal to round-off with the LDS-DMA tiles; refused shapes fall back"""
+    import ctypes
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(Bn * 100 + T)
+    pad = k - 1
+    x = np.zeros((Bn, pad + T, C))
+    x[:, pad:] = rng.standard_normal((Bn, T, C))
+    To = (T - 1) // s_ + 1
+    K = k * C
+    w = rng.standard_normal((N, K)) * 0.1 * (1.0 + 0.01 * np.arange(K))[None, :]
+    bias = rng.standard_normal(N)
+    idx = np.arange(To)[:, None] * s_ + np.arange(k)[None, :]
+    col = _bf16(x)[:, idx, :].reshape(Bn * To, K)
+    pre = col @ _bf16(w).T
+    st = nv.current_stream()
+    x16, w16, bd = _dev(x).bfloat16(), _dev(w).bfloat16(), _dev(bias)
+    ra = nv.Rows(x16.data_ptr(), (pad + T) * C, s_ * C, Bn, To)
+    wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(Bn * To, N, K))
+    ws = _ws(wsb)
+    v = (ctypes.c_int * 3)()
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LIDBOX_GEMM16S_KRES", mode)
+        for epi, ref in ((nv.EPI_BIAS_RELU, np.maximum(pre + bias, 0)), (nv.EPI_BIAS, pre + bias), (nv.EPI_NONE, pre), (nv.EPI_RELU, np.maximum(pre, 0))):
+            c32 = torch.full((Bn, To, N), 7.0, device="cuda")
+            c16 = torch.zeros((Bn, To, N), dtype=torch.bfloat16, device="cuda")
+            nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(w16), K, _rows(c32, To * N, N, Bn, To), nv.ptr(c16), K, N, epi,
+                                                 nv.ptr(bd) if epi in (nv.EPI_BIAS_RELU, nv.EPI_BIAS) else None, nv.ptr(ws), wsb, st))
+            nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(v))
+            assert (list(v) == [1, 64, 1]) == (mode == "1"), list(v)
+            _close(c32.cpu().numpy().reshape(-1, N), ref)
+            assert torch.equal(c16, c32.bfloat16())
+            outs[(mode, epi)] = c32.cpu().double().numpy()
+        # shadow only, into rows wider than N (a padded shadow) through a flat descriptor
+        Np = N + 8
+        sh = torch.full((Bn * To, Np), 3.0, dtype=torch.bfloat16, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra, nv.ptr(w16), K, nv.Rows(None, 0, Np, 1, Bn * To), nv.ptr(sh), K, N, nv.EPI_BIAS_RELU, nv.ptr(bd),
+                                             nv.ptr(ws), wsb, st))
+        nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(v))
+        assert (list(v) == [1, 64, 1]) == (mode == "1")
+        assert torch.equal(sh[:, :N], torch.from_numpy(outs[(mode, nv.EPI_BIAS_RELU)]).float().cuda().reshape(-1, N).bfloat16())
+        assert bool((sh[:, N:] == 3.0).all())
+    for epi in (nv.EPI_BIAS_RELU, nv.EPI_NONE):
+        _close(outs[("1", epi)], outs[("0", epi)], rel=1e-5)
+    # flat rows (one "utterance" of 300 rows, windows that do not overlap) run on it when their 32-row image fits; a ReLU-mask
+    # epilogue (dgrad) is not its business
+    monkeypatch.setenv("LIDBOX_GEMM16S_KRES", "1")
+    a16 = _dev(rng.standard_normal((300, K))).bfloat16()
+    c32 = torch.empty((300, N), device="cuda")
+    ra2, rc2 = nv.Rows(a16.data_ptr(), 0, K, 1, 300), _rows(c32, 0, N, 1, 300)
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra2, nv.ptr(w16), K, rc2, None, K, N, nv.EPI_NONE, None, nv.ptr(ws), wsb, st))
+    nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(v))
+    assert (list(v) == [1, 64, 1]) == (31 * K * 2 + (K + 15) // 16 * 32 <= 3072)
+    ref2 = _bf16(a16.float().cpu().numpy()) @ _bf16(w).T
+    _close(c32.cpu().numpy(), ref2)
+    mk = _dev(rng.standard_normal((300, N)))
+    nv.check(nv.lib.lidbox_gemm_bf16s_nt(ra2, nv.ptr(w16), K, rc2, None, K, N, nv.EPI_RELU_MASK, nv.ptr(mk), nv.ptr(ws), wsb, st))
+    nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(v))
+    assert list(v) != [1, 64, 1]
+    _close(c32.cpu().numpy(), ref2 * (mk.cpu().numpy() > 0))
+
+
+def test_bf16_storage_short_contraction_policy(monkeypatch):
+    """frame1's forward (K = 200 over windows five frames deep) takes the K-resident kernel on its own when there are utterances
+    enough to keep every CU's twelve waves busy (>= 2 x 256 column-tile x utterance pairs); small batches stay on the LDS-DMA tiles"""
+    import ctypes
+    from lidbox_amd import _native as nv
+    monkeypatch.delenv("LIDBOX_GEMM16S_KRES", raising=False)
+    st = nv.current_stream()
+    v = (ctypes.c_int * 3)()
+    for Bn, want in ((256, True), (64, True), (16, False)):
+        x16 = torch.randn(Bn, 202, 40, device="cuda").bfloat16()
+        w16 = (torch.randn(512, 200, device="cuda") * 0.05).bfloat16()
+        c16 = torch.empty(Bn, 198, 512, dtype=torch.bfloat16, device="cuda")
+        wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(Bn * 198, 512, 200))
+        ws = _ws(wsb)
+        nv.check(nv.lib.lidbox_gemm_bf16s_nt(nv.Rows(x16.data_ptr(), 202 * 40, 40, Bn, 198), nv.ptr(w16), 200, nv.Rows(None, 198 * 512, 512, Bn, 198),
+                                             nv.ptr(c16), 200, 512, nv.EPI_RELU, None, nv.ptr(ws), wsb, st))
+        nv.check(nv.lib.lidbox_gemm_bf16s_last_variant(v))
+        assert (list(v) == [1, 64, 1]) == want, (Bn, list(v))
+        col = x16.float().unfold(1, 5, 1).permute(0, 1, 3, 2).reshape(Bn * 198, 200)         # [b, t, tap, channel]
+        ref = torch.relu(col.double() @ w16.double().T)
+        assert float((c16.double().reshape(-1, 512) - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+
+
 def test_refresh_bf16_weights_one_launch():
     """flat -> flat16 plus bf16 images of listed matrices inside it (the per-step weight-shadow refresh): transposed,
     row-padded, and blocks side by side in one destination"""
