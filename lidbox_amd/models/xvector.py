@@ -39,12 +39,11 @@ class GlobalMeanStddevPooling1D:
 
 def frame_layer(filters, kernel_size, strides, padding="causal", activation="relu", name="frame", dilation_rate=1):
     """reference xvector.py:38-39.  dilation_rate is not in the reference (its third argument is Keras `strides`);
-    it is this build's opt-in for Kaldi-style dilated TDNN contexts and follows Keras Conv1D(dilation_rate=...)."""
-    if padding != "causal":
-        raise ValueError("only padding='causal' is supported")
+    it is this build's opt-in for Kaldi-style dilated TDNN contexts and follows Keras Conv1D(dilation_rate=...).
+    padding: "causal" (what every reference model uses), "valid" or "same", as Keras Conv1D takes them."""
     if activation not in ("relu", None):
         raise ValueError("activation must be 'relu' or None")
-    return ConvSpec(name, filters, kernel_size, strides, relu=(activation == "relu"), dilation_rate=dilation_rate)
+    return ConvSpec(name, filters, kernel_size, strides, relu=(activation == "relu"), dilation_rate=dilation_rate, padding=padding)
 
 
 def segment_layer(units, activation="relu", name="segment"):

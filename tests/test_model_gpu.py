@@ -413,6 +413,9 @@ def test_cnn_padding_modes_match_oracle(padding, T, compute_dtype):
     assert abs(l0 - float(ref_loss.detach())) < tol and l1 < l0
     with pytest.raises(ValueError):
         cnn.create((T, 12), 4, padding="full")
+    # xvector.frame_layer hands `padding` to Conv1D too (reference xvector.py:38-39)
+    from lidbox_amd.models import xvector
+    assert xvector.frame_layer(8, 7, 2, padding=padding).geometry(T) == mo.conv1d_padding(T, 7, 2, 1, padding)
 
 
 def test_angular_proximity_head_train_step():
