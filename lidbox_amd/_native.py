@@ -75,6 +75,8 @@ _SIGS = {
     "lidbox_extract_features_workspace": (_sz, [_vp, _i, _i, _i, _vp, _l]),
     "lidbox_extract_features_fwd": (_i, [_vp, _i, _vp, _i, _i, _l, _vp, _l, _vp, _sz, _vp]),
     "lidbox_extract_features_fwd_shadow": (_i, [_vp, _i, _vp, _i, _i, _l, _vp, _l, _vp, _vp, _sz, _vp]),
+    "lidbox_extract_features_fwd_ex": (_i, [_vp, _i, _vp, _i, _i, _i, _l, _vp, _l, _vp, _vp, _vp, _sz, _vp]),
+    "lidbox_extract_features_fwd_pcm16": (_i, [_vp, _i, _vp, _i, _i, _l, _vp, _l, _vp, _vp]),
     "lidbox_cmvn_fwd": (_i, [_vp, _l, _l, _l, _i, _vp, _vp]),
     "lidbox_cmvn_strided_fwd": (_i, [_vp, _l, _l, _l, _l, _i, _vp, _l, _vp]),
     "lidbox_window_norm_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

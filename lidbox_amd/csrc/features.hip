@@ -101,6 +101,7 @@ struct lidbox_feat_plan {
     int device;
     // device tables
     float*  d_win512;        // [512] 0.5*hann (zero beyond L)           (fused)
+    float*  d_win512_pcm;    // [512] the same / 32768: 16-bit PCM sources read in place (tf.audio.decode_wav's scale, audio.py:17-23)
     float2* d_tw256;         // [16 k1][16 n2]  W256^(n2*k1)             (fused)
     float2* d_tw512;         // [256]           W512^k                   (fused)
     float*  d_win;           // [L] hann                                 (generic)
@@ -204,6 +205,8 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     std::vector<float> win(L), win512(516, 0.0f);      // [512..515] stay zero: the load target of masked lanes
     lidbox_hann_window(L, win.data());
     for (int i = 0; i < Leff && i < 512; ++i) win512[i] = 0.5f * win[i];
+    std::vector<float> win512_pcm(512);
+    for (int i = 0; i < 512; ++i) win512_pcm[i] = win512[i] * (1.0f / 32768.0f);      // exact: a power of two
     // twiddles (double -> float)
     std::vector<float2> tw256(256), tw512(256), twN(nfft);
     for (int k1 = 0; k1 < 16; ++k1)
@@ -289,7 +292,8 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     size_t o_bc = o_sw + al(seg_w.size() * 4);
     size_t o_bh = o_bc + al(bs_chirp.size() * 8);
     size_t o_bt = o_bh + al(bs_bhat.size() * 8);
-    size_t total = o_bt + al(bs_tw.size() * 8);
+    size_t o_wp = o_bt + al(bs_tw.size() * 8);
+    size_t total = o_wp + al(512 * 4);
     char* blk = nullptr;
     if (hipMalloc((void**)&blk, total) != hipSuccess) {
         lidbox_set_error("lidbox_feat_plan_create: hipMalloc(%zu) failed", total);
@@ -318,6 +322,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     LBX_UP(o_bc, bs_chirp.data(), bs_chirp.size() * 8);
     LBX_UP(o_bh, bs_bhat.data(), bs_bhat.size() * 8);
     LBX_UP(o_bt, bs_tw.data(), bs_tw.size() * 8);
+    LBX_UP(o_wp, win512_pcm.data(), 512 * 4);
 #undef LBX_UP
     p->d_win512 = (float*)(blk + o_win512);
     p->d_tw256 = (float2*)(blk + o_tw256);
@@ -334,6 +339,7 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
     p->d_bs_chirp = (float2*)(blk + o_bc);
     p->d_bs_bhat = (float2*)(blk + o_bh);
     p->d_bs_tw = (float2*)(blk + o_bt);
+    p->d_win512_pcm = (float*)(blk + o_wp);
 
     // fused path limits: LDS tables must leave room for >= 2 workgroups per CU
     p->fused_ok = (nfft == 512) && (L <= 512) && (M <= 64) && (p->nnz <= 1024) &&
@@ -358,19 +364,8 @@ extern "C" int lidbox_feat_plan_channels(const lidbox_feat_plan* p, int kind) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-#ifndef LBX_FEAT_UNTANGLE_FENCE
-#define LBX_FEAT_UNTANGLE_FENCE 0           // n > 0: scheduling fence after every n untangle slots (register-pressure experiment)
-#endif
 #ifndef LBX_FEAT_NO_HOIST
 #define LBX_FEAT_NO_HOIST 1                  // keep the untangle's per-lane addresses out of loop-invariant registers
-#endif
-#ifndef LBX_FEAT_PRUNE13
-#define LBX_FEAT_PRUNE13 0                  // 1: skip the always-zero samples 416..511 of frames <= 416 samples (loads, window products, pass-1 inputs);
-                                            // measured SLOWER for log-mel (28.7 vs 28.0 us at B = 256, 160.6 vs 156.4 at 2048: the wave-uniform branch
-                                            // duplicates the load + pass-1 code and costs 8 registers), neutral for MFCC -- off
-#endif
-#ifndef LBX_FEAT_LANE0_V2
-#define LBX_FEAT_LANE0_V2 1                 // 0: round 1's lane-0 pairing of the untangling (A/B aid)
 #endif
 #ifndef LBX_FEAT_SEGMEL
 #define LBX_FEAT_SEGMEL 1                   // 0: always use the per-band CSR mel loop (A/B aid)
@@ -409,26 +404,48 @@ struct FusedArgs {
     float* out;
     long out_bs;                // floats between consecutive utterances in out
     unsigned short* out16;      // SHADOW instantiations: bfloat16 copy of the output (round-to-nearest-even) at the same ELEMENT offsets as out
+    int* nonfinite;             // may be NULL: |= 1 when a stored feature value is not finite
     int tiles_per_utt;          // ceil(T / 8)
     long ntiles;                // B * tiles_per_utt
     int iters;                  // tiles per wave
     int tiles_per_wg;           // consecutive tiles one workgroup owns (its waves take them round-robin)
     unsigned nwg;
-#ifdef LBX_FEAT_TIMING
-    long long* stamps;          // [nwg*4][12] s_memtime samples of each wave's first tile (debug builds only)
+#if defined(LBX_FEAT_TIMING) || defined(LBX_FEAT_TIMELINE)
+    long long* stamps;          // [nwg*NW][16] s_memtime samples of each wave's LBX_FEAT_TIMING-th tile, 12 = kernel entry, 13 = tables staged,
+                                // 14 = wave exit, 15 = s_memrealtime at exit (debug builds only)
 #endif
 };
 
+// Debug builds.  -DLBX_FEAT_TIMING=k: per-phase s_memtime stamps of every wave's k-th tile (scheduling fences around each stamp:
+// the phase split is approximate and the build is slower).  -DLBX_FEAT_TIMELINE=k: only the kernel-level stamps and the k-th
+// tile's first and last, no fences (tools/feat_timeline.py).
+#ifdef LBX_FEAT_TIMELINE
+#define LBX_FEAT_TIMING LBX_FEAT_TIMELINE
+#define LBX_STAMP_FENCE() do { } while (0)
+#define LBX_STAMP_ON(i) ((i) == 0 || (i) == 8)
+#else
+#define LBX_STAMP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define LBX_STAMP_ON(i) true
+#endif
 #ifdef LBX_FEAT_TIMING
 #define LBX_STAMP(i)                                                                              \
     do {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (it == LBX_FEAT_TIMING && lane == 0 && a.stamps)                                       \
-            a.stamps[((long)blockIdx.x * 4 + wave) * 12 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
+        LBX_STAMP_FENCE();                                                                        \
+        if (LBX_STAMP_ON(i) && it == LBX_FEAT_TIMING && lane == 0 && a.stamps)                    \
+            a.stamps[((long)blockIdx.x * NW + wave) * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+        LBX_STAMP_FENCE();                                                                        \
+    } while (0)
+#define LBX_STAMP_K(i)                                                                            \
+    do {                                                                                          \
+        LBX_STAMP_FENCE();                                                                        \
+        if ((threadIdx.x & 63) == 0 && a.stamps)                                                  \
+            a.stamps[((long)blockIdx.x * NW + (threadIdx.x >> 6)) * 16 + (i)] =                   \
+                ((i) == 15 || (i) == 11) ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime(); \
+        LBX_STAMP_FENCE();                                                                        \
     } while (0)
 #else
 #define LBX_STAMP(i) do { } while (0)
+#define LBX_STAMP_K(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -458,8 +475,8 @@ __device__ __forceinline__ void dft4_z3(float2& x0, float2& x1, float2& x2, floa
 // register that holds X[k] after dft16 (digit-reversed)
 #define R16(k) (4 * ((k) & 3) + ((k) >> 2))
 
-// forward 16-point DFT in place; input v[n] natural order, output X[k] in v[R16(k)].  NIN (13 ... 16): inputs v[NIN ...] are
-// zero and are never read (pass 1 of a frame of <= 32 * NIN samples: 25 ms at 16 kHz is 400 <= 416).
+// forward 16-point DFT in place; input v[n] natural order, output X[k] in v[R16(k)].  NIN (13 or 16): inputs v[NIN ...] are zero and
+// are never read (pass 1 of a frame of <= 32 * NIN samples: 25 ms at 16 kHz is 400 <= 416).
 template <int NIN = 16>
 __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
@@ -498,15 +515,309 @@ __host__ __device__ inline int mel_table_floats(bool segmel, int M, int nnz, int
     return segmel ? 3 * 64 + seg_len * 64 : 3 * M + nnz;
 }
 
-// NW = waves per workgroup.  4: the round-1 shape, three workgroups per CU (every workgroup stages its own copy of the
-// tables: 3 x 9.7 KB).  14 ("wide", log-mel only): ONE persistent workgroup per CU whose 14 waves share one copy of the
-// tables -- 9.7 + 14 x 10.3 KB = 154 KB of the 160 -- i.e. 3.5 waves per SIMD instead of 3 at <= 128 registers, and every CU
-// gets the same number of consecutive tiles (+- 1).  Round 4's counters (profiles/r04_feature_census.txt) show the kernel
-// waiting, not issuing: a wave64 vector instruction costs ~2.3 cycles (tools/micro/valu_rate2), the 1 606 of a tile ~3.7 k
-// of the ~8 k cycles a SIMD spends per tile, and waves are parked 36 % of their cycles.
-template <int KIND, bool VEC4, bool POW2, bool SEGMEL, int NW = 4, bool SHADOW = false>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_feat512_kernel(const FusedArgs a) {
-    constexpr int NT = 64 * NW;
+
+// value of lane + d (d < 64; callers only use it where lane + d <= 63).  __shfl_down derives the lane index itself; hipcc hoists that
+// out of the tile loop as one more live register (and spills it at the streaming kernel's cap): the caller's own copy is used instead.
+__device__ __forceinline__ float lane_down(const float v, const int d, const int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + d) & 63) << 2, __builtin_bit_cast(int, v)));
+}
+
+// ---- tile pieces shared by fused_feat512_kernel and feat512_stream_kernel -------------------------------------------------------
+// Steps 2-6 of a tile.  za / zb: the windowed packed samples of lane q (n2 = 2q / 2q + 1, n1 = 0..15) of frame slot f.  Leaves
+// |X[bin]|^power of the wave's 8 frames in its power buffer (wbuf: [8][P_STRIDE], or TRANSPOSED [PT_ROWS][8] with one skew row per
+// 8 bins, so that the mel lanes -- one per run of bins -- read their 32-byte rows from different banks).  The exchange uses the same
+// bytes.  stamp(i): phase stamps of the timing builds.
+template <bool POW2, bool TRANSPOSED, int NIN = 16, typename Stamp>
+__device__ __forceinline__ void fft512_power_tile(float2 (&za)[16], float2 (&zb)[16], char* wbuf, const int q, const int f,
+                                                  const float2* s_tw256, const float2* s_tw512, const float power_half, Stamp&& stamp) {
+    float* s_P = reinterpret_cast<float*>(wbuf);
+    // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
+    dft16<NIN>(za);
+    dft16<NIN>(zb);
+    stamp(2);
+    // ---- 3. twiddle by W256^(n2*k1)
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const float4 w = *reinterpret_cast<const float4*>(&s_tw256[k1 * 16 + 2 * q]);
+        za[R16(k1)] = cmul(za[R16(k1)], make_float2(w.x, w.y));
+        zb[R16(k1)] = cmul(zb[R16(k1)], make_float2(w.z, w.w));
+    }
+    stamp(3);
+    // ---- 4. exchange through LDS in two half passes; lane q ends with
+    //         ua = A[0..15][k1 = q], ub = A[0..15][k1 = (16 - q) % 16, or 8 for q = 0]
+    float2 ua[16], ub[16];
+    char* ex = wbuf + f * EXCH_FRAME;
+    wave_lds_sync();                                 // previous tile's readers are done
+#ifdef LBX_ABL_NOEXCH
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { ua[j] = za[j]; ub[j] = zb[j]; }
+    (void)ex;
+#else
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+        *reinterpret_cast<float4*>(ex + k1 * EXCH_ROW + q * 16) =
+            make_float4(za[R16(k1)].x, za[R16(k1)].y, zb[R16(k1)].x, zb[R16(k1)].y);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(ex + q * EXCH_ROW + j * 16);
+        ua[2 * j] = make_float2(v.x, v.y);
+        ua[2 * j + 1] = make_float2(v.z, v.w);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k1 = 8; k1 < 16; ++k1)
+        *reinterpret_cast<float4*>(ex + (k1 - 8) * EXCH_ROW + q * 16) =
+            make_float4(za[R16(k1)].x, za[R16(k1)].y, zb[R16(k1)].x, zb[R16(k1)].y);
+    wave_lds_sync();
+    const int row2 = (q == 0) ? 0 : 8 - q;           // k1 = 8 for q = 0, else 16 - q
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(ex + row2 * EXCH_ROW + j * 16);
+        ub[2 * j] = make_float2(v.x, v.y);
+        ub[2 * j + 1] = make_float2(v.z, v.w);
+    }
+#endif
+    stamp(4);
+    // ---- 5. pass 2: DFT16 over n2 -> Z'[k1 + 16*k2] in reg R16(k2)
+    dft16(ua);
+    dft16(ub);
+    wave_lds_sync();                                 // exchange reads done before P overwrites
+    stamp(5);
+    // ---- 6. untangle conjugate pairs, |.|^2, into the per-frame power buffer.
+    //   q != 0 : slot s pairs ua[k2=s] (bin q+16s) with ub[k2=15-s] (bin 256-q-16s)
+    // The per-lane bins / LDS addresses of this section depend only on q, so the compiler hoists them out of
+    // the tile loop as ~15 live registers -- and, at the register cap, spills them to scratch and
+    // reloads them here every tile (15 dependent scratch loads in the busiest phase of the kernel).  An opaque
+    // copy of q keeps their (cheap) computation inside the loop instead.
+    int qv = q;
+#if LBX_FEAT_NO_HOIST
+    asm volatile("" : "+v"(qv));
+#endif
+    // Power-buffer addresses: within slots 0-7 and within slots 8-15 the two bins of a slot move by +-16 per slot, and so do their rows
+    // of the transposed layout (bin + bin / 8 moves by 18: 16 s is a multiple of 8), so four per-lane bases and immediate offsets
+    // replace the per-store address arithmetic (round 4's census: 140 integer instructions per tile).
+    auto P_addr = [&](int bin) -> float* { return TRANSPOSED ? s_P + (bin + (bin >> 3)) * 8 + f : s_P + f * P_STRIDE + bin; };
+    constexpr int PSTEP = TRANSPOSED ? 18 * 8 : 16;        // floats between the bins of consecutive slots
+    const bool q0 = (qv == 0);
+    // Lane 0 holds the two self-paired columns (k1 = 0 in ua, k1 = 8 in ub).  Its pairs are laid over the general
+    // pattern (ua[s] with ub[15-s]) so that only ONE operand of a slot differs: slots 0-7 pair ub[s] with ub[15-s]
+    // (bins 8 + 16 s and 248 - 16 s), slots 8-15 pair ua[s] with ua[16-s] (bins 16 s and 256 - 16 s; s = 8 pairs bin 128
+    // with itself), slot 16 pairs ua[0] with itself (bins 0 and 256): 33 selects per tile instead of 65.
+    const int qlo = q0 ? 8 : qv;
+    float* const lo1 = P_addr(qlo);                  // slot s < 8: bin qlo + 16 s
+    float* const hi1 = P_addr(256 - qlo - 112);      //             bin 256 - qlo - 16 s = (this) + 16 (7 - s)
+    float* const lo2 = P_addr(qv + 128);             // slot 8 <= s < 16: bin qv + 16 s
+    float* const hi2 = P_addr(16 - qv);              //             bin 256 - qv - 16 s = (this) + 16 (15 - s)
+    const float2* const twlo = s_tw512 + qlo;
+    const float2* const twhi = s_tw512 + qv;
+#pragma unroll
+    for (int s = 0; s < 17; ++s) {
+        float2 zk, zm, w;
+        float *pk_at, *pm_at;
+        if (s < 8) {
+            const float2 g = ua[R16(s)], l0 = ub[R16(s)];
+            zk = make_float2(q0 ? l0.x : g.x, q0 ? l0.y : g.y);
+            zm = ub[R16(15 - s)];
+            w = twlo[16 * s];
+            pk_at = lo1 + PSTEP * s;
+            pm_at = hi1 + PSTEP * (7 - s);
+        } else if (s < 16) {
+            zk = ua[R16(s)];
+            const float2 g = ub[R16(15 - s)], l0 = ua[R16((16 - s) & 15)];
+            zm = make_float2(q0 ? l0.x : g.x, q0 ? l0.y : g.y);
+            w = twhi[16 * s];
+            pk_at = lo2 + PSTEP * (s - 8);
+            pm_at = hi2 + PSTEP * (15 - s);
+        } else {
+            zk = ua[R16(0)];
+            zm = ua[R16(0)];
+            w = s_tw512[0];
+            pk_at = P_addr(0);
+            pm_at = P_addr(256);
+        }
+        if (s < 16 || q0) {
+            float pk, pm;
+            untangle(zk, zm, w, pk, pm);
+            if (!POW2) {
+                pk = __powf(pk, power_half);
+                pm = __powf(pm, power_half);
+            }
+            *pk_at = pk;
+            *pm_at = pm;
+        }
+    }
+    wave_lds_sync();
+}
+
+// ln(x) for x >= LOG_EPS (mel energies are >= 0, so x + 1e-6 is never denormal): v_log_f32 (log2, 1 ulp) times ln 2 -- what __logf does
+// minus its denormal rescue (a compare, a scale and a select per value)
+__device__ __forceinline__ float ln_pos(const float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
+// Step 7, segmented banded mel: lane = one run of <= seg_len consecutive bins of one band, for all 8 frames of the tile (two
+// 16-byte reads per bin of the transposed power buffer); runs are zero-padded to seg_len so the loop is uniform.  A band's partial
+// sums sit in consecutive lanes and are combined in a fixed order with wave shuffles; the band's first lane finishes (log) and
+// stages: [8][M] for mel / log-mel, [M][8] for MFCC (what the DCT runs read).  s_stage may alias s_P: every read of the power
+// buffer is issued before the first staging write of the same wave.
+template <int KIND>
+__device__ __forceinline__ void segmel_tile(const int lane, const int seg_len, const int seg_steps, const int M, const int* s_segmeta,
+                                            const float* s_segw, const float* s_P, float* s_stage) {
+    const int sband = s_segmeta[lane], bin0 = s_segmeta[64 + lane], sinfo = s_segmeta[128 + lane];
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    // chunks of 4 bins: the 12 LDS reads of a chunk are issued before its 32 FMAs; one LDS round trip per chunk instead of one
+    // per bin.  A row of the transposed buffer is 32 bytes = two ds_read_b128, and the LDS serves a b128 wave access in groups of 16
+    // lanes that cover the 64 banks once only when they hit 16 different 16-byte slots mod 256 bytes: with every lane on the FIRST half
+    // of its row a group can reach 8 of the 16 slots (2-way conflicts by construction).  Odd lanes therefore read the second half first
+    // -- each group holds 8 even and 8 odd lanes -- and carry frames 4-7 in acc[0..3], 0-3 in acc[4..7] until the swap below.  (Round 5
+    // measured this neutral on a kernel that was not LDS-bound, profiles/r05_feature_mel_halfswap_ab.txt; LBX_FEAT_MEL_HALFSWAP=0: off.)
+#ifndef LBX_FEAT_MEL_HALFSWAP
+#define LBX_FEAT_MEL_HALFSWAP 1
+#endif
+    const int half0 = (LBX_FEAT_MEL_HALFSWAP && (lane & 1)) ? 4 : 0, half1 = 4 - half0;
+    for (int j0 = 0; j0 < seg_len; j0 += 4) {
+        float w[4];
+        float4 p0[4], p1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            w[u] = (j < seg_len) ? s_segw[min(j, seg_len - 1) * 64 + lane] : 0.f;
+            const int bin = min(bin0 + j, 256);
+            const float* row = s_P + (bin + (bin >> 3)) * 8;
+            p0[u] = *reinterpret_cast<const float4*>(row + half0);
+            p1[u] = *reinterpret_cast<const float4*>(row + half1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = fmaf(p0[u].x, w[u], acc[0]); acc[1] = fmaf(p0[u].y, w[u], acc[1]);
+            acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
+            acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
+            acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
+        }
+    }
+    if (LBX_FEAT_MEL_HALFSWAP) {
+        const bool sw = (lane & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = acc[i], hi = acc[4 + i];
+            acc[i] = sw ? hi : lo;
+            acc[4 + i] = sw ? lo : hi;
+        }
+    }
+    const int sidx = sinfo & 255, sns = sinfo >> 8;
+    for (int st = 0; st < seg_steps; ++st) {
+        const int d = 1 << st;
+        const bool take = sidx + d < sns;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = lane_down(acc[i], d, lane);
+            acc[i] += take ? t : 0.f;
+        }
+    }
+    if (sband >= 0 && sidx == 0) {
+        if (KIND == LIDBOX_FEAT_MFCC) {
+            *reinterpret_cast<float4*>(s_stage + sband * 8) = make_float4(
+                ln_pos(acc[0] + LOG_EPS), ln_pos(acc[1] + LOG_EPS), ln_pos(acc[2] + LOG_EPS), ln_pos(acc[3] + LOG_EPS));
+            *reinterpret_cast<float4*>(s_stage + sband * 8 + 4) = make_float4(
+                ln_pos(acc[4] + LOG_EPS), ln_pos(acc[5] + LOG_EPS), ln_pos(acc[6] + LOG_EPS), ln_pos(acc[7] + LOG_EPS));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                s_stage[i * M + sband] = (KIND != LIDBOX_FEAT_MEL) ? ln_pos(acc[i] + LOG_EPS) : acc[i];
+        }
+    }
+}
+
+// DCT-II rows of the MFCC kind, same scheme as the mel runs: lane = (coefficient c, run of dct_len bands), all 8 frames at once from
+// the [M][8] log-mel tile; a coefficient's dct_runs partial sums sit in consecutive lanes and are combined in a fixed order.
+// DCT_REGS: the lane's weights are in wd[] (dct_len <= 8) instead of the LDS table.  Result tile [8][ncoef] at s_coef.
+template <bool DCT_REGS, int CH = 4>
+__device__ __forceinline__ void segdct_tile(const int lane, const int dct_runs, const int dct_len, const int ncoef, const int M,
+                                            const float (&wd)[8], const float* s_dct, const float* s_stage, float* s_coef) {
+    static_assert(!DCT_REGS || CH == 4, "register weights come in two groups of four");
+    const int c = lane / dct_runs, run = lane - c * dct_runs;
+    const bool on = c < ncoef;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    const int jend = DCT_REGS ? 8 : dct_len;
+#pragma unroll 2
+    for (int j0 = 0; j0 < jend; j0 += CH) {
+        if (DCT_REGS && j0 >= dct_len) break;
+        float w[CH];
+        float4 p0[CH], p1[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int n = run * dct_len + j0 + u;
+            const bool in = on && j0 + u < dct_len && n < M;
+            const int nn = in ? n : 0;
+            if (DCT_REGS) w[u] = j0 == 0 ? wd[u] : wd[4 + u];      // zero where the run has no band
+            else w[u] = in ? s_dct[nn * ncoef + c] : 0.f;
+            p0[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8);
+            p1[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            acc[0] = fmaf(p0[u].x, w[u], acc[0]); acc[1] = fmaf(p0[u].y, w[u], acc[1]);
+            acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
+            acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
+            acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
+        }
+    }
+    for (int d = 1; d < dct_runs; d <<= 1) {
+        const bool take = run + d < dct_runs;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = lane_down(acc[i], d, lane);
+            acc[i] += take ? t : 0.f;
+        }
+    }
+    if (on && run == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_coef[i * ncoef + c] = acc[i];
+    }
+}
+
+// The staged [8][M] tile (total = valid frames x M floats) out to dst: two float4 per lane where the tile allows it; d16 (SHADOW):
+// the bf16 copy the first Conv1D of the bf16-storage path reads (gemm_bf16.hip), written here instead of by a conversion launch over
+// the whole feature tensor.  Returns bad, turned NaN if a stored value is not finite (v * 0 is 0 or NaN: the sum cannot overflow).
+template <bool SHADOW>
+__device__ __forceinline__ float store_mel_tile(const int lane, const int total, float* dst, unsigned short* d16, const float* s_stage, float bad) {
+    if ((total & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        // 8 x M <= 512 floats (M <= 64 on this path); both reads are issued before the stores
+        const int i0 = 4 * lane, i1 = 256 + 4 * lane;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (i0 < total) v0 = *reinterpret_cast<const float4*>(s_stage + i0);
+        if (i1 < total) v1 = *reinterpret_cast<const float4*>(s_stage + i1);
+        if (i0 < total) *reinterpret_cast<float4*>(dst + i0) = v0;
+        if (i1 < total) *reinterpret_cast<float4*>(dst + i1) = v1;
+        if constexpr (SHADOW) {
+            typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+            const bf4 h0 = {(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w}, h1 = {(__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+            if (i0 < total) *reinterpret_cast<bf4*>(d16 + i0) = h0;
+            if (i1 < total) *reinterpret_cast<bf4*>(d16 + i1) = h1;
+        }
+        bad = fmaf(v0.x, 0.f, bad); bad = fmaf(v0.y, 0.f, bad); bad = fmaf(v0.z, 0.f, bad); bad = fmaf(v0.w, 0.f, bad);
+        bad = fmaf(v1.x, 0.f, bad); bad = fmaf(v1.y, 0.f, bad); bad = fmaf(v1.z, 0.f, bad); bad = fmaf(v1.w, 0.f, bad);
+    } else {
+        for (int i = lane; i < total; i += 64) {
+            const float v = s_stage[i];
+            dst[i] = v;
+            if constexpr (SHADOW) d16[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+            bad = fmaf(v, 0.f, bad);
+        }
+    }
+    return bad;
+}
+
+// The round-1 shape: 4-wave workgroups, three per CU, every workgroup stages its own copy of the tables, a wave loads its tile's
+// samples with plain (guarded) loads at the top of the tile.  Since round 6 this kernel only serves what feat512_stream_kernel does
+// not take: signals that are not 16-byte aligned (VEC4 = false), plans whose bands do not split into 64 runs (SEGMEL = false) or
+// whose tables leave the streaming shape fewer than 8 waves.
+template <int KIND, bool VEC4, bool POW2, bool SEGMEL>
+__global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(const FusedArgs a) {
+    constexpr int NW = 4, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- LDS carve: tables, then one scratch block per wave
     float* s_win = reinterpret_cast<float*>(smem);                    // 2048 B
@@ -530,6 +841,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
     const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
 
     const int tid = threadIdx.x;
+    LBX_STAMP_K(11);
+    LBX_STAMP_K(12);
     for (int i = tid; i < 512; i += NT) s_win[i] = a.win512[i];
     if (tid < 256) {
         s_tw256[tid] = a.tw256[tid];
@@ -552,11 +865,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
                 for (int i = tid; i < a.M * a.ncoef; i += NT) s_dct[i] = a.dct[i];
     }
     __syncthreads();
+    LBX_STAMP_K(13);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane & 7;          // lane within the frame
     const int f = lane >> 3;         // frame slot within the wave
-    float wd[8];                     // DCT weights of this lane's (coefficient, run) -- see step 8
+    float wd[8];                     // DCT weights of this lane's (coefficient, run)
 #pragma unroll
     for (int u = 0; u < 8; ++u) wd[u] = 0.f;
     if (dct_regs) {
@@ -570,6 +884,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
     char* wbuf = smem + table_bytes + wave * wave_bytes;
     float* s_P = reinterpret_cast<float*>(wbuf);                         // [8][P_STRIDE] or (SEGMEL) [PT_ROWS][8]; aliases exchange
     float* s_stage = reinterpret_cast<float*>(wbuf + WAVE_SCRATCH);      // [8][M] (+ [8][ncoef])
+    float bad = 0.f;                                                     // 0, or NaN once a stored value was not finite
 
     const unsigned chunk = xcd_chunk_id(blockIdx.x, a.nwg);
     const long tile0 = (long)chunk * a.tiles_per_wg;
@@ -596,200 +911,61 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
         // utterance -- wave-uniform test; 24 of 25 tiles at 2 s): one base address per lane and immediate offsets,
         // no per-load address selects and no window guards: the samples after a frame are the utterance's own
         // later samples and the window table is zero there.  The guarded path below handles an utterance's last tile.
+        // (Round 2 also measured skipping the always-zero samples 416..511 of frames <= 416 samples behind a wave-uniform branch:
+        // slower for log-mel, 28.7 vs 28.0 us at B = 256, neutral for MFCC; removed.)
         const bool interior = VEC4 && LBX_FEAT_FAST_INTERIOR && (long)(t0 + 7) * a.S + 512 <= a.N;
-        // NL = float4 per lane that can be non-zero: 16, or 13 when frame_length <= 416 (the window table is zero behind the
-        // frame): the three loads, their window products and the zero inputs of pass 1's first radix-4 stage are skipped
-        auto load_window_pass1 = [&](auto nl_tag) {
-            constexpr int NL = decltype(nl_tag)::value;
-            if (interior) {
-                const float* base = src + 4 * q;
+        if (interior) {
+            const float* base = src + 4 * q;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float4 x[8];
+            for (int half = 0; half < 2; ++half) {
+                float4 x[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (8 * half + j < NL) x[j] = *reinterpret_cast<const float4*>(base + 32 * (8 * half + j));
+                for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4*>(base + 32 * (8 * half + j));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int n1 = 8 * half + j;
-                        if (n1 >= NL) continue;
-                        const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);
-                        za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
-                        zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8; ++j) {
+                    const int n1 = 8 * half + j;
+                    const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);
+                    za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
+                    zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
                 }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float4 x[8];
+            for (int half = 0; half < 2; ++half) {
+                float4 x[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (8 * half + j >= NL) continue;
-                        const int idx = 32 * (8 * half + j) + 4 * q;
-                        // masked lanes read four zeros that sit behind the window table (finite whatever the signal holds),
-                        // so the products below need no guards and the lane masks die here
-                        const float* zero4 = a.win512 + 512;
-                        if (VEC4) {
-                            x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : zero4);
-                        } else {
-                            const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : zero4;
-                            const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : zero4;
-                            const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : zero4;
-                            const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : zero4;
-                            x[j] = make_float4(*p0, *p1, *p2, *p3);
-                        }
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = 32 * (8 * half + j) + 4 * q;
+                    // masked lanes read four zeros that sit behind the window table (finite whatever the signal holds),
+                    // so the products below need no guards and the lane masks die here
+                    const float* zero4 = a.win512 + 512;
+                    if (VEC4) {
+                        x[j] = *reinterpret_cast<const float4*>((valid && idx < a.L) ? src + idx : zero4);
+                    } else {
+                        const float* p0 = (valid && idx + 0 < a.L) ? src + idx + 0 : zero4;
+                        const float* p1 = (valid && idx + 1 < a.L) ? src + idx + 1 : zero4;
+                        const float* p2 = (valid && idx + 2 < a.L) ? src + idx + 2 : zero4;
+                        const float* p3 = (valid && idx + 3 < a.L) ? src + idx + 3 : zero4;
+                        x[j] = make_float4(*p0, *p1, *p2, *p3);
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int n1 = 8 * half + j;
-                        if (n1 >= NL) continue;
-                        const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);      // zero beyond L
-                        za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
-                        zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            LBX_STAMP(1);
-            // ---- 2. pass 1: DFT16 over n1 for both n2 -> A[n2][k1] in reg R16(k1)
-            dft16<NL>(za);
-            dft16<NL>(zb);
-        };
-        if (LBX_FEAT_PRUNE13 && a.L <= 416) load_window_pass1(std::integral_constant<int, 13>{});       // wave-uniform
-        else load_window_pass1(std::integral_constant<int, 16>{});
-        LBX_STAMP(2);
-        // ---- 3. twiddle by W256^(n2*k1)
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) {
-            const float4 w = *reinterpret_cast<const float4*>(&s_tw256[k1 * 16 + 2 * q]);
-            za[R16(k1)] = cmul(za[R16(k1)], make_float2(w.x, w.y));
-            zb[R16(k1)] = cmul(zb[R16(k1)], make_float2(w.z, w.w));
-        }
-
-        LBX_STAMP(3);
-        // ---- 4. exchange through LDS in two half passes; lane q ends with
-        //         ua = A[0..15][k1 = q], ub = A[0..15][k1 = (16 - q) % 16, or 8 for q = 0]
-        float2 ua[16], ub[16];
-        char* ex = wbuf + f * EXCH_FRAME;
-        wave_lds_sync();                                 // previous tile's readers are done
-#pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1)
-            *reinterpret_cast<float4*>(ex + k1 * EXCH_ROW + q * 16) =
-                make_float4(za[R16(k1)].x, za[R16(k1)].y, zb[R16(k1)].x, zb[R16(k1)].y);
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(ex + q * EXCH_ROW + j * 16);
-            ua[2 * j] = make_float2(v.x, v.y);
-            ua[2 * j + 1] = make_float2(v.z, v.w);
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int k1 = 8; k1 < 16; ++k1)
-            *reinterpret_cast<float4*>(ex + (k1 - 8) * EXCH_ROW + q * 16) =
-                make_float4(za[R16(k1)].x, za[R16(k1)].y, zb[R16(k1)].x, zb[R16(k1)].y);
-        wave_lds_sync();
-        const int row2 = (q == 0) ? 0 : 8 - q;           // k1 = 8 for q = 0, else 16 - q
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(ex + row2 * EXCH_ROW + j * 16);
-            ub[2 * j] = make_float2(v.x, v.y);
-            ub[2 * j + 1] = make_float2(v.z, v.w);
-        }
-        LBX_STAMP(4);
-        // ---- 5. pass 2: DFT16 over n2 -> Z'[k1 + 16*k2] in reg R16(k2)
-        dft16(ua);
-        dft16(ub);
-        wave_lds_sync();                                 // exchange reads done before P overwrites
-
-        LBX_STAMP(5);
-        // ---- 6. untangle conjugate pairs, |.|^2, into the per-frame power buffer.
-        //   q != 0 : slot s pairs ua[k2=s] (bin q+16s) with ub[k2=15-s] (bin 256-q-16s)
-        //   q == 0 : slots 0..8 pair ua[s] with ua[(16-s)%16] (bins 16s, 256-16s);
-        //            slots 9..16 pair ub[s-9] with ub[24-s]   (bins 8+16(s-9), 248-16(s-9))
-        // The per-lane bins / LDS addresses of this section depend only on q, so the compiler hoists them out of
-        // the tile loop as ~15 live registers -- and, at the 168-VGPR cap of 3 waves/SIMD, spills them to scratch and
-        // reloads them here every tile (15 dependent scratch loads in the busiest phase of the kernel).  An opaque
-        // copy of q keeps their (cheap) computation inside the loop instead.
-        int qv = q;
-#if LBX_FEAT_NO_HOIST
-        asm volatile("" : "+v"(qv));
-#endif
-        float* Pf = s_P + f * P_STRIDE;
-        // SEGMEL: transposed [bin][frame] with one skew row per 8 bins, so that the mel lanes (one per run of bins,
-        // runs <= seg_len apart) read their 32-byte rows from different banks
-        auto P_store = [&](int bin, float v) {
-            if (SEGMEL) s_P[(bin + (bin >> 3)) * 8 + f] = v;
-            else Pf[bin] = v;
-        };
-        const bool q0 = (qv == 0);
-#if LBX_FEAT_LANE0_V2
-        // Lane 0 holds the two self-paired columns (k1 = 0 in ua, k1 = 8 in ub).  Its pairs are laid over the general
-        // pattern (ua[s] with ub[15-s]) so that only ONE operand of a slot differs: slots 0-7 pair ub[s] with ub[15-s]
-        // (bins 8 + 16 s and 248 - 16 s), slots 8-15 pair ua[s] with ua[16-s] (bins 16 s and 256 - 16 s; s = 8 pairs bin 128
-        // with itself), slot 16 pairs ua[0] with itself (bins 0 and 256): 33 selects per tile instead of 65.
-        const int qlo = q0 ? 8 : qv;
-#pragma unroll
-        for (int s = 0; s < 17; ++s) {
-            float2 zk, zm;
-            int bin;
-            if (s < 8) {
-                const float2 g = ua[R16(s)], l0 = ub[R16(s)];
-                zk = make_float2(q0 ? l0.x : g.x, q0 ? l0.y : g.y);
-                zm = ub[R16(15 - s)];
-                bin = qlo + 16 * s;
-            } else if (s < 16) {
-                zk = ua[R16(s)];
-                const float2 g = ub[R16(15 - s)], l0 = ua[R16((16 - s) & 15)];
-                zm = make_float2(q0 ? l0.x : g.x, q0 ? l0.y : g.y);
-                bin = qv + 16 * s;
-            } else {
-                zk = ua[R16(0)];
-                zm = ua[R16(0)];
-                bin = 0;
-            }
-#else
-#pragma unroll
-        for (int s = 0; s < 17; ++s) {
-            float2 zk, zm;
-            int bin;
-            if (s <= 8) {
-                zk = ua[R16(s)];
-                const float2 alt = ua[R16((16 - s) & 15)];
-                const float2 gen = ub[R16(15 - s)];
-                zm = make_float2(q0 ? alt.x : gen.x, q0 ? alt.y : gen.y);
-                bin = qv + 16 * s;
-            } else if (s < 16) {
-                const float2 g1 = ua[R16(s)], a1 = ub[R16(s - 9)];
-                const float2 g2 = ub[R16(15 - s)], a2 = ub[R16(24 - s)];
-                zk = make_float2(q0 ? a1.x : g1.x, q0 ? a1.y : g1.y);
-                zm = make_float2(q0 ? a2.x : g2.x, q0 ? a2.y : g2.y);
-                bin = q0 ? 8 + 16 * (s - 9) : qv + 16 * s;
-            } else {
-                zk = ub[R16(7)];
-                zm = ub[R16(8)];
-                bin = 8 + 16 * 7;
-            }
-#endif
-            if (s < 16 || q0) {
-                const float2 w = s_tw512[bin];
-                float pk, pm;
-                untangle(zk, zm, w, pk, pm);
-                if (!POW2) {
-                    pk = __powf(pk, a.power_half);
-                    pm = __powf(pm, a.power_half);
+                for (int j = 0; j < 8; ++j) {
+                    const int n1 = 8 * half + j;
+                    const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);      // zero beyond L
+                    za[n1] = make_float2(x[j].x * w.x, x[j].y * w.y);
+                    zb[n1] = make_float2(x[j].z * w.z, x[j].w * w.w);
                 }
-                P_store(bin, pk);
-                P_store(256 - bin, pm);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#if LBX_FEAT_UNTANGLE_FENCE
-            if ((s % LBX_FEAT_UNTANGLE_FENCE) == LBX_FEAT_UNTANGLE_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
-        wave_lds_sync();
-
+        LBX_STAMP(1);
+        // ---- 2.-6. FFT, untangling, |.|^power into the wave's power buffer
+        fft512_power_tile<POW2, SEGMEL>(za, zb, wbuf, q, f, s_tw256, s_tw512, a.power_half, [&](int i) { LBX_STAMP(i); });
         LBX_STAMP(6);
+
+        float* Pf = s_P + f * P_STRIDE;
         const int nvalid = min(8, a.T - t0);             // frames of this tile inside the utterance
         if (KIND == LIDBOX_FEAT_SPECTROGRAM) {
             float* dst = a.out + (long)b * a.out_bs + (long)t0 * 257;
@@ -797,142 +973,34 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
 #pragma unroll
                 for (int k0 = 0; k0 < 320; k0 += 64) {
                     const int k = k0 + lane;
-                    if (k < 257) dst[ff * 257 + k] = s_P[ff * P_STRIDE + k];
+                    if (k < 257) {
+                        const float v = s_P[ff * P_STRIDE + k];
+                        dst[ff * 257 + k] = v;
+                        bad = fmaf(v, 0.f, bad);
+                    }
                 }
             }
         } else {
             if (SEGMEL) {
-                // ---- 7. banded mel, segmented: lane = one run of <= seg_len consecutive bins of one band, for all
-                //         8 frames of the tile (two 16-byte reads per bin); runs are zero-padded to seg_len so the
-                //         loop is uniform.  A band's partial sums sit in consecutive lanes and are combined in a
-                //         fixed order with wave shuffles; the band's first lane finishes (log) and stages.
-                const int sband = s_segmeta[lane], bin0 = s_segmeta[64 + lane], sinfo = s_segmeta[128 + lane];
-                float acc[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-                // A row of the transposed buffer is 32 bytes = two ds_read_b128, and the LDS serves a b128 wave access in groups
-                // of 16 lanes that cover the 64 banks once only when they hit 16 different 16-byte slots mod 256 bytes: with every
-                // lane on the FIRST half of its row a group can reach 8 of the 16 slots (2-way conflicts by construction: a third of
-                // this kernel's LDS cycles, profiles/r04_feature_census.txt).  Odd lanes therefore read the second half first -- each
-                // group contains 8 even and 8 odd lanes -- and carry frames 4-7 in acc[0..3], 0-3 in acc[4..7] until the swap below.
-#ifndef LBX_FEAT_MEL_HALFSWAP
-#define LBX_FEAT_MEL_HALFSWAP 0            // measured neutral (profiles/r05_feature_mel_halfswap_ab.txt): off
-#endif
-                const int half0 = (LBX_FEAT_MEL_HALFSWAP && (lane & 1)) ? 4 : 0, half1 = 4 - half0;
-                // chunks of 4 bins: the 12 LDS reads of a chunk are issued before its 32 FMAs (the FFT registers are
-                // dead here, so the operands cost nothing); one LDS round trip per chunk instead of one per bin
-                for (int j0 = 0; j0 < a.seg_len; j0 += 4) {
-                    float w[4];
-                    float4 p0[4], p1[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = j0 + u;
-                        w[u] = (j < a.seg_len) ? s_segw[min(j, a.seg_len - 1) * 64 + lane] : 0.f;
-                        const int bin = min(bin0 + j, 256);
-                        const float* row = s_P + (bin + (bin >> 3)) * 8;
-                        p0[u] = *reinterpret_cast<const float4*>(row + half0);
-                        p1[u] = *reinterpret_cast<const float4*>(row + half1);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc[0] = fmaf(p0[u].x, w[u], acc[0]); acc[1] = fmaf(p0[u].y, w[u], acc[1]);
-                        acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
-                        acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
-                        acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
-                    }
-                }
-                if (LBX_FEAT_MEL_HALFSWAP) {
-                    const bool sw = (lane & 1) != 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float lo = acc[i], hi = acc[4 + i];
-                        acc[i] = sw ? hi : lo;
-                        acc[4 + i] = sw ? lo : hi;
-                    }
-                }
-                const int sidx = sinfo & 255, sns = sinfo >> 8;
-                for (int st = 0; st < a.seg_steps; ++st) {
-                    const int d = 1 << st;
-                    const bool take = sidx + d < sns;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float t = __shfl_down(acc[i], d, 64);
-                        acc[i] += take ? t : 0.f;
-                    }
-                }
-                if (sband >= 0 && sidx == 0) {
-                    if (KIND == LIDBOX_FEAT_MFCC) {
-                        // the DCT below wants [band][8 frames] (two 16-byte rows per band)
-                        *reinterpret_cast<float4*>(s_stage + sband * 8) = make_float4(
-                            __logf(acc[0] + LOG_EPS), __logf(acc[1] + LOG_EPS), __logf(acc[2] + LOG_EPS), __logf(acc[3] + LOG_EPS));
-                        *reinterpret_cast<float4*>(s_stage + sband * 8 + 4) = make_float4(
-                            __logf(acc[4] + LOG_EPS), __logf(acc[5] + LOG_EPS), __logf(acc[6] + LOG_EPS), __logf(acc[7] + LOG_EPS));
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            s_stage[i * a.M + sband] = (KIND != LIDBOX_FEAT_MEL) ? __logf(acc[i] + LOG_EPS) : acc[i];
-                    }
-                }
+                segmel_tile<KIND>(lane, a.seg_len, a.seg_steps, a.M, s_segmeta, s_segw, s_P, s_stage);
             } else {
-            // ---- 7. banded mel: lane (f, q) owns bands q, q+8, ...
-            for (int m = q; m < a.M; m += 8) {
-                const int st = s_mstart[m], cn = s_mcnt[m];
-                const float* wv = s_mw + s_moff[m];
-                float acc = 0.f;
-                for (int j = 0; j < cn; ++j) acc = fmaf(Pf[st + j], wv[j], acc);
-                if (KIND != LIDBOX_FEAT_MEL) acc = __logf(acc + LOG_EPS);
-                s_stage[f * a.M + m] = acc;
-            }
+                // ---- 7. banded mel: lane (f, q) owns bands q, q+8, ...
+                for (int m = q; m < a.M; m += 8) {
+                    const int st = s_mstart[m], cn = s_mcnt[m];
+                    const float* wv = s_mw + s_moff[m];
+                    float acc = 0.f;
+                    for (int j = 0; j < cn; ++j) acc = fmaf(Pf[st + j], wv[j], acc);
+                    if (KIND != LIDBOX_FEAT_MEL) acc = __logf(acc + LOG_EPS);
+                    s_stage[f * a.M + m] = acc;
+                }
             }
             wave_lds_sync();
             LBX_STAMP(7);
             if (KIND == LIDBOX_FEAT_MFCC) {
                 float* s_coef = SEGMEL ? s_P : s_stage + 8 * a.M;
                 if (SEGMEL) {
-                    // DCT-II rows, same scheme as the mel runs: lane = (coefficient c, run of dct_len bands), all 8
-                    // frames at once from the transposed log-mel tile; a coefficient's dct_runs partial sums sit in
-                    // consecutive lanes and are combined in a fixed order.
-                    const int c = lane / a.dct_runs, run = lane - c * a.dct_runs;
-                    const bool on = c < a.ncoef;
-                    float acc[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-                    const int jend = dct_regs ? 8 : a.dct_len;
-#pragma unroll 2
-                    for (int j0 = 0; j0 < jend; j0 += 4) {
-                        if (dct_regs && j0 >= a.dct_len) break;
-                        float w[4];
-                        float4 p0[4], p1[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int n = run * a.dct_len + j0 + u;
-                            const bool in = on && j0 + u < a.dct_len && n < a.M;
-                            const int nn = in ? n : 0;
-                            if (dct_regs) w[u] = j0 == 0 ? wd[u] : wd[4 + u];      // zero where the run has no band
-                            else w[u] = in ? s_dct[nn * a.ncoef + c] : 0.f;
-                            p0[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8);
-                            p1[u] = *reinterpret_cast<const float4*>(s_stage + nn * 8 + 4);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc[0] = fmaf(p0[u].x, w[u], acc[0]); acc[1] = fmaf(p0[u].y, w[u], acc[1]);
-                            acc[2] = fmaf(p0[u].z, w[u], acc[2]); acc[3] = fmaf(p0[u].w, w[u], acc[3]);
-                            acc[4] = fmaf(p1[u].x, w[u], acc[4]); acc[5] = fmaf(p1[u].y, w[u], acc[5]);
-                            acc[6] = fmaf(p1[u].z, w[u], acc[6]); acc[7] = fmaf(p1[u].w, w[u], acc[7]);
-                        }
-                    }
-                    for (int d = 1; d < a.dct_runs; d <<= 1) {
-                        const bool take = run + d < a.dct_runs;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float t = __shfl_down(acc[i], d, 64);
-                            acc[i] += take ? t : 0.f;
-                        }
-                    }
-                    if (on && run == 0) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) s_coef[i * a.ncoef + c] = acc[i];
-                    }
+                    if (dct_regs) segdct_tile<true>(lane, a.dct_runs, a.dct_len, a.ncoef, a.M, wd, s_dct, s_stage, s_coef);
+                    else segdct_tile<false>(lane, a.dct_runs, a.dct_len, a.ncoef, a.M, wd, s_dct, s_stage, s_coef);
                 } else {
                     for (int c = q; c < a.ncoef; c += 8) {
                         float acc = 0.f;
@@ -943,38 +1011,241 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? LBX_FEAT_WAVES : 4) void fused_f
                 wave_lds_sync();
                 float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.ncoef;
                 const int total = nvalid * a.ncoef;
-                for (int i = lane; i < total; i += 64) dst[i] = s_coef[i];
+                for (int i = lane; i < total; i += 64) {
+                    const float v = s_coef[i];
+                    dst[i] = v;
+                    bad = fmaf(v, 0.f, bad);
+                }
             } else {
                 float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.M;
-                const int total = nvalid * a.M;
-                if ((total & 3) == 0 && (((uintptr_t)dst) & 15) == 0) {
-                    // 8 x M <= 512 floats (M <= 64 on this path): two float4 per lane cover the tile; both reads are
-                    // issued before the stores
-                    const int i0 = 4 * lane, i1 = 256 + 4 * lane;
-                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-                    if (i0 < total) v0 = *reinterpret_cast<const float4*>(s_stage + i0);
-                    if (i1 < total) v1 = *reinterpret_cast<const float4*>(s_stage + i1);
-                    if (i0 < total) *reinterpret_cast<float4*>(dst + i0) = v0;
-                    if (i1 < total) *reinterpret_cast<float4*>(dst + i1) = v1;
-                    if constexpr (SHADOW) {
-                        // the bf16 shadow the first Conv1D of the bf16-storage path reads (gemm_bf16.hip), written here instead of
-                        // by a conversion launch over the whole feature tensor
-                        typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-                        unsigned short* d16 = a.out16 + (dst - a.out);
-                        const bf4 h0 = {(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w}, h1 = {(__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
-                        if (i0 < total) *reinterpret_cast<bf4*>(d16 + i0) = h0;
-                        if (i1 < total) *reinterpret_cast<bf4*>(d16 + i1) = h1;
-                    }
-                } else {
-                    for (int i = lane; i < total; i += 64) {
-                        dst[i] = s_stage[i];
-                        if constexpr (SHADOW) a.out16[(dst - a.out) + i] = __builtin_bit_cast(unsigned short, (__bf16)s_stage[i]);
-                    }
-                }
+                bad = store_mel_tile<false>(lane, nvalid * a.M, dst, nullptr, s_stage, bad);
             }
         }
         LBX_STAMP(8);
     }
+    if (a.nonfinite && bad != bad) atomicOr(a.nonfinite, 1);
+    LBX_STAMP_K(14);
+    LBX_STAMP_K(15);
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming kernel (round 6): the fused tile as a software pipeline
+// ------------------------------------------------------------------------------------------------
+// Same tile arithmetic as fused_feat512_kernel (bit-identical results), different schedule.  Round 6's per-wave timeline of that
+// kernel at 256 utterances (tools/feat_timeline.py, profiles/r06_feature_timeline.txt): tables staged 1.6 us after entry, the first
+// tile's samples requested only then; first tile 9.7 us median / 16.4 us p90 (every wave of the machine waits for HBM, then all of
+// them hit the LDS exchange together), second tile 7.2 us; waves leave between 15.8 and 25.5 us because 25 tiles per CU on 14 waves
+// is 2 + 2 + ... + 1 with the two-tile waves piled on two of the four SIMDs.  Per tile the LDS pipe is busy ~830 cycles (the
+// exchange's 16 ds_write_b128 alone 208) and a SIMD ~3.7 k issue cycles: two co-critical resources that only overlap across waves.
+//   * ONE persistent workgroup per CU, as many waves as the LDS holds (16 = four per SIMD at <= 128 registers: the staging tile
+//     aliases the dead power buffer, 9 280 B per wave + one copy of the tables).
+//   * A wave's samples arrive by RAW BUFFER LOADS through a per-utterance descriptor whose num_records ends the utterance: reads
+//     behind it return 0 from the bounds check, so there is no guarded path, no address select and no exec branch (what sank round
+//     4's prefetch, tools/patches/feat_tile_prefetch.patch), and hipcc counts the loads itself.  The loads of the wave's FIRST tile
+//     are issued before the tables are staged; the loads of tile i + 1 are issued behind the untangling of tile i, into the FFT
+//     registers that died there, and land while mel / log / store run.
+//   * Tiles are handed out dynamically (one LDS counter per workgroup): a wave asks for its next tile at the top of the current one,
+//     so whichever SIMD is ahead takes the remainder.  A tile's result does not depend on the wave that computes it.
+//   * SRC16: the samples are 16-bit PCM read in place (8 bytes per lane and n1 instead of 16, converted in registers; the 1 / 32768 of
+//     tf.audio.decode_wav is folded into the window table: a power of two, so bit-identical to lidbox_pcm16_to_f32 -> this kernel).
+//   * The store stage folds "any value not finite" of what it writes into *nonfinite (tf.debugging.assert_all_finite of
+//     tf_utils.py:168-194 without a pass over the output).
+typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
+
+template <bool SRC16> struct StreamRegs { typedef u32x4_s type; };
+template <> struct StreamRegs<true> { typedef u32x2_s type; };
+
+__device__ __forceinline__ unsigned wave_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+template <int KIND, bool POW2, bool SHADOW, bool SRC16, int NL>
+__global__ __launch_bounds__(1024) void feat512_stream_kernel(const FusedArgs a) {
+    typedef typename StreamRegs<SRC16>::type xreg_t;
+    constexpr int ESZ = SRC16 ? 2 : 4;                                  // bytes per source sample
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NW = (int)(blockDim.x >> 6);
+    // ---- LDS carve: tables (+ DCT rows for MFCC), the tile counter, then one scratch block per wave
+    float* s_win = reinterpret_cast<float*>(smem);
+    float2* s_tw256 = reinterpret_cast<float2*>(smem + 2048);
+    float2* s_tw512 = reinterpret_cast<float2*>(smem + 4096);
+    int* s_segmeta = reinterpret_cast<int*>(smem + 6144);
+    float* s_segw = reinterpret_cast<float*>(s_segmeta + 192);
+    const int mel_floats = (KIND == LIDBOX_FEAT_SPECTROGRAM) ? 0 : mel_table_floats(true, a.M, a.nnz, a.seg_len);
+    float* s_dct = reinterpret_cast<float*>(smem + 6144) + mel_floats;
+    const int table_floats = 1536 + mel_floats + (KIND == LIDBOX_FEAT_MFCC ? a.M * a.ncoef : 0);
+    int* s_next = reinterpret_cast<int*>(smem + table_floats * 4);
+    const int table_bytes = (table_floats * 4 + 4 + 15) & ~15;
+
+    const int tid = threadIdx.x;
+    const int lane0 = tid & 63;
+    const int wave = (int)wave_uniform((unsigned)tid >> 6);
+    LBX_STAMP_K(11);
+    LBX_STAMP_K(12);
+
+    const unsigned chunk = xcd_chunk_id(blockIdx.x, a.nwg);
+    const unsigned tile0 = chunk * (unsigned)a.tiles_per_wg;
+    const unsigned ntl = min((unsigned)a.tiles_per_wg, (unsigned)a.ntiles - tile0);     // tiles of this workgroup
+    const unsigned tpu = (unsigned)a.tiles_per_utt;
+    const unsigned utt_bytes = ((unsigned)a.N & ~3u) * ESZ;             // a float4 / short4 at a multiple of 4 samples is wholly inside or wholly outside
+
+    // sample loads of local tile `local` (wave-uniform; past the workgroup's last tile: a descriptor of zero records, no traffic)
+    xreg_t x[NL];                                          // NL = 13: frames of <= 416 samples, the window table is zero behind them
+    auto issue = [&](unsigned local, const int ln) {
+        const unsigned lane_off = (unsigned)((ln >> 3) * a.S + 4 * (ln & 7)) * ESZ;
+        const bool on = local < ntl;
+        const unsigned tile = tile0 + (on ? local : 0u);
+        const unsigned b = tile / tpu;
+        const unsigned t0 = (tile - b * tpu) * 8u;
+        const char* base = reinterpret_cast<const char*>(a.signals) + (long)b * a.sig_stride * ESZ;
+        const unsigned lo = wave_uniform((unsigned)(uintptr_t)base), hi = wave_uniform((unsigned)((uintptr_t)base >> 32));
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), 0, on ? (int)utt_bytes : 0, 0x00020000);
+        const int voff = (int)(t0 * (unsigned)a.S * ESZ + lane_off);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+#ifdef LBX_ABL_NOLOAD
+            x[j] = (xreg_t)(unsigned)(voff + j);
+#else
+            if constexpr (SRC16) x[j] = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 64 * j, 0, 0);
+            else x[j] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 128 * j, 0, 0);
+#endif
+        }
+    };
+    // Table loads first (one value per thread and table where the workgroup is wide enough), THEN the first tile's samples: loads
+    // return in order, so the tables (L2 hits) are staged and the barrier is passed while the samples are still on their way from HBM.
+    const int nthr = (int)blockDim.x;
+    const float t_win = tid < 512 ? a.win512[tid] : 0.f;
+    const float2 t_256 = tid < 256 ? a.tw256[tid] : make_float2(0.f, 0.f), t_512 = tid < 256 ? a.tw512[tid] : make_float2(0.f, 0.f);
+    int t_meta = 0;
+    float t_segw = 0.f, t_dct = 0.f;
+    if (KIND != LIDBOX_FEAT_SPECTROGRAM) {
+        if (tid < 192) t_meta = a.seg_meta[tid];
+        if (tid < a.seg_len * 64) t_segw = a.seg_w[tid];
+        if (KIND == LIDBOX_FEAT_MFCC && tid < a.M * a.ncoef) t_dct = a.dct[tid];
+    }
+    unsigned cur = (unsigned)wave;
+    issue(cur, lane0);
+    if (tid < 512) s_win[tid] = t_win;
+    if (tid < 256) {
+        s_tw256[tid] = t_256;
+        s_tw512[tid] = t_512;
+    }
+    if (KIND != LIDBOX_FEAT_SPECTROGRAM) {
+        if (tid < 192) s_segmeta[tid] = t_meta;
+        if (tid < a.seg_len * 64) s_segw[tid] = t_segw;
+        if (KIND == LIDBOX_FEAT_MFCC && tid < a.M * a.ncoef) s_dct[tid] = t_dct;
+    }
+    // what a narrow workgroup (or a long table) leaves over
+    for (int i = tid + nthr; i < 512; i += nthr) s_win[i] = a.win512[i];
+    for (int i = tid + nthr; i < 256; i += nthr) {
+        s_tw256[i] = a.tw256[i];
+        s_tw512[i] = a.tw512[i];
+    }
+    if (KIND != LIDBOX_FEAT_SPECTROGRAM) {
+        for (int i = tid + nthr; i < 192; i += nthr) s_segmeta[i] = a.seg_meta[i];
+        for (int i = tid + nthr; i < a.seg_len * 64; i += nthr) s_segw[i] = a.seg_w[i];
+        if (KIND == LIDBOX_FEAT_MFCC)
+            for (int i = tid + nthr; i < a.M * a.ncoef; i += nthr) s_dct[i] = a.dct[i];
+    }
+    if (tid == 0) *s_next = NW;
+    __syncthreads();
+    LBX_STAMP_K(13);
+
+    char* wbuf = smem + table_bytes + wave * WAVE_SCRATCH;
+    float* s_P = reinterpret_cast<float*>(wbuf);          // SPECTROGRAM: [8][P_STRIDE]; else transposed [PT_ROWS][8]; aliases the exchange
+    float* s_stage = reinterpret_cast<float*>(wbuf);      // the staged [8][M] (MFCC: [M][8]) tile aliases the power buffer once the mel runs have read it
+    float* s_coef = reinterpret_cast<float*>(wbuf + 4096);
+    unsigned long long badmask = 0;                       // lanes that stored a value that was not finite (scalar registers)
+
+    for (int it = 0; cur < ntl; ++it) {
+        float bad = 0.f;                                  // 0, or NaN once a value this tile stored was not finite
+        // Per-lane addresses (window / twiddle / exchange rows, mel run, staging slots) depend only on the lane, so hipcc hoists them out
+        // of this loop as ~25 live registers -- and, with the next tile's 64 sample registers in flight across mel / store at the
+        // 128-register cap, spills them: a scratch reload behind the prefetch is a vmcnt(0) that waits for every sample load.  An opaque
+        // copy of the lane index per tile keeps their (cheap) computation inside the loop.
+        // (The lane index itself comes from mbcnt each tile, and the not-finite state lives in scalar registers.)
+        unsigned ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        const int q = lane & 7, f = lane >> 3;
+        // the next tile of this wave (asked for now: its loads go out in the middle of this one)
+        unsigned nxt = 0;
+        if (lane == 0) nxt = (unsigned)__hip_atomic_fetch_add(s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nxt = wave_uniform(nxt);
+        asm volatile("" : "+s"(nxt));
+        const unsigned tile = tile0 + cur;
+        const unsigned b = tile / tpu;
+        const int t0 = (int)((tile - b * tpu) * 8u);
+
+        // ---- 1. window.  lane q holds n2 = 2q (za) and 2q+1 (zb), n1 = 0..15: packed sample n = 16 n1 + n2 <-> reals 32 n1 + 4q .. + 3
+        LBX_STAMP(0);
+        float2 za[16], zb[16];
+#pragma unroll
+        for (int n1 = 0; n1 < NL; ++n1) {
+            const float4 w = *reinterpret_cast<const float4*>(s_win + 32 * n1 + 4 * q);      // zero beyond the frame
+            float4 v;
+            if constexpr (SRC16) {
+                const int p0 = (int)x[n1].x, p1 = (int)x[n1].y;
+                v = make_float4((float)(short)(p0 & 0xffff), (float)(p0 >> 16), (float)(short)(p1 & 0xffff), (float)(p1 >> 16));
+            } else {
+                v = __builtin_bit_cast(float4, x[n1]);
+            }
+            za[n1] = make_float2(v.x * w.x, v.y * w.y);
+            zb[n1] = make_float2(v.z * w.z, v.w * w.w);
+        }
+        LBX_STAMP(1);
+        // ---- 2.-6. FFT, untangling, |.|^power into the wave's power buffer
+        fft512_power_tile<POW2, KIND != LIDBOX_FEAT_SPECTROGRAM, NL>(za, zb, wbuf, q, f, s_tw256, s_tw512, a.power_half,
+                                                                 [&](int i) { LBX_STAMP(i); });
+        // ---- 1'. the next tile's samples, into registers that are dead from here to the top of the loop
+        issue(nxt, lane);
+        LBX_STAMP(6);
+
+        const int nvalid = min(8, a.T - t0);
+        if (KIND == LIDBOX_FEAT_SPECTROGRAM) {
+            float* dst = a.out + (long)b * a.out_bs + (long)t0 * 257;
+            for (int ff = 0; ff < nvalid; ++ff) {
+#pragma unroll
+                for (int k0 = 0; k0 < 320; k0 += 64) {
+                    const int k = k0 + lane;
+                    if (k < 257) {
+                        const float v = s_P[ff * P_STRIDE + k];
+                        dst[ff * 257 + k] = v;
+                        bad = fmaf(v, 0.f, bad);
+                    }
+                }
+            }
+        } else {
+#ifndef LBX_ABL_NOMEL
+            segmel_tile<KIND>(lane, a.seg_len, a.seg_steps, a.M, s_segmeta, s_segw, s_P, s_stage);
+#endif
+            wave_lds_sync();
+            LBX_STAMP(7);
+            if (KIND == LIDBOX_FEAT_MFCC) {
+                float wd[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wd[u] = 0.f;
+                segdct_tile<false, 2>(lane, a.dct_runs, a.dct_len, a.ncoef, a.M, wd, s_dct, s_stage, s_coef);      // two bands per batch: the next tile's samples are in flight
+                wave_lds_sync();
+                float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.ncoef;
+                const int total = nvalid * a.ncoef;
+                for (int i = lane; i < total; i += 64) {
+                    const float v = s_coef[i];
+                    dst[i] = v;
+                    bad = fmaf(v, 0.f, bad);
+                }
+            } else {
+                float* dst = a.out + (long)b * a.out_bs + (long)t0 * a.M;
+                bad = store_mel_tile<SHADOW>(lane, nvalid * a.M, dst, SHADOW ? a.out16 + (dst - a.out) : nullptr, s_stage, bad);
+            }
+        }
+        badmask |= __builtin_amdgcn_ballot_w64(bad != bad);
+        LBX_STAMP(8);
+        cur = nxt;
+    }
+    if (a.nonfinite && badmask != 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicOr(a.nonfinite, 1);
+    LBX_STAMP_K(14);
+    LBX_STAMP_K(15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1153,36 +1424,18 @@ __global__ void shadow_rows_kernel(const float* __restrict__ in, unsigned short*
     if (i < per) out16[blockIdx.y * bs + i] = __builtin_bit_cast(unsigned short, (__bf16)in[blockIdx.y * bs + i]);
 }
 
-constexpr int FEAT_WIDE_NW = 14;          // waves of the wide log-mel workgroup (see fused_feat512_kernel)
+// any value of out[b * bs + i], i < per, not finite -> *flag |= 1 (the kernels without a flag in their store stage)
+__global__ void nonfinite_rows_kernel(const float* __restrict__ x, long bs, long per, int* __restrict__ flag) {
+    float bad = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) bad = fmaf(x[blockIdx.y * bs + i], 0.f, bad);
+    if (bad != bad) atomicOr(flag, 1);
+}
 
 template <int KIND>
-int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool segmel, size_t lds, hipStream_t st, int wide_nw = 4) {
+int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool segmel, size_t lds, hipStream_t st) {
     const bool pow2 = (p->power == 2.0f);
 #define LBX_FUSED(V, P2, SG)                                                                          \
     hipLaunchKernelGGL((fused_feat512_kernel<KIND, V, P2, SG>), dim3(a.nwg), dim3(256), lds, st, a)
-    if (KIND == LIDBOX_FEAT_LOGMEL && segmel && vec4 && pow2 && (wide_nw == FEAT_WIDE_NW || a.out16)) {
-        // the log-mel instantiations with their own launch shape: the wide workgroup and / or the bf16 shadow store
-#define LBX_LOGMEL(NWV, SH)                                                                                                          \
-    do {                                                                                                                             \
-        /* the wide workgroup's LDS depends on the plan (tables + NWV wave slices): raise the limit to the CU's 160 KiB once per  */ \
-        /* DEVICE, so that a later plan with more mel bins / another sample rate, or a second GPU in the process, still launches   */ \
-        static std::atomic<unsigned long long> attr_devs{0};                                                                         \
-        int dev_ = 0;                                                                                                                \
-        LBX_HIP(hipGetDevice(&dev_));                                                                                                \
-        if (NWV != 4 && (dev_ >= 64 || !(attr_devs.load() >> dev_ & 1ull))) {                                                        \
-            LBX_HIP(hipFuncSetAttribute((const void*)fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, NWV, SH>,            \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                                    \
-            if (dev_ < 64) attr_devs.fetch_or(1ull << dev_);                                                                         \
-        }                                                                                                                            \
-        hipLaunchKernelGGL((fused_feat512_kernel<LIDBOX_FEAT_LOGMEL, true, true, true, NWV, SH>), dim3(a.nwg), dim3(64 * NWV), lds,  \
-                           st, a);                                                                                                   \
-    } while (0)
-        if (wide_nw == FEAT_WIDE_NW) { if (a.out16) LBX_LOGMEL(FEAT_WIDE_NW, true); else LBX_LOGMEL(FEAT_WIDE_NW, false); }
-        else LBX_LOGMEL(4, true);
-#undef LBX_LOGMEL
-        LBX_LAUNCH_OK();
-        return LIDBOX_OK;
-    }
     if (segmel && KIND != LIDBOX_FEAT_SPECTROGRAM) {
         if (vec4 && pow2) LBX_FUSED(true, true, (KIND != LIDBOX_FEAT_SPECTROGRAM));
         else if (vec4) LBX_FUSED(true, false, (KIND != LIDBOX_FEAT_SPECTROGRAM));
@@ -1197,6 +1450,42 @@ int launch_fused(const lidbox_feat_plan* p, const FusedArgs& a, bool vec4, bool 
 #undef LBX_FUSED
     LBX_LAUNCH_OK();
     return LIDBOX_OK;
+}
+
+// the streaming kernel: its LDS depends on the plan (tables + nw wave slices, up to the CU's 160 KiB), so the limit is raised once per
+// (instantiation, DEVICE): a later plan with more mel bins / another sample rate, or a second GPU in the process, still launches
+template <int KIND, bool POW2, bool SHADOW, bool SRC16, int NL>
+int launch_stream_nl(const FusedArgs& a, int nw, size_t lds, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_devs{0};
+    int dev = 0;
+    LBX_HIP(hipGetDevice(&dev));
+    if (dev >= 64 || !(attr_devs.load() >> dev & 1ull)) {
+        LBX_HIP(hipFuncSetAttribute((const void*)feat512_stream_kernel<KIND, POW2, SHADOW, SRC16, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev < 64) attr_devs.fetch_or(1ull << dev);
+    }
+    hipLaunchKernelGGL((feat512_stream_kernel<KIND, POW2, SHADOW, SRC16, NL>), dim3(a.nwg), dim3(64 * nw), lds, st, a);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
+
+// frames of <= 416 samples (25 ms at 16 kHz: 400): the window table is zero from sample 416 on, the three sample loads per lane behind
+// it, their window products and the zero inputs of pass 1's first radix-4 stage are compiled out (NL = 13)
+template <int KIND, bool POW2, bool SHADOW, bool SRC16>
+int launch_stream_one(const FusedArgs& a, int nw, size_t lds, hipStream_t st) {
+    static const bool no_prune = getenv("LIDBOX_FEAT_NO_PRUNE") != nullptr;      // A/B aid
+    if (a.L <= 416 && !no_prune) return launch_stream_nl<KIND, POW2, SHADOW, SRC16, 13>(a, nw, lds, st);
+    return launch_stream_nl<KIND, POW2, SHADOW, SRC16, 16>(a, nw, lds, st);
+}
+
+// Instantiations: power == 2 (every lidbox config) gets all of {shadow store (log-mel only), 16-bit PCM source, pruned loads};
+// another power only the plain float kernel (the caller converts PCM / shadows with a pass of its own).
+template <int KIND>
+int launch_stream(const lidbox_feat_plan* p, const FusedArgs& a, bool src16, int nw, size_t lds, hipStream_t st) {
+    if (p->power != 2.0f) return launch_stream_nl<KIND, false, false, false, 16>(a, nw, lds, st);
+    if (KIND == LIDBOX_FEAT_LOGMEL && a.out16)
+        return src16 ? launch_stream_one<KIND, true, KIND == LIDBOX_FEAT_LOGMEL, true>(a, nw, lds, st)
+                     : launch_stream_one<KIND, true, KIND == LIDBOX_FEAT_LOGMEL, false>(a, nw, lds, st);
+    return src16 ? launch_stream_one<KIND, true, false, true>(a, nw, lds, st) : launch_stream_one<KIND, true, false, false>(a, nw, lds, st);
 }
 
 }  // namespace
@@ -1221,19 +1510,35 @@ extern "C" int lidbox_extract_features_fwd(const lidbox_feat_plan* p, int kind, 
                                            int B, int N, long sig_stride, float* out,
                                            long out_batch_stride, void* workspace,
                                            size_t workspace_bytes, lidbox_stream_t stream) {
-    return lidbox_extract_features_fwd_shadow(p, kind, signals, B, N, sig_stride, out, out_batch_stride, nullptr, workspace, workspace_bytes, stream);
+    return lidbox_extract_features_fwd_ex(p, kind, signals, LIDBOX_SRC_F32, B, N, sig_stride, out, out_batch_stride, nullptr, nullptr, workspace,
+                                          workspace_bytes, stream);
 }
 
 // + out16: a bfloat16 copy of the features (round-to-nearest-even) at the same element offsets as out (same batch stride, in
-// elements) -- the shadow the bf16-storage Conv1D path reads, written by the feature kernel itself.  Fused path, kinds
-// log-mel / mel only (LIDBOX_E_INVALID otherwise).
+// elements) -- the shadow the bf16-storage Conv1D path reads, written by the feature kernel itself.
 extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int kind, const float* signals,
                                                   int B, int N, long sig_stride, float* out, long out_batch_stride, void* out16,
                                                   void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
-    LBX_ARG(p && signals && out, "plan, signals, out != NULL");
+    return lidbox_extract_features_fwd_ex(p, kind, signals, LIDBOX_SRC_F32, B, N, sig_stride, out, out_batch_stride, out16, nullptr, workspace,
+                                          workspace_bytes, stream);
+}
+
+// 16-bit mono PCM read in place: bit-identical to lidbox_pcm16_to_f32(channels = 1) followed by lidbox_extract_features_fwd
+extern "C" int lidbox_extract_features_fwd_pcm16(const lidbox_feat_plan* p, int kind, const int16_t* pcm, int B, int N, long sig_stride,
+                                                 float* out, long out_batch_stride, int* nonfinite, lidbox_stream_t stream) {
+    return lidbox_extract_features_fwd_ex(p, kind, pcm, LIDBOX_SRC_PCM16, B, N, sig_stride, out, out_batch_stride, nullptr, nonfinite, nullptr, 0, stream);
+}
+
+extern "C" int lidbox_extract_features_fwd_ex(const lidbox_feat_plan* p, int kind, const void* signals_v, int src_format,
+                                              int B, int N, long sig_stride, float* out, long out_batch_stride, void* out16,
+                                              int* nonfinite, void* workspace, size_t workspace_bytes, lidbox_stream_t stream) {
+    LBX_ARG(p && signals_v && out, "plan, signals, out != NULL");
     LBX_ARG(kind >= LIDBOX_FEAT_SPECTROGRAM && kind <= LIDBOX_FEAT_MFCC, "kind");
+    LBX_ARG(src_format == LIDBOX_SRC_F32 || src_format == LIDBOX_SRC_PCM16, "src_format");
     LBX_ARG(kind != LIDBOX_FEAT_MFCC || p->ncoef > 0, "the plan's MFCC slice [coef_begin, coef_end) is empty");
     LBX_ARG(B >= 0 && N >= 0 && sig_stride >= N, "B >= 0, N >= 0, sig_stride >= N");
+    const bool src16 = src_format == LIDBOX_SRC_PCM16;
+    const float* signals = reinterpret_cast<const float*>(signals_v);
     hipStream_t st = (hipStream_t)stream;
     const int T = lidbox_num_frames(N, p->L, p->S);
     if (B == 0 || T == 0) return LIDBOX_OK;
@@ -1241,10 +1546,16 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
     if (out_batch_stride == 0) out_batch_stride = (long)T * chan;
     LBX_ARG(out_batch_stride >= (long)T * chan, "out_batch_stride >= T * channels");
     LBX_ARG(!out16 || (((uintptr_t)out16) & 7) == 0, "out16 must be 8-byte aligned");
-    // bf16 shadow of kinds / shapes whose kernel has no shadow store: one conversion pass over what was just written
+    // bf16 shadow / finite flag of kinds and shapes whose kernel does not produce them itself: one pass over what was just written
     auto shadow_after = [&]() -> int {
         const long per = (long)T * chan;
         shadow_rows_kernel<<<dim3((unsigned)lbx_cdiv(per, 256L), (unsigned)B), 256, 0, st>>>(out, (unsigned short*)out16, out_batch_stride, per);
+        LBX_LAUNCH_OK();
+        return LIDBOX_OK;
+    };
+    auto flag_after = [&]() -> int {
+        const long per = (long)T * chan;
+        nonfinite_rows_kernel<<<dim3((unsigned)std::min(lbx_cdiv(per, 256L), 64L), (unsigned)B), 256, 0, st>>>(out, out_batch_stride, per, nonfinite);
         LBX_LAUNCH_OK();
         return LIDBOX_OK;
     };
@@ -1261,15 +1572,56 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
         a.dct_runs = (p->M + a.dct_len - 1) / a.dct_len;          // drop runs that would be empty
         static const bool no_segmel = getenv("LIDBOX_FEAT_NO_SEGMEL") != nullptr;      // A/B aid
         const bool segmel = LBX_FEAT_SEGMEL && p->seg_ok && !no_segmel && kind != LIDBOX_FEAT_SPECTROGRAM;
-        a.win512 = p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
+        a.win512 = src16 ? p->d_win512_pcm : p->d_win512; a.tw256 = p->d_tw256; a.tw512 = p->d_tw512;
         a.mel_start = p->d_mel_start; a.mel_cnt = p->d_mel_cnt; a.mel_off = p->d_mel_off;
         a.mel_w = p->d_mel_w; a.dct = p->d_dct; a.out = out; a.out_bs = out_batch_stride;
         a.out16 = nullptr;
-#ifdef LBX_FEAT_TIMING
-        a.stamps = (workspace && workspace_bytes >= (size_t)768 * 4 * 12 * 8) ? (long long*)workspace : nullptr;
+        a.nonfinite = nonfinite;
+#if defined(LBX_FEAT_TIMING) || defined(LBX_FEAT_TIMELINE)
+        a.stamps = (workspace && workspace_bytes >= (size_t)4096 * 4 * 16 * 8) ? (long long*)workspace : nullptr;
 #endif
         a.tiles_per_utt = (T + 7) / 8;
         a.ntiles = (long)B * a.tiles_per_utt;
+        // float4 (short4) loads need 16-byte (8-byte) aligned frames
+        const bool vec4 = (((uintptr_t)signals & (src16 ? 7 : 15)) == 0) && (sig_stride % 4 == 0) && (p->S % 4 == 0) && (p->L % 4 == 0);
+
+        // ---- streaming kernel: one persistent workgroup per CU, all the waves the LDS holds, every CU the same number of consecutive
+        //      tiles (+- 1) handed out dynamically.  LIDBOX_FEAT_STREAM=0 keeps the round-1 shape (A/B aid).
+        {
+            static const int stream_env = getenv("LIDBOX_FEAT_STREAM") ? atoi(getenv("LIDBOX_FEAT_STREAM")) : 1;
+            const int table_floats = 1536 + (kind == LIDBOX_FEAT_SPECTROGRAM ? 0 : mel_table_floats(true, p->M, p->nnz, p->seg_len)) +
+                                     (kind == LIDBOX_FEAT_MFCC ? p->M * p->ncoef : 0);
+            const int table_bytes = (table_floats * 4 + 4 + 15) & ~15;
+            int nw = (160 * 1024 - table_bytes) / WAVE_SCRATCH;
+            if (nw > 16) nw = 16;
+            if (const char* e = getenv("LIDBOX_FEAT_STREAM_NW")) { const int v = atoi(e); if (v >= 1 && v < nw) nw = v; }      // tuning aid
+            const bool fits32 = (long)N * 4 < (1L << 31) && a.ntiles < (1L << 31) && (long)(T + 8) * p->S * 4 < (1L << 31);
+            if (stream_env != 0 && vec4 && fits32 && nw >= 8 && (segmel || kind == LIDBOX_FEAT_SPECTROGRAM) && (!src16 || p->power == 2.0f)) {
+                int ncu = 256;
+                (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device);
+                if (ncu < 1) ncu = 256;
+                a.tiles_per_wg = (int)lbx_cdiv(a.ntiles, (long)ncu);
+                a.nwg = (unsigned)lbx_cdiv(a.ntiles, (long)a.tiles_per_wg);
+                if (a.tiles_per_wg < nw) nw = a.tiles_per_wg;      // tiny batches: no idle waves behind the table staging
+                a.iters = 0;
+                const bool shadow_in_kernel = out16 && kind == LIDBOX_FEAT_LOGMEL && p->power == 2.0f;
+                if (shadow_in_kernel) a.out16 = (unsigned short*)out16;
+                const size_t lds = (size_t)table_bytes + (size_t)nw * WAVE_SCRATCH;
+                int rc;
+                switch (kind) {
+                    case LIDBOX_FEAT_SPECTROGRAM: rc = launch_stream<LIDBOX_FEAT_SPECTROGRAM>(p, a, src16, nw, lds, st); break;
+                    case LIDBOX_FEAT_MEL: rc = launch_stream<LIDBOX_FEAT_MEL>(p, a, src16, nw, lds, st); break;
+                    case LIDBOX_FEAT_LOGMEL: rc = launch_stream<LIDBOX_FEAT_LOGMEL>(p, a, src16, nw, lds, st); break;
+                    default: rc = launch_stream<LIDBOX_FEAT_MFCC>(p, a, src16, nw, lds, st); break;
+                }
+                if (rc != LIDBOX_OK || !out16 || shadow_in_kernel) return rc;
+                return shadow_after();
+            }
+        }
+        LBX_ARG(!src16, "16-bit PCM sources need the streaming kernel: 8-byte aligned signals, sig_stride / frame_length / frame_step multiples of 4 "
+                        "(convert with lidbox_pcm16_to_f32 otherwise)");
+
+        // ---- round-1 shape (unaligned signals, plans outside the streaming kernel's table limits)
         // LDS: tables + 4 wave scratch blocks (must mirror the carve in the kernel)
         const bool dct_regs = kind == LIDBOX_FEAT_MFCC && segmel && a.dct_len <= 8;      // mirrors the kernel
         const int table_floats = 1536 + mel_table_floats(segmel, p->M, p->nnz, p->seg_len) +
@@ -1278,10 +1630,7 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
         const int stage_floats = (kind == LIDBOX_FEAT_SPECTROGRAM) ? 0
                                  : 8 * p->M + ((kind == LIDBOX_FEAT_MFCC && !segmel) ? 8 * p->ncoef : 0);
         const int wave_bytes = WAVE_SCRATCH + ((stage_floats * 4 + 15) & ~15);
-        size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
-        // float4 loads need 16-byte aligned frames
-        const bool vec4 = (((uintptr_t)signals & 15) == 0) && (sig_stride % 4 == 0) &&
-                          (p->S % 4 == 0) && (p->L % 4 == 0);
+        const size_t lds = (size_t)table_bytes + 4 * (size_t)wave_bytes;
         // grid: about four dispatch rounds of resident workgroups, equal tile counts per wave.  One tile per wave
         // while that holds (B <= ~490 at 2 s): the dispatcher then balances the tail; measured 35 vs 39 us at B = 256
         // against three tiles per wave on two thirds of the slots, and no difference at B = 2048.
@@ -1291,36 +1640,17 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
         if (const char* e = getenv("LIDBOX_FEAT_ITERS")) { const int v = atoi(e); if (v >= 1) a.iters = v; }   // tuning aid
         a.nwg = (unsigned)lbx_cdiv(a.ntiles, 4L * a.iters);
         a.tiles_per_wg = 4 * a.iters;
-        // wide workgroups (log-mel, the train step's kind): one persistent 14-wave workgroup per CU, every CU the same number
-        // of consecutive tiles (+- 1), its waves take them round-robin.  Measured against the 4-wave shape (round 4,
-        // profiles/r04_feature_wide_ab.txt).  LIDBOX_FEAT_WIDE=0 keeps the 4-wave shape (A/B aid).
-        int wide_nw = 4;
-        {
-            static const int wide_env = getenv("LIDBOX_FEAT_WIDE") ? atoi(getenv("LIDBOX_FEAT_WIDE")) : 1;
-            const size_t lds_wide = (size_t)table_bytes + FEAT_WIDE_NW * (size_t)wave_bytes;
-            // interleaved on one box (B x 2 s): 256 +10 %, 512 +12 %, 1024 equal, 2048 -3 % -> up to 100 tiles per CU
-            if (wide_env != 0 && kind == LIDBOX_FEAT_LOGMEL && segmel && vec4 && p->power == 2.0f && lds_wide <= 160 * 1024 &&
-                a.ntiles >= 4L * 256 && (a.ntiles <= 100L * 256 || wide_env > 1)) {
-                wide_nw = FEAT_WIDE_NW;
-                lds = lds_wide;
-                a.tiles_per_wg = (int)lbx_cdiv(a.ntiles, 256L);
-                a.nwg = (unsigned)lbx_cdiv(a.ntiles, (long)a.tiles_per_wg);
-                a.iters = (int)lbx_cdiv((long)a.tiles_per_wg, (long)FEAT_WIDE_NW);
-            }
-        }
-        // the log-mel instantiation the train step uses stores the shadow itself (SHADOW = true)
-        const bool shadow_in_kernel = out16 && kind == LIDBOX_FEAT_LOGMEL && segmel && vec4 && p->power == 2.0f && out_batch_stride % 4 == 0;
-        if (shadow_in_kernel) a.out16 = (unsigned short*)out16;
         int rc;
         switch (kind) {
             case LIDBOX_FEAT_SPECTROGRAM: rc = launch_fused<LIDBOX_FEAT_SPECTROGRAM>(p, a, vec4, false, lds, st); break;
             case LIDBOX_FEAT_MEL: rc = launch_fused<LIDBOX_FEAT_MEL>(p, a, vec4, segmel, lds, st); break;
-            case LIDBOX_FEAT_LOGMEL: rc = launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st, wide_nw); break;
+            case LIDBOX_FEAT_LOGMEL: rc = launch_fused<LIDBOX_FEAT_LOGMEL>(p, a, vec4, segmel, lds, st); break;
             default: rc = launch_fused<LIDBOX_FEAT_MFCC>(p, a, vec4, segmel, lds, st); break;
         }
-        if (rc != LIDBOX_OK || !out16 || shadow_in_kernel) return rc;
+        if (rc != LIDBOX_OK || !out16) return rc;
         return shadow_after();
     }
+    LBX_ARG(!src16, "16-bit PCM sources need the fused path (fft_length 512); convert with lidbox_pcm16_to_f32 otherwise");
 
     // ---- generic path (dense output only)
     LBX_ARG(out_batch_stride == (long)T * chan, "the non-fused path needs a dense output (out_batch_stride = T*channels)");
@@ -1351,7 +1681,11 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
                            p->power, spec);
     }
     LBX_LAUNCH_OK();
-    if (kind == LIDBOX_FEAT_SPECTROGRAM) return out16 ? shadow_after() : LIDBOX_OK;
+    auto finish = [&]() -> int {
+        if (nonfinite) { const int rc = flag_after(); if (rc != LIDBOX_OK) return rc; }
+        return out16 ? shadow_after() : LIDBOX_OK;
+    };
+    if (kind == LIDBOX_FEAT_SPECTROGRAM) return finish();
     float* mel = (kind == LIDBOX_FEAT_MFCC) ? (float*)workspace + nframes * p->F : out;
     hipLaunchKernelGGL(generic_mel_kernel, dim3((unsigned)lbx_cdiv(nframes * p->M, 256)), dim3(256), 0, st,
                        spec, nframes, p->F, p->M, p->d_mel_start, p->d_mel_cnt, p->d_mel_off,
@@ -1362,5 +1696,5 @@ extern "C" int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* p, int
                            st, mel, nframes, p->M, p->ncoef, p->d_dct, out);
         LBX_LAUNCH_OK();
     }
-    return out16 ? shadow_after() : LIDBOX_OK;
+    return finish();
 }

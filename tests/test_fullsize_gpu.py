@@ -184,7 +184,10 @@ def test_config4_mfcc_cmvn_cnn_full_size_runs_and_learns():
     assert np.isfinite(l1) and l1 < 0.95 * l0
     assert tr.step_count == 41
     moved = (m.flat - w0).abs()
-    assert 1e-3 < float(moved.max()) <= 41 * 1e-3 * 1.01
+    # Adam's step is lr * m_hat / sqrt(v_hat): exactly lr at t = 1, and by Cauchy-Schwarz at most
+    # lr * (1 - b1) / sqrt(1 - b2) * sqrt(sum_k (b1^2 / b2)^k) * sqrt(1 - b2^t) / (1 - b1^t) <= 1.5 lr for t <= 41 (b1 0.9, b2 0.999);
+    # a weight whose gradient shrinks from step to step moves by slightly more than lr per step (measured: 0.0439 over 41 steps)
+    assert 1e-3 < float(moved.max()) <= 41 * 1e-3 * 1.5
 
 
 def test_config5_bf16_step_time_smoke():
@@ -234,7 +237,7 @@ def _oracle_features64(config, sig):
     return fo.extract_features(sig, sr, "logmelspectrogram")
 
 
-def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None):
+def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None, dense_masks=None):
     """loss and gradients of the model step in float64 (torch autograd on the host) on input features x.
     relu_masks: per Conv1D layer, the ReLU decisions (output > 0) the GPU step took.  A pre-activation within fp32 rounding of
     zero may fall on either side of the kink; the gradient of the piecewise-linear network is discontinuous there, so the
@@ -262,10 +265,24 @@ def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None):
             if bool(differ.any()):
                 flip_z = max(flip_z, float(z.detach()[differ].abs().max()))
             h = z * mk.to(torch.float64)
+
+    def dense_relu(h, name, j):
+        # the Dense layers behind the pooling have the same kink: same treatment (the step's own decisions, disagreements counted)
+        nonlocal flips, flip_z
+        z = h @ p[name + ".W"] + p[name + ".b"]
+        if dense_masks is None:
+            return F.relu(z)
+        mk = torch.from_numpy(dense_masks[j])
+        differ = mk != (z.detach() > 0)
+        flips += int(differ.sum())
+        if bool(differ.any()):
+            flip_z = max(flip_z, float(z.detach()[differ].abs().max()))
+        return z * mk.to(torch.float64)
+
     if config == 3:        # cnn.py:37-45 + keras_utils.py:141-147
         h = h.mean(dim=1)
-        h = F.relu(h @ p["fc_1.W"] + p["fc_1.b"])
-        h = F.relu(h @ p["fc_2.W"] + p["fc_2.b"])
+        h = dense_relu(h, "fc_1", 0)
+        h = dense_relu(h, "fc_2", 1)
         loss = tref.sparse_ce_from_logits(F.log_softmax(h @ p["output.W"] + p["output.b"], dim=-1), yt)
     elif config == 4:      # xvector.py:58-61 (segment1 without its activation) -> L2 norm -> losses.py:25-49
         h = tref.stats_pool(h)
@@ -273,8 +290,8 @@ def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None):
         loss = tref.ap_loss(yt, z, num_langs)
     else:                  # xvector.py:58-67
         h = tref.stats_pool(h)
-        h = F.relu(h @ p["segment1.W"] + p["segment1.b"])
-        h = F.relu(h @ p["segment2.W"] + p["segment2.b"])
+        h = dense_relu(h, "segment1", 0)
+        h = dense_relu(h, "segment2", 1)
         loss = tref.sparse_ce_from_logits(F.log_softmax(h @ p["outputs.W"] + p["outputs.b"], dim=-1), yt)
     loss.backward()
     return float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}, (flips, flip_z)
@@ -325,7 +342,9 @@ def test_whole_captured_step_at_bench_shape_matches_float64_oracle(config):
     ws = m.workspace(B, T)
     masks = None if bf16 else [(ws.act[i + 1][:, ws.pads[i + 1]:ws.pads[i + 1] + ws.Ts[i + 1], :] > 0).cpu().numpy()
                                for i in range(len(m.convs))]
-    ref_loss, ref_g, (flips, flip_z) = _oracle_step64(config, w0, x_gpu, y.cpu().numpy(), langs, relu_masks=masks)
+    dmasks = None if bf16 else [(h > 0).cpu().numpy() for h in ws.h[:-1]]          # the ReLU Dense layers (all but the logits)
+    ref_loss, ref_g, (flips, flip_z) = _oracle_step64(config, w0, x_gpu, y.cpu().numpy(), langs, relu_masks=masks, dense_masks=dmasks)
+    print("config %d: %d ReLU decisions differ from the float64 oracle's, largest |z| among them %.3g" % (config, flips, flip_z))
     assert flips <= 200 and flip_z <= 2e-6, (flips, flip_z)          # only pre-activations within fp32 rounding of zero may differ
     if not bf16:
         # the tolerances of tests/test_model_gpu.py::test_xvector_loss_and_gradients_match_oracle
