@@ -103,9 +103,10 @@ int lidbox_extract_features_fwd_shadow(const lidbox_feat_plan* plan, int kind, c
 /* The general form (round 6).  src_format: LIDBOX_SRC_F32 (signals = float [B, N]) or LIDBOX_SRC_PCM16 (signals = int16_t [B, N], mono,
  * read in place: value / 32768 as tf.audio.decode_wav gives it, lidbox/features/audio.py:17-23 -- bit-identical to lidbox_pcm16_to_f32
  * followed by the float call, at half the bytes read; needs the fused kernel, 8-byte aligned signals and sig_stride / frame_length /
- * frame_step multiples of 4, LIDBOX_E_INVALID otherwise).  sig_stride counts samples.  nonfinite (may be NULL): device int the call ORs 1
- * into when any value it wrote to out is NaN or +-Inf -- tf.debugging.assert_all_finite of tf_utils.py:168-194 without a pass over the
- * output; the caller zeroes it and reads it when it wants the answer. */
+ * frame_step multiples of 4, LIDBOX_E_INVALID otherwise).  sig_stride counts samples.  nonfinite (may be NULL): an int the kernels can
+ * write -- device memory or pinned host memory -- set to 1 when any value the call wrote to out is NaN or +-Inf:
+ * tf.debugging.assert_all_finite of tf_utils.py:168-194 without a pass over the output; the caller zeroes it and reads it (after
+ * synchronising the stream) when it wants the answer. */
 enum { LIDBOX_SRC_F32 = 0, LIDBOX_SRC_PCM16 = 1 };
 int lidbox_extract_features_fwd_ex(const lidbox_feat_plan* plan, int kind, const void* signals, int src_format,
                                    int B, int N, long sig_stride, float* out, long out_batch_stride, void* out16,

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("LIDBOX_HIP_LIB") or os.path.join(_HERE, "csrc", "libl
 ABI_VERSION = 1
 
 FEAT_SPECTROGRAM, FEAT_MEL, FEAT_LOGMEL, FEAT_MFCC = 0, 1, 2, 3
+SRC_F32, SRC_PCM16 = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_ACCUM_RELU_MASK, EPI_ACCUM_RELU, EPI_RELU = range(8)
 EPI_MASK_BF16 = 0x100            # flag for lidbox_gemm_bf16s_nt: the ReLU-mask source is bfloat16 data
 

@@ -404,7 +404,8 @@ struct FusedArgs {
     float* out;
     long out_bs;                // floats between consecutive utterances in out
     unsigned short* out16;      // SHADOW instantiations: bfloat16 copy of the output (round-to-nearest-even) at the same ELEMENT offsets as out
-    int* nonfinite;             // may be NULL: |= 1 when a stored feature value is not finite
+    int* nonfinite;             // may be NULL: set to 1 when a stored feature value is not finite (a plain store: every writer writes the same
+                                // value, and the word may live in pinned host memory)
     int tiles_per_utt;          // ceil(T / 8)
     long ntiles;                // B * tiles_per_utt
     int iters;                  // tiles per wave
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(256, LBX_FEAT_WAVES) void fused_feat512_kernel(cons
         }
         LBX_STAMP(8);
     }
-    if (a.nonfinite && bad != bad) atomicOr(a.nonfinite, 1);
+    if (a.nonfinite && bad != bad) *a.nonfinite = 1;
     LBX_STAMP_K(14);
     LBX_STAMP_K(15);
 }
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(1024) void feat512_stream_kernel(const FusedArgs a)
         LBX_STAMP(8);
         cur = nxt;
     }
-    if (a.nonfinite && badmask != 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicOr(a.nonfinite, 1);
+    if (a.nonfinite && badmask != 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) *a.nonfinite = 1;
     LBX_STAMP_K(14);
     LBX_STAMP_K(15);
 }
@@ -1428,7 +1429,7 @@ __global__ void shadow_rows_kernel(const float* __restrict__ in, unsigned short*
 __global__ void nonfinite_rows_kernel(const float* __restrict__ x, long bs, long per, int* __restrict__ flag) {
     float bad = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) bad = fmaf(x[blockIdx.y * bs + i], 0.f, bad);
-    if (bad != bad) atomicOr(flag, 1);
+    if (bad != bad) *flag = 1;
 }
 
 template <int KIND>

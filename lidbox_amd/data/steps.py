@@ -96,7 +96,10 @@ def extract_features(ds, config):
     logger.info("Extracting '%s' features on device '%s' with arguments:\n  %s", feature_type, device,
                 "\n  ".join(repr(a) for a in args[1:]))
     for batch in _batches(ds, config):
-        signals = torch.stack([torch.as_tensor(x["signal"], dtype=torch.float32) for x in batch]).to(device)
+        sigs = [torch.as_tensor(x["signal"]) for x in batch]
+        if not all(t.dtype == torch.int16 for t in sigs):                            # 16-bit PCM stays int16: the kernel reads it in place
+            sigs = [t.to(torch.float32) for t in sigs]
+        signals = torch.stack(sigs).to(device)
         rates = [int(x["sample_rate"]) for x in batch]
         feats = tf_utils.extract_features(signals, rates, *args)
         for i, x in enumerate(batch):                                                # unbatch (:736)

@@ -22,14 +22,19 @@ def _assert_all_finite(X, message):
 
 def extract_features(signals, sample_rates, feattype, spec_kwargs=None, melspec_kwargs=None, mfcc_kwargs=None,
                      db_spec_kwargs=None, feat_scale_kwargs=None, window_norm_kwargs=None, check_finite=True):
-    """reference lidbox/data/tf_utils.py:166-195.  signals [B,N] float32 on the HIP device,
-    sample_rates [B] (tensor, list or int).  check_finite=False skips the device->host sync the
+    """reference lidbox/data/tf_utils.py:166-195.  signals [B,N] float32 (or int16: 16-bit PCM read in place) on the HIP
+    device, sample_rates [B] (tensor, list or int).  check_finite=False skips the device->host sync the
     reference's asserts imply."""
     if not isinstance(signals, torch.Tensor) or signals.dim() != 2:
         raise ValueError("Input signals for feature extraction must be batches of mono signals without "
                          "channels, i.e. of shape [B, N] where B is batch size and N number of samples.")
-    rates = torch.as_tensor(sample_rates).reshape(-1).tolist()
-    if any(r != rates[0] for r in rates):
+    if isinstance(sample_rates, int):
+        rates = [sample_rates]
+    elif isinstance(sample_rates, (list, tuple)) and sample_rates and all(type(r) is int for r in sample_rates[:1]):
+        rates = sample_rates
+    else:
+        rates = torch.as_tensor(sample_rates).reshape(-1).tolist()
+    if rates.count(rates[0]) != len(rates):
         raise ValueError("Different sample rates in a single batch not supported, all signals in the same "
                          "batch should have the same sample rate.")
     if feattype not in _KIND:
@@ -44,9 +49,12 @@ def extract_features(signals, sample_rates, feattype, spec_kwargs=None, melspec_
         sample_rate, frame_length, frame_step, spec_kwargs.get("fft_length", 512), spec_kwargs.get("power", 2.0),
         melspec_kwargs.get("num_mel_bins", 40), melspec_kwargs.get("fmin", 0.0), melspec_kwargs.get("fmax", 8000.0),
         mfcc_kwargs.get("coef_begin", 1), mfcc_kwargs.get("coef_end", 13), device=signals.device)
-    X = plan.run(_KIND[feattype], signals)
-    if check_finite:
-        _assert_all_finite(X, feattype + " failed")
+    # the kernel's store stage folds "a value is not finite" into a 4-byte flag: tf.debugging.assert_all_finite (reference
+    # tf_utils.py:173-194) costs one scalar read instead of a pass over the features
+    flag = audio_features.FiniteFlag.get(signals.device) if check_finite else None
+    X = plan.run(_KIND[feattype], signals, nonfinite=flag)
+    if check_finite and not flag.ok():
+        raise FloatingPointError(feattype + " failed")
     if feattype == "db_spectrogram":
         X = audio_features.power_to_db(X, **(db_spec_kwargs or {}))
         if check_finite:

@@ -32,6 +32,8 @@ class FeaturePlan:
                                                 ctypes.byref(h)))
         self.handle = h
         self.frame_length, self.frame_step, self.fft_length = int(frame_length), int(frame_step), int(fft_length)
+        self.power = float(power)
+        self.fused = bool(nv.lib.lidbox_feat_plan_is_fused(h, 2, None, 0))      # the fused kernels need no workspace
 
     def channels(self, kind):
         return nv.lib.lidbox_feat_plan_channels(self.handle, kind)
@@ -39,10 +41,15 @@ class FeaturePlan:
     def num_frames(self, num_samples):
         return nv.lib.lidbox_num_frames(int(num_samples), self.frame_length, self.frame_step)
 
-    def run(self, kind, signals, out=None, out_batch_stride=0, out16=None):
-        """signals [B,N] float32 on the HIP device -> [B,T,C].  out16: optional bfloat16 tensor laid out like `out`, receives
-        bf16(out) from the same call (the shadow the bf16-storage Conv1D path reads)."""
-        nv.require_gpu_tensor(signals, "signals", torch.float32)
+    def run(self, kind, signals, out=None, out_batch_stride=0, out16=None, nonfinite=None):
+        """signals [B,N] on the HIP device -> [B,T,C].  float32, or int16: 16-bit mono PCM read in place (value / 32768 as
+        tf.audio.decode_wav scales it, reference audio.py:17-23; bit-identical to pcm16_to_float followed by the float call, half
+        the bytes read).  out16: optional bfloat16 tensor laid out like `out`, receives bf16(out) from the same call (the shadow the
+        bf16-storage Conv1D path reads).  nonfinite: optional int32 device tensor of one element the kernel ORs 1 into when a value
+        it wrote is NaN / Inf (the caller zeroes it and reads it when it wants the answer: `all_finite`)."""
+        if not isinstance(signals, torch.Tensor) or signals.dtype not in (torch.float32, torch.int16):
+            nv.require_gpu_tensor(signals, "signals", torch.float32)      # raises the usual message
+        nv.require_gpu_tensor(signals, "signals", signals.dtype)
         if signals.dim() != 2:
             raise ValueError("Input signals for feature extraction must be batches of mono signals "
                              "without channels, i.e. of shape [B, N]")
@@ -55,15 +62,73 @@ class FeaturePlan:
         if B == 0 or T == 0:
             return out
         stride = signals.stride(0) if B > 1 else N      # a size-1 dim may carry any stride
-        wbytes = nv.lib.lidbox_extract_features_workspace(self.handle, kind, B, N, nv.ptr(signals), stride)
+        pcm = signals.dtype == torch.int16
+        if pcm and not self._pcm_in_place(signals, stride):
+            signals = pcm16_to_float(signals.contiguous().reshape(-1), 1, device=signals.device).reshape(B, N)      # one conversion pass, then the float path
+            stride, pcm = N, False
+        wbytes = 0 if (pcm or self.fused) else nv.lib.lidbox_extract_features_workspace(self.handle, kind, B, N, nv.ptr(signals), stride)
         ws = torch.empty(wbytes, dtype=torch.uint8, device=signals.device) if wbytes else None
-        with torch.cuda.device(signals.device):
-            if out16 is not None:
-                nv.require_gpu_tensor(out16, "out16", torch.bfloat16)
-            nv.check(nv.lib.lidbox_extract_features_fwd_shadow(self.handle, kind, nv.ptr(signals), B, N, stride,
-                                                               nv.ptr(out), int(out_batch_stride), nv.ptr(out16), nv.ptr(ws), wbytes,
-                                                               nv.current_stream()))
+        if out16 is not None:
+            nv.require_gpu_tensor(out16, "out16", torch.bfloat16)
+        flag_ptr = None
+        if nonfinite is not None:
+            flag_ptr = nonfinite.ptr if isinstance(nonfinite, FiniteFlag) else nv.ptr(nv.require_gpu_tensor(nonfinite, "nonfinite", torch.int32))
+
+        def call():
+            nv.check(nv.lib.lidbox_extract_features_fwd_ex(self.handle, kind, nv.ptr(signals), nv.SRC_PCM16 if pcm else nv.SRC_F32, B, N,
+                                                           stride, nv.ptr(out), int(out_batch_stride), nv.ptr(out16), flag_ptr,
+                                                           nv.ptr(ws), wbytes, nv.current_stream()))
+        if signals.device.index == torch.cuda.current_device():
+            call()
+        else:
+            with torch.cuda.device(signals.device):
+                call()
         return out
+
+    def _pcm_in_place(self, signals, stride):
+        """what lidbox_extract_features_fwd_ex asks of a 16-bit source (include/lidbox_hip.h): the fused fft_length-512 kernel with
+        power 2, 8-byte aligned rows, row stride / frame_length / frame_step multiples of 4"""
+        return (self.fft_length == 512 and self.power == 2.0 and self.frame_length <= 512 and signals.data_ptr() % 8 == 0
+                and stride % 4 == 0 and self.frame_length % 4 == 0 and self.frame_step % 4 == 0
+                and bool(nv.lib.lidbox_feat_plan_is_fused(self.handle, 2, nv.ptr(signals), stride)))
+
+
+def all_finite(flag):
+    """True when no call since the flag was zeroed wrote a NaN / Inf (one 4-byte read; synchronises the stream)."""
+    if isinstance(flag, FiniteFlag):
+        return flag.ok()
+    return int(flag.item()) == 0
+
+
+class FiniteFlag:
+    """The word the feature kernels OR "a stored value was not finite" into, in PINNED HOST memory the device writes directly (a
+    kernel touches it only when it has found such a value): asking for the answer is a stream synchronisation and a host load, no
+    device-to-host copy and no allocation per call.  One per (thread, device), re-armed after it has fired."""
+
+    _local = threading.local()
+
+    def __init__(self):
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        import ctypes
+        self.ptr = ctypes.c_void_p(self.host.data_ptr())      # hipHostMalloc'd: the same address is valid on the device
+
+    @classmethod
+    def get(cls, device):
+        flags = getattr(cls._local, "flags", None)
+        if flags is None:
+            flags = cls._local.flags = {}
+        key = torch.device(device).index
+        f = flags.get(key)
+        if f is None:
+            f = flags[key] = cls()
+        return f
+
+    def ok(self):
+        torch.cuda.current_stream().synchronize()
+        if int(self.host[0]) == 0:
+            return True
+        self.host[0] = 0
+        return False
 
 
 def get_plan(sample_rate, frame_length, frame_step, fft_length=512, power=2.0, num_mel_bins=40, fmin=0.0,

@@ -76,8 +76,10 @@ class GradSync:
         # asks for), and widened back into the fp32 gradient buffer for Adam (lidbox_bf16_to_f32).  The sum over ranks is then
         # formed in bf16 by the collective: ~3 significant digits per element, the precision of the bf16 backward that
         # produced the gradients; fp32 master weights and Adam moments are untouched.
-        wire_dtype = {None: None, "float32": None, "bfloat16": torch.bfloat16, torch.float32: None,
-                      torch.bfloat16: torch.bfloat16}[wire_dtype]
+        wire_formats = {None: None, "float32": None, "bfloat16": torch.bfloat16, torch.float32: None, torch.bfloat16: torch.bfloat16}
+        if wire_dtype not in wire_formats:
+            raise ValueError("grad_wire_dtype must be None, 'float32' or 'bfloat16', got %r" % (wire_dtype,))
+        wire_dtype = wire_formats[wire_dtype]
         if wire_dtype is not None and flat.dtype != torch.float32:
             raise ValueError("a bfloat16 wire format needs a float32 gradient buffer")
         self.wire_dtype = wire_dtype

@@ -225,6 +225,130 @@ def test_data_parallel_grad_sync_two_gloo_ranks(tmp_path, nv):
         assert "ok" in out
 
 
+_DP8_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    from lidbox_amd.metrics import SparseAverageDetectionCost
+    from lidbox_amd.train import GradSync, init_distributed, plan_buckets, shard_bounds
+    from oracle import model_np as mo
+
+    rank, world, _ = init_distributed(backend="gloo")
+    assert world == 8 and dist.get_backend() == "gloo"
+
+    class Conv:
+        def __init__(self, name):
+            self.name = name
+
+    class XVector:        # layout of lidbox.models.xvector (4 languages): what plan_buckets needs, no device
+        convs = [Conv("frame%%d" %% i) for i in range(1, 6)]
+        layout = {"frame1.W": (0, (5, 40, 512)), "frame2.W": (102912, (3, 512, 512)), "frame3.W": (889856, (3, 512, 512)),
+                  "frame4.W": (1676800, (1, 512, 512)), "frame5.W": (1939456, (1, 512, 1500))}
+        num_flat = 4510176
+    bounds, split = plan_buckets(XVector(), 3)
+    assert bounds == [0, 102912, 889856, 4510176]
+    n = XVector.num_flat
+
+    # BASELINE configs[2] / [4]: 8 ranks, uneven shards (2051 = 3 x 257 + 5 x 256).  A rank's backward leaves
+    # sum_{b in shard} g_b / GLOBAL batch in its flat buffer (Trainer._loss_scale); the bucketed all-reduce(sum), launched from the
+    # top bucket down as the backward pass does, must leave the global-batch mean gradient on every rank.
+    B = 2051
+    lo, hi = shard_bounds(B, rank, world)
+    assert hi - lo == (257 if rank < 3 else 256)
+    g = torch.Generator().manual_seed(1234)
+    base = torch.randn(n, generator=g, dtype=torch.float32)                  # the same on every rank
+    coef = torch.randn(B, generator=g, dtype=torch.float64)                  # utterance b's gradient = coef[b] * base (rank-1: cheap and exact to reason about)
+    mine = (base.double() * (coef[lo:hi].sum() / B)).float()
+    expect = base.double() * coef.mean()
+    flat = mine.clone()
+    sync = GradSync(flat, bounds)
+    assert sync.active and sync.world == 8 and sync.num_buckets == 3 and sync.wire_bytes == 4 * n
+    for i in (2, 1, 0):
+        sync.launch(i)
+    sync.wait()
+    tol = 8 * 2.0 ** -24 * float(expect.abs().max()) * 4
+    assert float((flat.double() - expect).abs().max()) <= tol
+    # every rank holds the same bits (the collective's result does not depend on the rank)
+    probe = flat[::4099].clone()
+    ref = probe.clone(); dist.broadcast(ref, 0)
+    assert torch.equal(probe, ref)
+
+    # bf16 wire format at world 8: each rank rounds once, the collective sums in bf16 (world - 1 more roundings), the result is
+    # widened to fp32: within (world + 1) half-ulps of bf16 of the fp32 sum, and again identical on every rank
+    flat16 = mine.clone()
+    s16 = GradSync(flat16, bounds, wire_dtype="bfloat16")
+    assert s16.wire_bytes == 2 * n
+    for i in (2, 1, 0):
+        s16.launch(i)
+    s16.wait()
+    assert flat16.dtype == torch.float32
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    bound = sum(p.abs().double() for p in parts) * (world + 1) * 2.0 ** -9 + 1e-30
+    assert bool(((flat16.double() - expect).abs() <= bound).all())
+    ref16 = flat16[::4099].clone(); dist.broadcast(ref16, 0)
+    assert torch.equal(flat16[::4099], ref16)
+    try:
+        GradSync(mine.clone(), bounds, wire_dtype="float16")
+        raise SystemExit("an unknown wire format must be rejected")
+    except ValueError:
+        pass
+
+    # C_avg at configs[4]'s world size: every rank counts its shard (here with the oracle's counting, the HIP kernel needs a GPU),
+    # sync_counters() all-reduces the four state tensors, the result equals one process over the whole batch -- exactly
+    N, Th, Bm = 10, 13, 803
+    rng = np.random.default_rng(7)
+    scores = rng.standard_normal((Bm, N)).astype(np.float32)
+    labels = rng.integers(0, N, size=Bm)
+    th = np.linspace(-2.0, 2.0, Th).astype(np.float32)
+    lo, hi = shard_bounds(Bm, rank, world)
+    part = mo.SparseAverageDetectionCost(N, th)
+    part.update_state(labels[lo:hi], scores[lo:hi])
+    m = SparseAverageDetectionCost(N, th, device="cpu")
+    for dst, src in zip(m.counters(), (part.tp, part.fn, part.fp_pairs, part.tn_pairs)):
+        dst.copy_(torch.from_numpy(src))
+    m.sync_counters()
+    whole = mo.SparseAverageDetectionCost(N, th)
+    whole.update_state(labels, scores)
+    for got, want in zip(m.counters(), (whole.tp, whole.fn, whole.fp_pairs, whole.tn_pairs)):
+        assert np.array_equal(got.numpy(), want)
+    synced = mo.SparseAverageDetectionCost(N, th)
+    synced.tp, synced.fn, synced.fp_pairs, synced.tn_pairs = [c.numpy() for c in m.counters()]
+    assert synced.result() == whole.result()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_data_parallel_at_baseline_world_size_eight_gloo_ranks(tmp_path, nv):
+    """BASELINE configs[2] / [4] run on 8 GPUs; no box this build saw had more than one.  What can be checked without them: the
+    bucket plan of the real x-vector layout, uneven shards, the fp32 and bf16 wire formats and the C_avg counter exchange across
+    EIGHT gloo ranks on the host equal the single-process answer."""
+    script = tmp_path / "dp8_worker.py"
+    script.write_text(_DP8_WORKER % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
+        assert "ok" in out
+
+
 def test_bucket_plan_is_contiguous_partition():
     """plan_buckets needs no device: use a layout-only stand-in with the x-vector's shapes"""
     from lidbox_amd.train import plan_buckets

@@ -408,3 +408,109 @@ def test_bf16_shadow_equals_rounded_features(B, dur):
     ref = plan.run(nv.FEAT_LOGMEL, x)
     assert torch.equal(buf[:, :T], ref) and torch.equal(buf16[:, :T], ref.to(torch.bfloat16))
     assert (buf[:, T:] == -5.0).all() and (buf16[:, T:] == -5.0).all()
+
+
+# ------------------------------------------------------------------ round 6: the streaming kernel's extras
+@pytest.mark.parametrize("kind", ["logmelspectrogram", "mfcc", "melspectrogram", "spectrogram"])
+def test_pcm16_source_read_in_place_is_bit_identical_to_convert_then_extract(kind, wav_paths):
+    """16-bit PCM handed to the feature kernel as it lies in memory (reference audio.py:17-23 read_wav -> tf.audio.decode_wav: value /
+    32768) against lidbox_pcm16_to_f32 followed by the float call: same bits (the scale is a power of two folded into the window
+    table), on random PCM with full-scale values, on the reference's WAV fixtures, and against the float64 oracle."""
+    from lidbox_amd.data import tf_utils
+    from lidbox_amd.features import audio
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-32768, 32768, size=(37, 16000), dtype=np.int16)
+    pcm[0, :8] = [-32768, 32767, 0, 1, -1, 255, -256, 12345]
+    rates = [16000] * len(pcm)
+    x16 = _dev(pcm)
+    got = tf_utils.extract_features(x16, rates, kind)
+    xf = audio.pcm16_to_float(x16.reshape(-1), 1).reshape(pcm.shape)
+    assert torch.equal(xf.cpu(), torch.from_numpy(pcm.astype(np.float32) / 32768.0))
+    want = tf_utils.extract_features(xf, rates, kind)
+    assert torch.equal(got, want)
+    ref = fo.extract_features(pcm[:4].astype(np.float64) / 32768.0, rates[:4], kind)
+    if kind in ("logmelspectrogram", "mfcc"):
+        assert np.abs(got[:4].cpu().numpy() - ref).max() <= LOGMEL_TOL
+    else:
+        assert np.abs(got[:4].cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    # the reference's fixtures, one utterance per call (odd lengths: the tail of the last float4 is outside the utterance)
+    for path in wav_paths:
+        sig64, rate = fo.read_wav_pcm16(path)
+        raw = np.round(sig64 * 32768.0).astype(np.int16)
+        a = tf_utils.extract_features(_dev(raw[None, :]), [rate], kind)
+        b = tf_utils.extract_features(_dev((raw.astype(np.float32) / 32768.0)[None, :]), [rate], kind)
+        assert torch.equal(a, b), path
+    # a source the in-place kernel cannot take (rows 2 bytes off an 8-byte boundary) goes through one conversion pass: same result
+    big = _dev(np.concatenate([np.zeros((37, 1), np.int16), pcm], axis=1))
+    assert torch.equal(tf_utils.extract_features(big[:, 1:], rates, kind), want)
+
+
+def test_nonfinite_flag_from_the_store_stage():
+    """tf.debugging.assert_all_finite of reference tf_utils.py:173-194 without a pass over the output: the kernels fold "a value
+    I stored is not finite" into a 4-byte flag.  Clean signals leave it 0; one NaN / Inf sample anywhere inside a frame sets it and
+    extract_features raises like the reference; a poisoned sample that no frame reads (the tail behind the last frame) does not."""
+    from lidbox_amd import _native as nv
+    from lidbox_amd.data import tf_utils
+    from lidbox_amd.features import audio
+    rng = np.random.default_rng(9)
+    sig = (rng.standard_normal((300, 16000 + 77)) * 0.1).astype(np.float32)          # 300 x 13 tiles: the streaming kernel, several tiles per wave
+    plan = audio.get_plan(16000, 400, 160)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for kind in (nv.FEAT_LOGMEL, nv.FEAT_MFCC, nv.FEAT_MEL, nv.FEAT_SPECTROGRAM):
+        x = _dev(sig)
+        flag.zero_()
+        out = plan.run(kind, x, nonfinite=flag)
+        assert audio.all_finite(flag) and bool(torch.isfinite(out).all())
+        for b, n, v in ((0, 0, np.nan), (299, 15900, np.inf), (150, 8000, -np.inf)):
+            x = _dev(sig)
+            x[b, n] = v
+            flag.zero_()
+            out = plan.run(kind, x, nonfinite=flag)
+            assert not audio.all_finite(flag), (kind, b, n)
+            assert not bool(torch.isfinite(out).all())
+        x = _dev(sig)
+        x[7, 16000 + 50] = np.nan          # behind the last frame (98 frames: the last one covers samples 15 520 ... 15 919)
+        flag.zero_()
+        out = plan.run(kind, x, nonfinite=flag)
+        assert audio.all_finite(flag) and bool(torch.isfinite(out).all())
+    x = _dev(sig)
+    x[3, 1234] = np.nan
+    with pytest.raises(FloatingPointError):
+        tf_utils.extract_features(x, [16000] * 300, "logmelspectrogram")
+    assert tf_utils.extract_features(x, [16000] * 300, "logmelspectrogram", check_finite=False).shape == (300, 98, 40)
+    # the paths without a flag in their store stage (another fft_length: generic kernels) report through one extra pass
+    plan1k = audio.get_plan(16000, 400, 160, fft_length=1024)
+    flag.zero_()
+    plan1k.run(nv.FEAT_LOGMEL, x[:4], nonfinite=flag)
+    assert not audio.all_finite(flag)
+    flag.zero_()
+    plan1k.run(nv.FEAT_LOGMEL, _dev(sig[:4]), nonfinite=flag)
+    assert audio.all_finite(flag)
+
+
+@pytest.mark.parametrize("frame_ms,step_ms", [(32, 10), (25, 10), (26, 8), (20, 5)])
+def test_streaming_kernel_frame_lengths_and_the_unaligned_kernel_agree(frame_ms, step_ms):
+    """Frames of <= 416 samples take the pruned instantiation (13 of 16 sample loads per lane), longer ones (32 ms = 512 samples) the
+    full one; signals whose rows are not 16-byte aligned take the round-1 kernel with its guarded loads.  All against the oracle,
+    and the two kernels against each other (same arithmetic, different instruction selection: within 2e-5 of the largest value)."""
+    from lidbox_amd.data import tf_utils
+    rng = np.random.default_rng(frame_ms)
+    B, N = 130, 12000 + 3                                                      # 130 utterances: several tiles per wave
+    sig = (rng.standard_normal((B, N + 1)) * 0.1).astype(np.float32)
+    kw = dict(spec_kwargs=dict(frame_length_ms=frame_ms, frame_step_ms=step_ms))
+    dev = _dev(sig)
+    for kind, tol in (("logmelspectrogram", LOGMEL_TOL), ("mfcc", MFCC_TOL)):
+        ref = fo.extract_features(sig[:3, :N], [16000] * 3, kind, **kw)
+        aligned = tf_utils.extract_features(dev[:, :N], [16000] * B, kind, **kw)              # rows 48 016 bytes apart: 16-byte aligned
+        unaligned = tf_utils.extract_features(dev[:, 1:N + 1], [16000] * B, kind, **kw)      # 4 bytes off
+        ref_u = fo.extract_features(sig[:3, 1:N + 1], [16000] * 3, kind, **kw)
+        assert aligned.shape[1:] == ref.shape[1:]
+        assert np.abs(aligned[:3].cpu().numpy() - ref).max() <= tol
+        assert np.abs(unaligned[:3].cpu().numpy() - ref_u).max() <= tol
+    spec_a = tf_utils.extract_features(dev[:, :N], [16000] * B, "spectrogram", **kw)
+    spec_u = tf_utils.extract_features(dev[:, 4:N + 4 - 3].contiguous(), [16000] * B, "spectrogram", **kw)      # same kernel, shifted copy
+    assert spec_a.shape[0] == spec_u.shape[0] == B
+    # one input through both kernels: a dense copy (aligned) vs a view one float off (unaligned) of the same samples
+    same_a = tf_utils.extract_features(dev[:, 1:N + 1].contiguous(), [16000] * B, "spectrogram", **kw)
+    same_u = tf_utils.extract_features(dev[:, 1:N + 1], [16000] * B, "spectrogram", **kw)
+    assert float((same_a - same_u).abs().max()) <= 2e-5 * float(same_a.abs().max())
