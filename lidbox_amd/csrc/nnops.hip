@@ -1292,7 +1292,17 @@ extern "C" int lidbox_ap_head_fwd_bwd(const float* x, const int32_t* labels, int
     LBX_ARG(delta_weight > 0.f, "delta_weight > 0 (losses.py:16)");
     LBX_ARG(D <= AP_HEAD_MAX_D, "D <= 4096 (wider rows: the separate entry points)");
     if (B == 0) return LIDBOX_OK;
-    hipLaunchKernelGGL(ap_head_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), (size_t)8 * D * sizeof(float), (hipStream_t)stream, x, labels,
+    const size_t lds = (size_t)8 * D * sizeof(float);         // 128 KB at D = 4096: above the 64 KB a kernel may use without asking
+    if (lds > 65536) {
+        static std::atomic<unsigned long long> attr_devs{0};
+        int dev = 0;
+        LBX_HIP(hipGetDevice(&dev));
+        if (dev >= 64 || !(attr_devs.load() >> dev & 1ull)) {
+            LBX_HIP(hipFuncSetAttribute((const void*)ap_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dev < 64) attr_devs.fetch_or(1ull << dev);
+        }
+    }
+    hipLaunchKernelGGL(ap_head_kernel, dim3((unsigned)lbx_cdiv(B, 4)), dim3(256), lds, (hipStream_t)stream, x, labels,
                        B, D, N, delta_weight, scale, zn, loss_per_example, dx, scores);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;

@@ -18,51 +18,54 @@ namespace {
 // 256 threads = cw columns x (256/cw) row groups.
 // x and out may be the same buffer (every element is read and written by the same thread, the write comes last);
 // xs / os: floats between consecutive `outer` slices (>= R * inner).
-__global__ __launch_bounds__(256) void cmvn_kernel(const float* x, long R, long inner, long xs, long os,
+__global__ __launch_bounds__(256) void cmvn_kernel(const float* x, long outer, long R, long inner, long xs, long os,
                                                    int cw, int normalize_variance,
                                                    float* out) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int col = tid % cw, g = tid / cw, ng = 256 / cw;
     const long c = (long)blockIdx.x * cw + col;
-    const long o = blockIdx.y;
     const bool active = c < inner;
-    const float* xp = x + o * xs + c;
-    float* op = out + o * os + c;
+    // grid.y is capped at 65 535: a workgroup walks the outer slices o = blockIdx.y, + gridDim.y, ... (block-uniform trip count)
+    for (long o = blockIdx.y; o < outer; o += gridDim.y) {
+        const float* xp = x + o * xs + c;
+        float* op = out + o * os + c;
 
-    float s = 0.f;
-    if (active)
-        for (long r = g; r < R; r += ng) s += xp[r * inner];
-    red[tid] = s;
-    __syncthreads();
-    for (int h = ng / 2; h > 0; h >>= 1) {
-        if (g < h) red[tid] += red[tid + h * cw];
-        __syncthreads();
-    }
-    const float mean = red[col] / (float)R;
-    __syncthreads();
-
-    float sd = 1.f;
-    if (normalize_variance) {
-        float v = 0.f;
+        float s = 0.f;
         if (active)
-            for (long r = g; r < R; r += ng) {
-                const float d = xp[r * inner] - mean;
-                v = fmaf(d, d, v);
-            }
-        red[tid] = v;
+            for (long r = g; r < R; r += ng) s += xp[r * inner];
+        __syncthreads();                                 // the previous slice's readers of red[] are done
+        red[tid] = s;
         __syncthreads();
         for (int h = ng / 2; h > 0; h >>= 1) {
             if (g < h) red[tid] += red[tid + h * cw];
             __syncthreads();
         }
-        sd = sqrtf(red[col] / (float)R);             // population std of x
-    }
-    if (active)
-        for (long r = g; r < R; r += ng) {
-            const float d = xp[r * inner] - mean;
-            op[r * inner] = normalize_variance ? (sd != 0.f ? d / sd : 0.f) : d;   // divide_no_nan
+        const float mean = red[col] / (float)R;
+        __syncthreads();
+
+        float sd = 1.f;
+        if (normalize_variance) {
+            float v = 0.f;
+            if (active)
+                for (long r = g; r < R; r += ng) {
+                    const float d = xp[r * inner] - mean;
+                    v = fmaf(d, d, v);
+                }
+            red[tid] = v;
+            __syncthreads();
+            for (int h = ng / 2; h > 0; h >>= 1) {
+                if (g < h) red[tid] += red[tid + h * cw];
+                __syncthreads();
+            }
+            sd = sqrtf(red[col] / (float)R);             // population std of x
         }
+        if (active)
+            for (long r = g; r < R; r += ng) {
+                const float d = xp[r * inner] - mean;
+                op[r * inner] = normalize_variance ? (sd != 0.f ? d / sd : 0.f) : d;   // divide_no_nan
+            }
+    }
 }
 
 // numpy-'reflect' index into [0, T)
@@ -269,8 +272,8 @@ extern "C" int lidbox_cmvn_strided_fwd(const float* x, long outer, long R, long 
     if (outer == 0 || R == 0 || inner == 0) return LIDBOX_OK;
     int cw = 64;
     while (cw > 1 && cw / 2 >= inner) cw /= 2;
-    dim3 grid((unsigned)lbx_cdiv(inner, cw), (unsigned)outer);
-    hipLaunchKernelGGL(cmvn_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, R, inner, x_outer_stride,
+    dim3 grid((unsigned)lbx_cdiv(inner, cw), (unsigned)(outer < 65535 ? outer : 65535));
+    hipLaunchKernelGGL(cmvn_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, outer, R, inner, x_outer_stride,
                        out_outer_stride, cw, normalize_variance, out);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;

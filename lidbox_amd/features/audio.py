@@ -124,7 +124,7 @@ class FiniteFlag:
         return f
 
     def ok(self):
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().synchronize()      # (polling an event instead was measured: no faster)
         if int(self.host[0]) == 0:
             return True
         self.host[0] = 0

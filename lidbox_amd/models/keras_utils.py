@@ -25,6 +25,7 @@ import time
 import numpy as np
 import torch
 
+from .. import _native as nv
 from .. import metrics as lidbox_metrics
 from ..losses import SparseAngularProximity
 from ..train import Trainer
@@ -364,10 +365,28 @@ class KerasWrapper:
         return buf
 
     def _eval_loss(self, out, y):
-        if isinstance(self.loss, SparseAngularProximity):
-            zn = torch.nn.functional.normalize(out, dim=1)
-            return float(self.loss(y, zn)), self.loss.predict(zn)
-        return float(-out[torch.arange(out.shape[0], device=out.device), y.long()].mean()), out
+        """(mean loss of the batch, the scores the metrics read) on the library's own kernels: tf.math.l2_normalize + the loss for
+        SparseAngularProximity (reference losses.py:25-52), sparse categorical cross-entropy on the model's log-probabilities /
+        probabilities otherwise (keras_utils.py:141-147)"""
+        out = out.contiguous()
+        B, N = out.shape
+        st = nv.current_stream()
+        with torch.cuda.device(out.device):
+            if isinstance(self.loss, SparseAngularProximity):
+                zn = torch.empty_like(out)
+                nv.check(nv.lib.lidbox_l2_normalize_fwd(nv.ptr(out), B, N, nv.ptr(zn), st))
+                return float(self.loss(y, zn)), self.loss.predict(zn)
+            loss = torch.empty(1, dtype=torch.float32, device=out.device)
+            y32 = y.to(torch.int32).contiguous()
+            if getattr(self.keras_model, "output_activation", None) == "softmax":
+                # probabilities (a model built with output_activation="softmax", from_logits=False): Keras clips to [1e-7, 1 - 1e-7],
+                # renormalises and takes -log; the one configuration of this method that still prepares its operand with tensor ops
+                q = out.clamp(1e-7, 1 - 1e-7)
+                logp = (torch.log(q) - torch.log(q.sum(dim=1, keepdim=True))).contiguous()
+                nv.check(nv.lib.lidbox_nll_fwd_bwd(nv.ptr(logp), nv.ptr(y32), B, N, 1.0 / B, nv.ptr(loss), None, st))
+            else:
+                nv.check(nv.lib.lidbox_nll_fwd_bwd(nv.ptr(out), nv.ptr(y32), B, N, 1.0 / B, nv.ptr(loss), None, st))
+        return float(loss), out
 
     def evaluate(self, dataset):
         """mean loss and metric values over a dataset of (inputs, targets) batches (Keras `Model.evaluate`)"""

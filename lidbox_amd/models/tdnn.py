@@ -191,6 +191,10 @@ class _Workspace:
                 and chans[-1] % 4 == 0 and model.shadow_fwd_ok(len(convs) - 1) and convs[-1].d == 1
                 and os.environ.get("LIDBOX_BF16_POOL_FP32", "0") != "1"):
             self.last16 = torch.zeros((B, self.Ts[-1], (chans[-1] + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
+            # the fp32 buffers of the last layer stay allocated (the row descriptors are derived from them) but nothing writes
+            # them in this mode: poisoned, so that a reader that should have taken the shadow fails loudly instead of seeing zeros
+            self.act[-1].fill_(float("nan"))
+            self.dact[-1].fill_(float("nan"))
         fe = model.frontend
         if fe:
             # 2-D front-end (xvector_2d.py:69-73): model input [B, T, F]; layer i: a = relu(conv) [B*T*F_i+1, C_i+1] dense,
@@ -340,8 +344,7 @@ class SequentialTDNN:
         # its launches are latency-bound and the fp32 family's 64 x 64 tiles + tuned splits run them faster than the bf16
         # family's 128 x 128 tile (0.910 -> 0.871 ms/step at bs 256, neutral at bs 512).  LIDBOX_BF16_DENSE=1
         # puts the head on the bf16 family as well (A/B aid).
-        import os as _os0
-        self.dense_gemm = self.gemm if _os0.environ.get("LIDBOX_BF16_DENSE") == "1" else _GemmFamily("float32")
+        self.dense_gemm = self.gemm if os.environ.get("LIDBOX_BF16_DENSE") == "1" else _GemmFamily("float32")
         if self.compute_dtype == "bfloat16":
             widths = [self.input_dim] + [c.filters for c in self.convs] + [d.units for d in self.denses]
             if attention is not None:
@@ -387,9 +390,8 @@ class SequentialTDNN:
         # (dgrad reads a Keras kernel [k*C_in, C_out] as the [N][K] operand it is) but only the kernels listed in
         # `_flat16_live` are refreshed (`_refresh_bf16_weights`); every other element stays zero and `_p16` refuses to hand
         # it out.  `w16t[i]` is conv i's kernel transposed to [C_out, k*C_in] (forward's [N][K] operand)
-        import os as _os
         # (the storage path's output-stationary dgrad and its trail rows are laid out for causal windows)
-        self.bf16_storage = self.compute_dtype == "bfloat16" and _os.environ.get("LIDBOX_BF16_STORAGE", "1") != "0" \
+        self.bf16_storage = self.compute_dtype == "bfloat16" and os.environ.get("LIDBOX_BF16_STORAGE", "1") != "0" \
             and attention is None and not self.frontend and all(c.padding == "causal" for c in self.convs)
         if self.bf16_storage and not any(self.shadow_fwd_ok(i) for i in range(len(self.convs))):
             self.bf16_storage = False                    # no layer qualifies (e.g. the CNN's 12- / 500-channel layers): nothing to shadow
@@ -405,7 +407,7 @@ class SequentialTDNN:
             # activations act[1..n-1] and of all conv output gradients dact[1..n] have no reader -- they are not written at
             # all (the ReLU masks come from the shadows' signs).  LIDBOX_BF16_FP32_COPIES=1 keeps writing them (tests, A/B).
             n = len(self.convs)
-            self.bf16_only = _os.environ.get("LIDBOX_BF16_FP32_COPIES", "0") != "1" and self.pool == "stats" and all(
+            self.bf16_only = os.environ.get("LIDBOX_BF16_FP32_COPIES", "0") != "1" and self.pool == "stats" and all(
                 self.shadow_wgrad_ok(i) and (i == 0 or (self.shadow_dgrad_ok(i) and (self.convs[i].k <= self.convs[i].s or i < n - 1)))
                 for i in range(n))
             bf = dict(dtype=torch.bfloat16, device=self.device)

@@ -237,7 +237,7 @@ def _oracle_features64(config, sig):
     return fo.extract_features(sig, sr, "logmelspectrogram")
 
 
-def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None, dense_masks=None):
+def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None, dense_masks=None, force_masks=True):
     """loss and gradients of the model step in float64 (torch autograd on the host) on input features x.
     relu_masks: per Conv1D layer, the ReLU decisions (output > 0) the GPU step took.  A pre-activation within fp32 rounding of
     zero may fall on either side of the kink; the gradient of the piecewise-linear network is discontinuous there, so the
@@ -253,7 +253,7 @@ def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None, dense_masks=Non
     h = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
     p = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in w0.items()}
     yt = torch.from_numpy(y.astype(np.int64))
-    flips, flip_z = 0, 0.0
+    flips, flip_z, decisions, z_scale = 0, 0.0, 0, 0.0
     for i, (name, _, _, stride) in enumerate(model_np.CNN_CONVS if config == 3 else model_np.XVECTOR_FRAMES):
         z = tref.conv1d_causal(h, p[name + ".W"], p[name + ".b"], stride, relu=False)          # xvector.py:38-39 / cnn.py:32-35
         if relu_masks is None:
@@ -262,9 +262,13 @@ def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None, dense_masks=Non
             mk = torch.from_numpy(relu_masks[i])
             differ = mk != (z.detach() > 0)
             flips += int(differ.sum())
+            decisions += differ.numel()
             if bool(differ.any()):
+                # size of a disagreeing pre-activation, absolute (fp32 leg) and relative to the layer's RMS (bf16 leg)
                 flip_z = max(flip_z, float(z.detach()[differ].abs().max()))
-            h = z * mk.to(torch.float64)
+                z_scale = max(z_scale, float(z.detach()[differ].abs().max() / z.detach().pow(2).mean().sqrt()))
+            # force_masks: evaluate the oracle on the step's linear piece; otherwise only count the disagreements
+            h = z * mk.to(torch.float64) if force_masks else F.relu(z)
 
     def dense_relu(h, name, j):
         # the Dense layers behind the pooling have the same kink: same treatment (the step's own decisions, disagreements counted)
@@ -294,7 +298,7 @@ def _oracle_step64(config, w0, x, y, num_langs, relu_masks=None, dense_masks=Non
         h = dense_relu(h, "segment2", 1)
         loss = tref.sparse_ce_from_logits(F.log_softmax(h @ p["outputs.W"] + p["outputs.b"], dim=-1), yt)
     loss.backward()
-    return float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}, (flips, flip_z)
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in p.items()}, (flips, flip_z, decisions, z_scale)
 
 
 @pytest.mark.parametrize("config", [1, 3, 4])
@@ -340,12 +344,29 @@ def test_whole_captured_step_at_bench_shape_matches_float64_oracle(config):
     assert x_gpu.shape == x_ref.shape and np.abs(x_gpu - x_ref).max() <= 1e-3, np.abs(x_gpu - x_ref).max()      # log-mel / MFCC max-abs
     # the ReLU decisions of the captured step (fp32 activations; the bf16 configuration keeps shadows only and has the looser bounds)
     ws = m.workspace(B, T)
-    masks = None if bf16 else [(ws.act[i + 1][:, ws.pads[i + 1]:ws.pads[i + 1] + ws.Ts[i + 1], :] > 0).cpu().numpy()
-                               for i in range(len(m.convs))]
+    if not bf16:
+        masks = [(ws.act[i + 1][:, ws.pads[i + 1]:ws.pads[i + 1] + ws.Ts[i + 1], :] > 0).cpu().numpy() for i in range(len(m.convs))]
+    else:
+        # bf16 storage: the conv outputs exist as bf16 shadows only (the last one as `last16` when the pooling reads the shadow)
+        masks = []
+        for i, cv in enumerate(m.convs):
+            if i + 1 == len(m.convs) and ws.last16 is not None:
+                a16 = ws.last16[:, :, :cv.filters]
+            else:
+                a16 = ws.act16[i + 1][:, ws.pads[i + 1]:ws.pads[i + 1] + ws.Ts[i + 1], :cv.filters]
+            masks.append((a16 > 0).cpu().numpy())
     dmasks = None if bf16 else [(h > 0).cpu().numpy() for h in ws.h[:-1]]          # the ReLU Dense layers (all but the logits)
-    ref_loss, ref_g, (flips, flip_z) = _oracle_step64(config, w0, x_gpu, y.cpu().numpy(), langs, relu_masks=masks, dense_masks=dmasks)
-    print("config %d: %d ReLU decisions differ from the float64 oracle's, largest |z| among them %.3g" % (config, flips, flip_z))
-    assert flips <= 200 and flip_z <= 2e-6, (flips, flip_z)          # only pre-activations within fp32 rounding of zero may differ
+    ref_loss, ref_g, (flips, flip_z, decisions, z_rel) = _oracle_step64(config, w0, x_gpu, y.cpu().numpy(), langs, relu_masks=masks,
+                                                                       dense_masks=dmasks, force_masks=not bf16)
+    print("config %d: %d of %d ReLU decisions differ from the float64 oracle's, largest |z| among them %.3g (%.3g of the layer's RMS)"
+          % (config, flips, decisions, flip_z, z_rel))
+    if not bf16:
+        assert flips <= 200 and flip_z <= 2e-6, (flips, flip_z)      # only pre-activations within fp32 rounding of zero may differ
+    else:
+        # bf16 operands move every pre-activation by ~2^-8 of the layer's scale: decisions may differ only where |z| is that small.
+        # The oracle keeps its own decisions here (the loss / gradient tolerances below are the bf16 path's, which absorb them).
+        # (measured at the bench shape: 132 624 of 120.5 M decisions, the largest at 0.023 of its layer's RMS)
+        assert flips <= 5e-3 * decisions and z_rel <= 0.05, (flips, decisions, z_rel)
     if not bf16:
         # the tolerances of tests/test_model_gpu.py::test_xvector_loss_and_gradients_match_oracle
         assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
