@@ -1,4 +1,4 @@
-"""ISA census of fused_feat512_kernel<2, true, true, true, NW, false> (the log-mel instantiation; --nw=14 for the wide one) from hipcc's device assembly.
+"""ISA census of feat512_stream_kernel<2, true, false, false, 13> (the log-mel instantiation of the train step) from hipcc's device assembly.
 
     python tools/feat_census.py [--timing]      (build container or GPU box: needs hipcc only)
 
@@ -18,7 +18,7 @@ if timing:
     cmd.insert(1, "-DLBX_FEAT_TIMING=0")
 subprocess.run(cmd, check=True, capture_output=True)
 NW = next((a.split("=")[1] for a in sys.argv if a.startswith("--nw=")), "4")        # --nw=14: the wide workgroup's instantiation
-KERNEL = "_ZN12_GLOBAL__N_120fused_feat512_kernelILi2ELb1ELb1ELb1ELi%sELb0EEEvNS_9FusedArgsE" % NW
+KERNEL = "_ZN12_GLOBAL__N_121feat512_stream_kernelILi2ELb1ELb0ELb0ELi13EEEvNS_9FusedArgsE"
 lines = open(out).read().split("\n")
 i0 = lines.index(KERNEL + ": ; @" + KERNEL) if (KERNEL + ": ; @" + KERNEL) in lines else next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
 i1 = next(i for i in range(i0, len(lines)) if lines[i].strip().startswith("s_endpgm"))

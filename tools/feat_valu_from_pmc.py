@@ -16,9 +16,9 @@ import sys
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "fused_feat512_kernel" not in r["Kernel_Name"]:
+        if "feat512_stream_kernel" not in r["Kernel_Name"]:
             continue
-        key = (re.search(r"fused_feat512_kernel<[^>]*>", r["Kernel_Name"]).group(0), int(r["Grid_Size"]))
+        key = (re.search(r"feat512_stream_kernel<[^>]*>", r["Kernel_Name"]).group(0), int(r["Grid_Size"]))
         rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for (name, grid), c in sorted(rows.items()):

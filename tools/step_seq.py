@@ -8,7 +8,7 @@ def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return re.sub(r"\(.*", "", n)[:56]
 # a step starts at the feature kernel
-starts = [i for i, r in enumerate(rows) if "fused_feat512" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "feat512_stream" in r["Kernel_Name"] or "fused_feat512" in r["Kernel_Name"]]
 i0 = starts[-back]; i1 = starts[-back + 1] if back > 1 else len(rows)
 prev_end = None
 tot = 0.0

@@ -3,7 +3,7 @@ usage: python tools/step_trace.py <kernel_trace.csv>   (prints the dispatches of
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "fused_feat512" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "feat512_stream" in r["Kernel_Name"] or "fused_feat512" in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
