@@ -247,6 +247,8 @@ class KernelTimer:
                 elif self.ENTRY[_n] in (14, 16):
                     if self.nv.lib.lidbox_gemm_bf16s_tn_last_pp() > 0:     # the ping-pong wgrad tile (gemm16_pp_tn.h)
                         key = "gemm16s_tn_pp_kernel"
+                    elif self.nv.lib.lidbox_gemm_bf16s_tn_last_kres() > 0:  # the K1-resident wgrad (gemm16_tn_kres.h: frame1)
+                        key = "gemm16s_tn_kres_kernel"
                 self.records.setdefault(key, []).append((e0, e1, work, nk))
                 return rc
             setattr(self.nv.lib, name, wrapper)

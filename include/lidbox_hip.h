@@ -371,6 +371,11 @@ int lidbox_gemm_bf16s_last_carried(void);
  * is chosen for long slices of big layers (K1, N multiples of 256, >= 8 tiles, >= 2048 rows per slice: frame2's wgrad at 512
  * utterances); LIDBOX_GEMM16_TN_PP=0 / 1 in the environment forces never / whenever the operands allow (tuning aid). */
 int lidbox_gemm_bf16s_tn_last_pp(void);
+/* ... and the number of utterance slices of the K1-resident kernel (gemm16_tn_kres.h, round 6) if that ran, else 0: a contraction
+ * of <= 224 (whole output rows of one workgroup), N a multiple of 128, overlapping or adjacent windows of a batched input whose batch
+ * stride is a whole number of row strides -- frame1's wgrad (k = 5, 40 channels: K1 = 200).  LIDBOX_GEMM16_TN_KRES=0 / 1: never /
+ * whenever the operands allow. */
+int lidbox_gemm_bf16s_tn_last_kres(void);
 /* All bf16 weight shadows of a model in ONE launch (once per train step, after the optimizer): flat16[i] = bf16(flat[i]) for
  * the n parameters, and for each listed row-major [rows][cols] matrix at flat + offset a bf16 image at dst with its own
  * leading dimension: transposed ([cols][rows]: a Keras Conv1D kernel [k*C_in][C_out] -> the K-inner [C_out][k*C_in] operand

@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256, LBX16S_WAVES) void gemm16s_rows_kernel(RowsH A
 #include "gemm16_pp.h"
 #include "gemm16_pp_tn.h"
 #include "gemm16_kres.h"
+#include "gemm16_tn_kres.h"
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -1128,6 +1129,7 @@ int launch_rows16s_pp_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh,
 }
 
 thread_local int g16_last_carried = 0;                 // jobs the calling thread's last lidbox_gemm_bf16s_nt_carry ran inside its GEMM launch
+thread_local int g16_tn_last_kres = 0;                 // slices of the calling thread's last storage wgrad if the K1-resident kernel ran it, else 0
 thread_local int g16_tn_last_pp = 0;                   // slices of the calling thread's last storage wgrad if the ping-pong tile ran it, else 0
 thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the calling thread's last lidbox_gemm_bf16s_nt (0: register-staged)
 
@@ -1339,6 +1341,7 @@ extern "C" int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, lo
 
 extern "C" int lidbox_gemm_bf16s_last_carried(void) { return g16_last_carried; }
 extern "C" int lidbox_gemm_bf16s_tn_last_pp(void) { return g16_tn_last_pp; }
+extern "C" int lidbox_gemm_bf16s_tn_last_kres(void) { return g16_tn_last_kres; }
 
 extern "C" int lidbox_gemm_bf16s_last_variant(int* out3) {
     LBX_ARG(out3, "out3 != NULL");
@@ -1350,7 +1353,9 @@ extern "C" size_t lidbox_gemm_bf16s_tn_workspace(int M, int K1, int N) {
     if (M <= 0 || K1 <= 0 || N <= 0) return 0;
     const Tn16Plan pl = plan_tn16(M, K1, N, BKT);
     const TnPpPlan pp = plan_tn16_pp(M, K1, N);
-    const int splits = pp.use && pp.splits > pl.splits ? pp.splits : pl.splits;      // either kernel may run (descriptor checks at launch)
+    int splits = pp.use && pp.splits > pl.splits ? pp.splits : pl.splits;            // either kernel may run (descriptor checks at launch)
+    const TnKresPlan kp = plan_tn16_kres(M, K1, N);
+    if (kp.shape_ok && kp.max_slices > splits) splits = kp.max_slices;               // ... or the K1-resident one (gemm16_tn_kres.h)
     return ((size_t)splits * K1 * N + (size_t)splits * N) * sizeof(float);
 }
 
@@ -1400,11 +1405,66 @@ extern "C" int lidbox_gemm_bf16s_tn_partial(lidbox_rows_t A16, lidbox_rows_t B16
     if (pp.use && !(span_ok(A16, K1) && span_ok(B16, N) && K1 % 8 == 0 && N % 8 == 0 &&
                     ((A16.batch == 1 && B16.batch == 1) || (A16.batch == B16.batch && A16.rows_per_batch == B16.rows_per_batch))))
         pp.use = false;
+    hipStream_t st = (hipStream_t)stream;
+    // the K1-resident kernel (gemm16_tn_kres.h): short contraction over overlapping windows, the whole K1 extent in one workgroup's
+    // accumulators.  It walks the input as one flattened sequence of rows: utterances a whole number of row strides apart, at least as
+    // many of those as output rows, one stage's frames inside its LDS image; same utterance structure on both operands.
+    g16_tn_last_kres = 0;
+    {
+        const TnKresPlan kp = plan_tn16_kres(M, K1, N);
+        // (slices are ranges of utterances: with fewer utterances than half the slices the chip would be mostly idle)
+        const bool desc_ok = kp.shape_ok && (kp.forced || 2 * A16.batch >= kp.max_slices) && A16.batch == B16.batch &&
+                             A16.rows_per_batch == B16.rows_per_batch &&
+                             A16.row_stride > 0 && (A16.batch == 1 || A16.batch_stride % A16.row_stride == 0) &&
+                             (A16.batch == 1 || A16.batch_stride / A16.row_stride >= A16.rows_per_batch) &&
+                             63 * A16.row_stride + K1 <= TKR_IMG_ELEMS &&
+                             (63 + lbx_cdiv(K1, A16.row_stride)) * tkr_img_stride((int)A16.row_stride) <= TKR_IMG_BYTES && span_ok(A16, K1) &&
+                             span_ok(B16, N);
+        if (desc_ok) {
+            const int batch = A16.batch;
+            int slices = kp.max_slices < batch ? kp.max_slices : batch;
+            const int ups = (int)lbx_cdiv(batch, slices);
+            slices = (int)lbx_cdiv(batch, ups);
+            const size_t need_k = ((size_t)slices * K1 * N + (size_t)slices * N) * sizeof(float);
+            if (workspace && workspace_bytes >= need_k) {
+                const int tiles_n = N / TKR_BN;
+                const int Tq = batch == 1 ? A16.rows_per_batch : (int)(A16.batch_stride / A16.row_stride);
+                const long a_elems = (long)(batch - 1) * A16.batch_stride + (long)(A16.rows_per_batch - 1) * A16.row_stride + K1;
+                const long b_bytes = ((long)(batch - 1) * B16.batch_stride + (long)(B16.rows_per_batch - 1) * B16.row_stride + N) * 2;
+                float* P = (float*)workspace;
+                float* Pc = bias_grad ? P + (size_t)slices * K1 * N : nullptr;
+                const RowsH Ah{(const __bf16*)A16.base, A16.batch_stride, A16.row_stride, A16.batch, A16.rows_per_batch};
+                const RowsH Bh{(const __bf16*)B16.base, B16.batch_stride, B16.row_stride, B16.batch, B16.rows_per_batch};
+                {
+                    int dev = 0;
+                    LBX_HIP(hipGetDevice(&dev));
+                    static std::atomic<unsigned long long> attr_set{0};
+                    if (dev >= 64 || !((attr_set.load() >> dev) & 1ull)) {
+                        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_tn_kres_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TKR_LDS_BYTES));
+                        if (dev < 64) attr_set.fetch_or(1ull << dev);
+                    }
+                }
+                hipLaunchKernelGGL(gemm16s_tn_kres_kernel, dim3((unsigned)(tiles_n * slices)), dim3(512), TKR_LDS_BYTES, st, Ah, Bh, P, Pc, K1, N,
+                                   tiles_n, ups, Tq, a_elems, b_bytes);
+                LBX_LAUNCH_OK();
+                g16_tn_last_kres = slices;
+                g16_tn_last_pp = 0;
+                const long n = (long)K1 * N;
+                if (reduce_job_vec_ok(P, Pc, slices, n, N, Cm, ldc, bias_grad)) {
+                    const ReduceJob j = make_reduce_job(P, Pc, slices, n, N, Cm, ldc, accumulate, bias_grad);
+                    memcpy(job, &j, sizeof j);
+                    return LIDBOX_OK;
+                }
+                launch_splitk_reduce((const float*)P, (const float*)Pc, slices, n, N, Cm, ldc, accumulate, bias_grad, st);
+                LBX_LAUNCH_OK();
+                return LIDBOX_OK;
+            }
+        }
+    }
     if (pp.use) pl = Tn16Plan{pp.splits, pp.rows_per_split};
     g16_tn_last_pp = pp.use ? pp.splits : 0;
     const size_t need = ((size_t)pl.splits * K1 * N + (size_t)pl.splits * N) * sizeof(float);
     LBX_ARG(workspace && workspace_bytes >= need, "workspace too small (lidbox_gemm_bf16s_tn_workspace)");
-    hipStream_t st = (hipStream_t)stream;
     if (pp.use) {
         int dev = 0;
         LBX_HIP(hipGetDevice(&dev));

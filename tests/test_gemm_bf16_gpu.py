@@ -469,6 +469,94 @@ def test_bf16_storage_wgrad_pingpong_tile(Bn, T, C, k, s_, Co, monkeypatch):
     _close(out["1"], out["0"], rel=1e-5)
 
 
+@pytest.mark.parametrize("Bn,T,C,k,s_,Co", [(9, 130, 40, 5, 1, 256),       # frame1's window shape: K1 = 200 (6 full row blocks + 8 rows)
+                                            (70, 33, 40, 5, 1, 512),       # more utterances than slices (two per slice), N = 512
+                                            (5, 60, 16, 5, 2, 128),        # stride 2: K1 = 80, row stride 32 elements, one column tile
+                                            (3, 198, 24, 9, 1, 128),       # K1 = 216: seven blocks, the last one of 24 rows
+                                            (1, 5000, 40, 5, 1, 128),      # one long utterance (flat rows)
+                                            (130, 7, 8, 3, 1, 128)])       # utterances much shorter than a 64-row stage: several wraps per piece
+def test_bf16_storage_wgrad_k1_resident_kernel(Bn, T, C, k, s_, Co, monkeypatch):
+    """gemm16s_tn_kres_kernel (round 6: the whole K1 <= 224 extent in one workgroup's accumulators, windows read out of ONE LDS copy of
+    the frames through transpose reads with the input's row stride), forced on: the float64 product of the stored values, the bias
+    gradient, accumulate, run-to-run identical bits, and equal to round-off with the four-wave kernel's result"""
+    from lidbox_amd import _native as nv
+    rng = np.random.default_rng(Bn * 1000 + T)
+    pad = k - 1
+    x = np.zeros((Bn, pad + T, C))
+    x[:, pad:] = rng.standard_normal((Bn, T, C))
+    To = (T - 1) // s_ + 1
+    dy = rng.standard_normal((Bn, To, Co)) * (1.0 + 0.01 * np.arange(Co))[None, None, :]
+    idx = np.arange(To)[:, None] * s_ + np.arange(k)[None, :]
+    col = _bf16(x)[:, idx, :].reshape(Bn * To, k * C)
+    ref = col.T @ _bf16(dy).reshape(Bn * To, Co)
+    st = nv.current_stream()
+    x16, dy16 = _dev(x).bfloat16(), _dev(dy).bfloat16()
+    M, K1 = Bn * To, k * C
+    ra = nv.Rows(x16.data_ptr(), (pad + T) * C, s_ * C, Bn, To)
+    rb = nv.Rows(dy16.data_ptr(), To * Co, Co, Bn, To)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LIDBOX_GEMM16_TN_KRES", mode)
+        monkeypatch.setenv("LIDBOX_GEMM16_TN_PP", "0")
+        wsb = nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, Co)
+        ws = _ws(wsb)
+        dW = torch.full((K1, Co), -1.0, device="cuda")
+        db = torch.zeros(Co, device="cuda")
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws), wsb, st))
+        assert (nv.lib.lidbox_gemm_bf16s_tn_last_kres() > 0) == (mode == "1")
+        _close(dW.cpu().numpy(), ref)
+        _close(db.cpu().numpy(), _bf16(dy).reshape(M, Co).sum(axis=0), 1e-5)
+        dW2 = dW.clone()
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW2), Co, K1, Co, 1, None, nv.ptr(ws), wsb, st))
+        _close(dW2.cpu().numpy(), 2 * ref)
+        dW3 = torch.empty_like(dW)
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(ra, rb, nv.ptr(dW3), Co, K1, Co, 0, None, nv.ptr(ws), wsb, st))
+        assert torch.equal(dW, dW3)
+        out[mode] = dW.cpu().double().numpy()
+    _close(out["1"], out["0"], rel=1e-5)
+
+
+def test_bf16_storage_wgrad_k1_resident_policy_and_fallback(monkeypatch):
+    """the K1-resident wgrad runs by default on frame1's launch of configs[4]'s bf16 step (K1 = 200, N = 512, >= 64 k rows) and nowhere else;
+    operands it cannot flatten (batch stride not a whole number of row strides, N not in 128-column tiles, K1 > 224) fall back to the
+    four-wave kernel even when it is forced, with the same result"""
+    from lidbox_amd import _native as nv
+    monkeypatch.delenv("LIDBOX_GEMM16_TN_KRES", raising=False)
+    st = nv.current_stream()
+    rng = np.random.default_rng(5)
+
+    def run(Bn, T, C, k, s_, Co, extra_rows=0, want=None):
+        pad = k - 1
+        Tp = pad + T + extra_rows
+        x = np.zeros((Bn, Tp, C))
+        x[:, pad:pad + T] = rng.standard_normal((Bn, T, C))
+        To = (T - 1) // s_ + 1
+        dy = rng.standard_normal((Bn, To, Co))
+        idx = np.arange(To)[:, None] * s_ + np.arange(k)[None, :]
+        ref = _bf16(x)[:, idx, :].reshape(Bn * To, k * C).T @ _bf16(dy).reshape(Bn * To, Co)
+        x16, dy16 = _dev(x).bfloat16(), _dev(dy).bfloat16()
+        M, K1 = Bn * To, k * C
+        wsb = nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, Co)
+        ws = _ws(wsb)
+        dW = torch.empty((K1, Co), device="cuda")
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn(nv.Rows(x16.data_ptr(), Tp * C, s_ * C, Bn, To), nv.Rows(dy16.data_ptr(), To * Co, Co, Bn, To),
+                                             nv.ptr(dW), Co, K1, Co, 0, None, nv.ptr(ws), wsb, st))
+        _close(dW.cpu().numpy(), ref)
+        if want is not None:
+            assert (nv.lib.lidbox_gemm_bf16s_tn_last_kres() > 0) == want, (Bn, T, C, k, s_, Co)
+
+    run(352, 198, 40, 5, 1, 512, want=True)           # frame1 at 352 utterances: 69 696 rows
+    run(256, 198, 40, 5, 1, 512, want=False)          # 50 688 rows: below the policy's floor (measured slower inside the step)
+    run(352, 198, 48, 3, 1, 512, want=True)           # K1 = 144, row stride 48: one stage of frames is 3 168 elements (<= 4 096)
+    run(352, 198, 64, 3, 1, 512, want=False)          # K1 = 192, row stride 64: 4 224 elements do not fit one piece per thread
+    run(64, 99, 512, 3, 2, 512, want=False)           # frame2: K1 = 1536
+    monkeypatch.setenv("LIDBOX_GEMM16_TN_KRES", "1")
+    run(6, 50, 40, 5, 2, 128, extra_rows=1, want=False)      # 55 padded rows of 40, row stride 80: batch stride not a multiple
+    run(6, 50, 40, 5, 1, 136, want=False)                    # N = 136
+    run(6, 50, 48, 5, 1, 128, want=False)                    # K1 = 240
+    run(6, 50, 40, 5, 1, 128, want=True)
+
+
 def test_bf16_storage_wgrad_pingpong_policy_and_fallback(monkeypatch):
     """the ping-pong wgrad tile runs where it was measured faster (frame2's wgrad at 512 utterances: 12 tiles x 21 slices of 2 432
     rows) and nowhere else by default; operands it cannot walk with one utterance counter fall back even when it is forced"""
