@@ -38,6 +38,10 @@ constexpr int TKR_LDS_BYTES = 2 * TKR_STAGE_BYTES;                 // 106 496
 constexpr int TKR_MAX_K1 = 224;
 constexpr int TKR_PD = 4;                                          // stages of loads in flight (register sets); the step macro is unrolled by it
 
+#ifndef LBX_TKR_ABLATE
+#define LBX_TKR_ABLATE 0                                            // measurement builds only (wrong results): 1 no compute, 2 no loads, 4 no slab stores,
+#endif                                                              // 8 no operand fetches after a stage's first substep
+
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_tkr;
 typedef unsigned u32x4_tkr __attribute__((ext_vector_type(4)));
 
@@ -197,7 +201,11 @@ __global__ __launch_bounds__(512) void gemm16s_tn_kres_kernel(RowsH A, RowsH Bd,
 #pragma unroll
         for (int ks = 0; ks < TKR_ROWS / 16; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < TKR_ROWS / 16) {
+            if (LBX_TKR_ABLATE & 8) {                               // operands of the first substep for all four: the MFMA chain alone
+                b[nxt] = b[cur];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) a[nxt][i] = a[cur][i];
+            } else if (ks + 1 < TKR_ROWS / 16) {
                 b[nxt] = tkr_tr8(Bs + boff + (ks + 1) * 16 * TKR_LDB, TKR_LDB);
 #pragma unroll
                 for (int i = 0; i < NB; ++i) a[nxt][i] = tkr_tr8(reinterpret_cast<const __bf16*>(Im + aoffb[i] + (ks + 1) * 16 * S), S / 2);
@@ -207,9 +215,6 @@ __global__ __launch_bounds__(512) void gemm16s_tn_kres_kernel(RowsH A, RowsH Bd,
         }
         __builtin_amdgcn_s_setprio(0);
     };
-#ifndef LBX_TKR_ABLATE
-#define LBX_TKR_ABLATE 0                                            // measurement builds only (wrong results): 1 no compute, 2 no loads, 4 no slab stores
-#endif
     auto compute = [&](int buf) {
         if (LBX_TKR_ABLATE & 1) return;
         switch (nb) {                                               // wave-uniform (scalar) dispatch, once per stage
