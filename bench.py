@@ -408,6 +408,17 @@ def cpu_baseline(seconds, batch=PER_GPU_BATCH, config="xvector", num_langs=NUM_L
                        "cores (best of a 8/16/32/64-thread sweep)" % (n, batch, what, dt, best_threads, ncpu))
 
 
+def scaling_run_problem(gpus, nranks, backend, sync_active, grad_sync_mode, no_graph):
+    """A scaling line must measure the path DESIGN section 5 describes -- one rank per GPU over nccl (= RCCL), the gradient all-reduces
+    captured inside the step's graph -- or fail: a silent fallback (segmented / eager exchange, a communicator with fewer ranks, gloo)
+    would be reported as this build's scaling.  Returns the message to exit with, or None when the run is what it claims to be."""
+    want = "eager" if no_graph else "in_graph"
+    if nranks == gpus and backend == "nccl" and sync_active and grad_sync_mode == want:
+        return None
+    return ("bench.py --gpus %d: ranks %d, backend %s, gradient exchange active %s in mode %r (expected %d ranks over nccl (= RCCL) with the "
+            "exchange %s)" % (gpus, nranks, backend, sync_active, grad_sync_mode, gpus, want))
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` without WORLD_SIZE: run the same command as N ranks of one node through
     torch.distributed.run on 127.0.0.1 (a free port), pass its stdout (rank 0's one JSON line) through."""
@@ -767,16 +778,9 @@ def main():
     if not np.isfinite(final_loss):
         raise SystemExit("non-finite loss %r" % final_loss)
     if world > 1:
-        # a scaling line must measure the path DESIGN section 5 describes -- RCCL all-reduces captured inside the step's graph, one
-        # rank per GPU -- or fail: a silent fallback (segmented / eager exchange, a communicator with fewer ranks) would be
-        # reported as this build's scaling
-        nranks = dist.get_world_size()
-        backend = dist.get_backend()
-        mode = trainer.grad_sync_mode
-        want = "eager" if args.no_graph else "in_graph"
-        if nranks != args.gpus or backend != "nccl" or not trainer.sync.active or mode != want:
-            raise SystemExit("bench.py --gpus %d: ranks %d, backend %s, gradient exchange active %s in mode %r (expected %d ranks over "
-                             "nccl (= RCCL) with the exchange %s)" % (args.gpus, nranks, backend, trainer.sync.active, mode, args.gpus, want))
+        problem = scaling_run_problem(args.gpus, dist.get_world_size(), dist.get_backend(), trainer.sync.active, trainer.grad_sync_mode, args.no_graph)
+        if problem:
+            raise SystemExit(problem)
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = global_B * args.steps / elapsed

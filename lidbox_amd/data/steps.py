@@ -102,8 +102,8 @@ def extract_features(ds, config):
         signals = torch.stack(sigs).to(device)
         rates = [int(x["sample_rate"]) for x in batch]
         feats = tf_utils.extract_features(signals, rates, *args)
-        for i, x in enumerate(batch):                                                # unbatch (:736)
-            yield dict(x, input=feats[i], feature_type=feature_type)
+        for x, f in zip(batch, feats.unbind(0)):                                     # unbatch (:736): one call for all the views
+            yield dict(x, input=f, feature_type=feature_type)
 
 
 # ------------------------------------------------------------------ signal steps

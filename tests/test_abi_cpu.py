@@ -349,6 +349,25 @@ def test_data_parallel_at_baseline_world_size_eight_gloo_ranks(tmp_path, nv):
         assert "ok" in out
 
 
+def test_bench_refuses_a_scaling_run_that_is_not_what_it_claims():
+    """bench.py --gpus N prints a line only for N ranks over nccl with the gradient exchange captured in the step's graph (host logic:
+    the condition is a function of what the run reports about itself)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ok = bench.scaling_run_problem
+    assert ok(8, 8, "nccl", True, "in_graph", False) is None
+    assert ok(2, 2, "nccl", True, "eager", True) is None                      # --no-graph: the eager exchange is what was asked for
+    for bad in ((8, 4, "nccl", True, "in_graph", False),                       # a communicator with fewer ranks
+                (8, 8, "gloo", True, "in_graph", False),                       # not RCCL
+                (8, 8, "nccl", False, "none", False),                          # no exchange at all
+                (8, 8, "nccl", True, "segmented", False),                      # host-launched between graph segments
+                (8, 8, "nccl", True, "eager", False)):
+        msg = ok(*bad)
+        assert msg and "--gpus 8" in msg and "expected 8 ranks" in msg
+
+
 def test_bucket_plan_is_contiguous_partition():
     """plan_buckets needs no device: use a layout-only stand-in with the x-vector's shapes"""
     from lidbox_amd.train import plan_buckets
