@@ -94,6 +94,7 @@ extern "C" int lidbox_mel_weight_matrix(int M, int F, int sample_rate, float lo_
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
+constexpr int BLUESTEIN_MAX_M2 = 16384;     // complex points of one 128 KB LDS buffer
 struct lidbox_feat_plan {
     int sample_rate, L, S, nfft, F, M, coef_begin, coef_end, ncoef, nnz;
     float power;
@@ -116,7 +117,7 @@ struct lidbox_feat_plan {
     bool    seg_ok;          // the bands split into <= 64 segments of <= 32 bins
     float*  d_dct;           // [M][ncoef]
     // Bluestein (chirp-z) path for fft_length that is not a power of two (bs_m2 == 0: not available, direct DFT)
-    int     bs_m2;           // convolution length: the power of two >= 2 nfft - 1 (<= 8192)
+    int     bs_m2;           // convolution length: the power of two >= min(L, nfft) + F - 1 (<= BLUESTEIN_MAX_M2)
     float2* d_bs_chirp;      // [nfft]  w_n = e^{-i pi n^2 / nfft}
     float2* d_bs_bhat;       // [bs_m2] FFT of the wrapped conjugate chirp, scaled by 1 / bs_m2
     float2* d_bs_tw;         // [bs_m2] e^{-2 pi i j / bs_m2}
@@ -222,21 +223,24 @@ extern "C" int lidbox_feat_plan_create(int sample_rate, int L, int S, int nfft, 
         const double a = -2.0 * M_PI * (double)j / (double)nfft;
         twN[j] = make_float2((float)cos(a), (float)sin(a));
     }
-    // Bluestein tables (fft_length not a power of two, 2 nfft - 1 <= 8192): X_k = w_k sum_n (x_n w_n) conj(w)_{k-n}, w_n = e^{-i pi n^2 / N}
-    // -- a circular convolution of length m2 >= 2 N - 1 done with power-of-two FFTs.  n^2 is reduced mod 2 N in integers (exact phase).
+    // Bluestein tables (fft_length not a power of two): X_k = w_k sum_n (x_n w_n) conj(w)_{k-n}, w_n = e^{-i pi n^2 / N} -- a circular
+    // convolution done with power-of-two FFTs.  Only the bins k < F = N / 2 + 1 of a frame that is zero from Leff on are wanted, so the
+    // chirp is needed at k - n in (-Leff, F) and the convolution length is the power of two >= Leff + F - 1 (not 2 N - 1): 16 384 points
+    // (the largest one LDS buffer holds) cover every fft_length <= 10 922 whatever the frame, and all of them up to the plan's 16 384
+    // for frames of <= 8 192 samples.  n^2 is reduced mod 2 N in integers (exact phase).
     int m2 = 0;
     std::vector<float2> bs_chirp(1), bs_bhat(1), bs_tw(1);
-    if (nfft >= 3 && (nfft & (nfft - 1)) != 0 && 2 * nfft - 1 <= 8192) {
+    if (nfft >= 3 && (nfft & (nfft - 1)) != 0 && Leff + p->F - 1 <= BLUESTEIN_MAX_M2) {
         m2 = 1;
-        while (m2 < 2 * nfft - 1) m2 <<= 1;
+        while (m2 < Leff + p->F - 1) m2 <<= 1;
         bs_chirp.resize(nfft);
         std::vector<double> br(m2, 0.0), bi(m2, 0.0);
         for (int n = 0; n < nfft; ++n) {
             const long q = ((long)n * n) % (2L * nfft);
             const double a = M_PI * (double)q / (double)nfft;
             bs_chirp[n] = make_float2((float)cos(a), (float)-sin(a));
-            br[n] = cos(a); bi[n] = sin(a);                       // conj(w_n)
-            if (n > 0) { br[m2 - n] = cos(a); bi[m2 - n] = sin(a); }
+            if (n < p->F) { br[n] = cos(a); bi[n] = sin(a); }                       // conj(w_n) at k - n = n >= 0 ...
+            if (n > 0 && n < Leff) { br[m2 - n] = cos(a); bi[m2 - n] = sin(a); }    // ... and at k - n = -n (the chirp is even)
         }
         // iterative radix-2 FFT of b in float64 on the host (once per plan)
         for (int i = 1, j = 0; i < m2; ++i) {
@@ -1333,8 +1337,8 @@ __global__ __launch_bounds__(256) void pow2_fft_spectrogram_kernel(
 // workgroup per frame: a_n = x_n win_n w_n (zero beyond the frame), A = FFT_m2(a), C = A . Bhat (the plan's transform of the wrapped
 // conjugate chirp, 1 / m2 folded in), c = IFFT_m2(C) as conj(FFT(conj(C))), X_k = c_k w_k for k <= nfft / 2, then |.|^power.  Both
 // transforms are the radix-2 Stockham passes of pow2_fft_spectrogram_kernel over m2 complex points; LDS = 2 m2 x 8 bytes (128 KB at
-// the largest m2 = 8192, i.e. fft_length <= 4096).  O(m2 log m2) per frame against the direct DFT's O(N^2 / 2): 64 x 1 s at
-// fft_length 2000 runs ~20 x faster (tests/test_features_gpu.py).
+// m2 = 8192; m2 = 16 384 runs bluestein_inplace_spectrogram_kernel below).  O(m2 log m2) per frame against the direct DFT's
+// O(N^2 / 2): 64 x 1 s at fft_length 2000 runs ~20 x faster (tests/test_features_gpu.py).
 __device__ __forceinline__ float2* stockham_fft(float2* in, float2* outb, int n, const float2* __restrict__ tw, int tid) {
     const int half = n >> 1;
     for (int Ns = 1; Ns < n; Ns <<= 1) {
@@ -1385,6 +1389,69 @@ __global__ __launch_bounds__(256) void bluestein_spectrogram_kernel(
     float* dst = out + ((long)b * T + t) * F;
     for (int k = tid; k < F; k += 256) {
         const float2 y = make_float2(c[k].x, -c[k].y), w = chirp[k];
+        const float xr = y.x * w.x - y.y * w.y, xi = y.x * w.y + y.y * w.x;
+        const float p2 = xr * xr + xi * xi;
+        dst[k] = (power == 2.0f) ? p2 : powf(p2, 0.5f * power);
+    }
+}
+
+// The same transform for m2 = 16 384 (round 6: fft_length up to 10 922 at any frame length, up to 16 384 for frames <= 8 192 samples):
+// ONE LDS buffer of m2 complex values (128 KB), so both FFTs run in place -- the forward one as decimation in frequency (natural order
+// in, bit-reversed out), the product reads Bhat through the bit-reversed index, the inverse one as decimation in time (bit-reversed
+// in, natural out): no reordering pass, no second buffer.  1 024 threads (one workgroup per CU at this LDS size).  Any power of two
+// m2 >= 2 works (LIDBOX_FEAT_BLUESTEIN_INPLACE=1 runs it at every size: the tests compare the two kernels on the same plans).
+__global__ __launch_bounds__(1024) void bluestein_inplace_spectrogram_kernel(
+    const float* __restrict__ signals, long sig_stride, int T, int L, int S, int nfft, int F, int m2,
+    const float* __restrict__ win, const float2* __restrict__ chirp, const float2* __restrict__ bhat, const float2* __restrict__ tw,
+    float power, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* x = reinterpret_cast<float2*>(smem);
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int Leff = L < nfft ? L : nfft;
+    const int lg = 31 - __clz(m2), nb = m2 >> 1;
+    const float* src = signals + (long)b * sig_stride + (long)t * S;
+    for (int n = tid; n < m2; n += 1024) {
+        float2 v = make_float2(0.f, 0.f);
+        if (n < Leff) {
+            const float xs = src[n] * win[n];
+            const float2 w = chirp[n];
+            v = make_float2(xs * w.x, xs * w.y);
+        }
+        x[n] = v;
+    }
+    __syncthreads();
+    for (int len = m2; len >= 2; len >>= 1) {                // A = FFT(a), decimation in frequency
+        const int half = len >> 1, tw_step = m2 / len;       // e^{-2 pi i k / len} = tw[k * m2 / len]
+        for (int j = tid; j < nb; j += 1024) {
+            const int k = j & (half - 1);
+            const int i0 = ((j - k) << 1) + k;
+            const float2 u = x[i0], v = x[i0 + half], w = tw[k * tw_step];
+            const float2 d = make_float2(u.x - v.x, u.y - v.y);
+            x[i0] = make_float2(u.x + v.x, u.y + v.y);
+            x[i0 + half] = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < m2; i += 1024) {                   // conj(A . Bhat), both at bit-reversed position i
+        const float2 a = x[i], h = bhat[__brev((unsigned)i) >> (32 - lg)];
+        x[i] = make_float2(a.x * h.x - a.y * h.y, -(a.x * h.y + a.y * h.x));
+    }
+    __syncthreads();
+    for (int len = 2; len <= m2; len <<= 1) {                // FFT of it, decimation in time: natural order out
+        const int half = len >> 1, tw_step = m2 / len;
+        for (int j = tid; j < nb; j += 1024) {
+            const int k = j & (half - 1);
+            const int i0 = ((j - k) << 1) + k;
+            const float2 u = x[i0], v = x[i0 + half], w = tw[k * tw_step];
+            const float2 vw = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            x[i0] = make_float2(u.x + vw.x, u.y + vw.y);
+            x[i0 + half] = make_float2(u.x - vw.x, u.y - vw.y);
+        }
+        __syncthreads();
+    }
+    float* dst = out + ((long)b * T + t) * F;
+    for (int k = tid; k < F; k += 1024) {
+        const float2 y = make_float2(x[k].x, -x[k].y), w = chirp[k];
         const float xr = y.x * w.x - y.y * w.y, xi = y.x * w.y + y.y * w.x;
         const float p2 = xr * xr + xi * xi;
         dst[k] = (power == 2.0f) ? p2 : powf(p2, 0.5f * power);
@@ -1661,7 +1728,7 @@ extern "C" int lidbox_extract_features_fwd_ex(const lidbox_feat_plan* p, int kin
     float* spec = (kind == LIDBOX_FEAT_SPECTROGRAM) ? out : (float*)workspace;
     const int Leff = p->L < p->nfft ? p->L : p->nfft;
     const bool pow2 = p->nfft >= 4 && (p->nfft & (p->nfft - 1)) == 0;
-    static const bool force_dft = getenv("LIDBOX_FEAT_FORCE_DFT") != nullptr;          // A/B and test aid
+    const bool force_dft = getenv("LIDBOX_FEAT_FORCE_DFT") != nullptr;                 // A/B and test aid (read per call)
     if (pow2 && !force_dft) {
         // LDS: two buffers of nfft / 2 complex values (<= 128 KB at the largest fft_length a plan accepts)
         const size_t lds = (size_t)p->nfft * 8;
@@ -1670,12 +1737,19 @@ extern "C" int lidbox_extract_features_fwd_ex(const lidbox_feat_plan* p, int kin
         hipLaunchKernelGGL(pow2_fft_spectrogram_kernel, dim3(T, B), dim3(256), lds, st,
                            signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN, p->power, spec);
     } else if (p->bs_m2 && !force_dft) {
-        // any other length up to 4096: Bluestein on two power-of-two transforms of bs_m2 points
-        const size_t lds = (size_t)p->bs_m2 * 16;
-        if (lds > 65536)
-            LBX_HIP(hipFuncSetAttribute((const void*)bluestein_spectrogram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(bluestein_spectrogram_kernel, dim3(T, B), dim3(256), lds, st, signals, sig_stride, T, p->L, p->S, p->nfft, p->F,
-                           p->bs_m2, p->d_win, p->d_bs_chirp, p->d_bs_bhat, p->d_bs_tw, p->power, spec);
+        // any other length: Bluestein on two power-of-two transforms of bs_m2 points -- between two LDS buffers up to 8192 points,
+        // in place in one buffer at 16 384
+        const char* e = getenv("LIDBOX_FEAT_BLUESTEIN_INPLACE");
+        const bool inplace = p->bs_m2 > 8192 || (e && atoi(e) != 0);
+        const size_t lds = (size_t)p->bs_m2 * (inplace ? 8 : 16);
+        const void* fn = inplace ? (const void*)bluestein_inplace_spectrogram_kernel : (const void*)bluestein_spectrogram_kernel;
+        if (lds > 65536) LBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (inplace)
+            hipLaunchKernelGGL(bluestein_inplace_spectrogram_kernel, dim3(T, B), dim3(1024), lds, st, signals, sig_stride, T, p->L, p->S,
+                               p->nfft, p->F, p->bs_m2, p->d_win, p->d_bs_chirp, p->d_bs_bhat, p->d_bs_tw, p->power, spec);
+        else
+            hipLaunchKernelGGL(bluestein_spectrogram_kernel, dim3(T, B), dim3(256), lds, st, signals, sig_stride, T, p->L, p->S, p->nfft,
+                               p->F, p->bs_m2, p->d_win, p->d_bs_chirp, p->d_bs_bhat, p->d_bs_tw, p->power, spec);
     } else {
         hipLaunchKernelGGL(generic_spectrogram_kernel, dim3(T, B), dim3(256), (size_t)Leff * 4, st,
                            signals, sig_stride, T, p->L, p->S, p->nfft, p->F, p->d_win, p->d_twN,

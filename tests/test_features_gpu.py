@@ -127,10 +127,12 @@ def test_generic_path_other_fft_lengths(wav_paths):
     assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
-def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths):
-    """fft_length != 512: powers of two run the LDS radix-2 FFT kernel (O(N log N)), other lengths up to 4096 Bluestein's chirp-z
-    transform on two power-of-two FFTs (tf.signal.stft takes any fft_length, reference audio.py:229), longer ones the direct DFT;
-    all against the oracle, the largest accepted length (16384) included, plus log-mel / MFCC on top of the FFT kernels"""
+def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths, monkeypatch):
+    """fft_length != 512: powers of two run the LDS radix-2 FFT kernel (O(N log N)), other lengths Bluestein's chirp-z transform on two
+    power-of-two FFTs of >= min(frame, fft_length) + fft_length / 2 points (tf.signal.stft takes any fft_length, reference audio.py:229)
+    -- between two LDS buffers up to 8192 points (4095 / 250 ms, 5000 / 300 ms, 12000 / 25 ms), in place in one buffer at 16 384
+    (6000 / 400 ms, 10000 / 700 ms) -- and what needs more (12000 / 800 ms) the direct DFT; all against the oracle, the largest accepted
+    length (16384) included, plus log-mel / MFCC on top of the FFT kernels"""
     import time
     from lidbox_amd.features import audio
     from lidbox_amd.data import tf_utils
@@ -138,11 +140,20 @@ def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths):
     x = _dev(np.stack([s[:16000], s[4000:20000], s[8000:24000]]))
     ref_in = np.stack([s[:16000], s[4000:20000], s[8000:24000]])
     for n_fft, len_ms in ((128, 5), (1024, 25), (4096, 100), (16384, 500), (600, 25), (1000, 60), (400, 25), (401, 25), (1009, 50), (2000, 100),
-                          (4095, 250), (3, 1), (6000, 300)):
+                          (4095, 250), (3, 1), (6000, 300), (5000, 300), (12000, 25), (6000, 400), (10000, 700), (12000, 800)):
         got = audio.spectrograms(x, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft).cpu().numpy()
         ref = fo.spectrograms(ref_in, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft)
         assert got.shape == ref.shape and got.shape[2] == n_fft // 2 + 1
         assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), n_fft
+    # the in-place kernel on plans the two-buffer kernel serves: same oracle, same bound, and the two kernels agree closely
+    for n_fft, len_ms in ((600, 25), (1009, 50), (2000, 100), (3, 1), (4095, 250)):
+        two = audio.spectrograms(x, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft).cpu().numpy()
+        monkeypatch.setenv("LIDBOX_FEAT_BLUESTEIN_INPLACE", "1")
+        one = audio.spectrograms(x, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft).cpu().numpy()
+        monkeypatch.delenv("LIDBOX_FEAT_BLUESTEIN_INPLACE")
+        ref = fo.spectrograms(ref_in, r, frame_length_ms=len_ms, frame_step_ms=10, fft_length=n_fft)
+        assert np.abs(one - ref).max() <= 2e-5 * np.abs(ref).max(), n_fft
+        assert np.abs(one - two).max() <= 2e-5 * np.abs(ref).max(), n_fft
     got = tf_utils.extract_features(x, [r] * 3, "logmelspectrogram", spec_kwargs=dict(fft_length=1024)).cpu().numpy()
     ref = fo.extract_features(ref_in, [r] * 3, "logmelspectrogram", spec_kwargs=dict(fft_length=1024))
     assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-3
@@ -153,18 +164,24 @@ def test_generic_path_pow2_fft_vs_oracle_and_direct_dft(wav_paths):
     ref = fo.extract_features(ref_in, [r] * 3, "logmelspectrogram", spec_kwargs=dict(fft_length=400))
     assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-3
     # the FFT kernels are not a slower way to the same numbers: 64 x 1 s at fft_length 2048 (radix-2), 2000 (Bluestein, two 4096-point
-    # transforms) and 4500 (past Bluestein's range: the direct DFT)
+    # transforms), 2000 on the direct DFT (LIDBOX_FEAT_FORCE_DFT), and 6000 with 400-ms frames (in place, 16 384 points) against ITS direct DFT
     big = torch.randn(64, 16000, device="cuda") * 0.1
     times = {}
-    for n_fft in (2048, 2000, 4500):
-        audio.spectrograms(big, 16000, frame_length_ms=100, fft_length=n_fft)
+    for key, n_fft, len_ms, dft in (("pow2", 2048, 100, False), ("bs", 2000, 100, False), ("dft", 2000, 100, True),
+                                    ("bs16k", 6000, 400, False), ("dft6000", 6000, 400, True)):
+        if dft:
+            monkeypatch.setenv("LIDBOX_FEAT_FORCE_DFT", "1")
+        audio.spectrograms(big, 16000, frame_length_ms=len_ms, fft_length=n_fft)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
-            audio.spectrograms(big, 16000, frame_length_ms=100, fft_length=n_fft)
+            audio.spectrograms(big, 16000, frame_length_ms=len_ms, fft_length=n_fft)
         torch.cuda.synchronize()
-        times[n_fft] = (time.perf_counter() - t0) / 3
-    assert times[2048] < times[2000] < 0.25 * times[4500], times
+        times[key] = (time.perf_counter() - t0) / 3
+        if dft:
+            monkeypatch.delenv("LIDBOX_FEAT_FORCE_DFT")
+    assert times["pow2"] < times["bs"] < 0.25 * times["dft"], times
+    assert times["bs16k"] < 0.25 * times["dft6000"], times
 
 
 def test_linear_to_mel_standalone(wav_paths):
