@@ -751,23 +751,25 @@ __global__ __launch_bounds__(256) void ap_head_kernel(const float* __restrict__ 
     }
 }
 
-// C_avg counters (reference metrics.py:51-71).  grid (N scored classes m, ceil(Th / 64)); 256 threads = 4 waves x 64 thresholds.
-// LDS pos[wave][l][th] counts the examples with label l whose score for class m is >= threshold: every wave takes every
-// fourth block of 64 examples, loads their scores and labels with ONE load per lane and walks them through v_readlane
-// (no memory round trip inside the walk -- round 4's kernel made one dependent load per example: 512 round trips, 203 us at
-// 512 x 100 x 100), counting with ds_add_u32 into its own copy (lane = threshold = column: conflict-free, no ordering
-// question: every addend is 1.0f and integer counters: exact in any order).  The workgroup is
-// the only writer of cells [*, m, th-tile]: no global atomics, exact results.
-constexpr int CAVG_WAVES = 4, CAVG_BATCH = 25;
-__global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restrict__ scores,
-                                                          const int32_t* __restrict__ labels, int B, int N,
-                                                          const float* __restrict__ thresholds, int Th,
-                                                          int lch, float* __restrict__ tp,
-                                                          float* __restrict__ fn, float* __restrict__ fp,
-                                                          float* __restrict__ tn) {
-    extern __shared__ unsigned s_cnt[];       // pos[CAVG_WAVES][lch][64] then cnt[lch]: integer counters (ds_add_u32)
+// C_avg counters (reference metrics.py:51-71).  grid (N scored classes m, ceil(Th / 64), label chunks); 1 024 threads = 16 waves x 64
+// thresholds.  LDS pos[l][th] counts the examples with label l whose score for class m is >= threshold.  The batch is cut into units of
+// 16 ... 64 examples; wave w takes units w, w + 16, ...: it loads a unit's scores and labels with ONE load per lane and walks them through
+// v_readlane (no memory round trip inside the walk -- round 4's kernel made one dependent load per example: 203 us at 512 x 100 x 100),
+// counting with ds_add_u32 (lane = threshold = column: conflict-free inside a wave; integer counters: exact in any order, so all waves
+// share ONE copy).  An iteration of the walk is a chain of ~11 dependent scalar / vector instructions, ~90 cycles for a wave that is
+// alone on its SIMD: round 5's four waves with 128 iterations each spent 5.5 us of the kernel's 13 there at 512 examples; sixteen waves
+// with 32 iterations each overlap four chains per SIMD (round 6).  The workgroup is the only writer of cells [chunk, m, th-tile]: no
+// global atomics, exact results.
+constexpr int CAVG_WAVES = 16, CAVG_BATCH = 8, CAVG_LCH = CAVG_WAVES * CAVG_BATCH;        // 128 labels per chunk
+__global__ __launch_bounds__(1024) void cavg_update_kernel(const float* __restrict__ scores,
+                                                           const int32_t* __restrict__ labels, int B, int N,
+                                                           const float* __restrict__ thresholds, int Th,
+                                                           int lch, int unit, float* __restrict__ tp,
+                                                           float* __restrict__ fn, float* __restrict__ fp,
+                                                           float* __restrict__ tn) {
+    extern __shared__ unsigned s_cnt[];       // pos[lch][64] then cnt[lch]: integer counters (ds_add_u32)
     unsigned* pos = s_cnt;
-    unsigned* cnt = s_cnt + CAVG_WAVES * lch * 64;
+    unsigned* cnt = s_cnt + lch * 64;
     const int m = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int th = blockIdx.y * 64 + lane;
@@ -779,9 +781,9 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
         pa = (diag ? tp : fp) + cell;                                          // metrics.py:63-66 / :68-71
         pb = (diag ? fn : tn) + cell;
     };
-    for (int l0 = 0; l0 < N; l0 += lch) {
+    for (int l0 = blockIdx.z * lch; l0 < N; l0 += gridDim.z * lch) {          // label chunks: across grid.z first, then in turn
         const int nl = min(lch, N - l0);
-        // the counters this thread will update (its wave's labels wv, wv + 4, ...): every load goes out NOW, ahead of the LDS
+        // the counters this thread will update (its wave's labels wv, wv + 16, ...): every load goes out NOW, ahead of the LDS
         // clear and the walk -- the write-out at the end then adds and stores without a round trip to HBM of its own
         float va[CAVG_BATCH], vb[CAVG_BATCH];
 #pragma unroll
@@ -795,27 +797,29 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
                 vb[u] = *pb;
             }
         }
-        // first block of examples of this wave: its scores / labels are in flight during the clear as well
-        int b0 = wv * 64;
-        float sv = b0 + lane < B ? scores[(long)(b0 + lane) * N + m] : 0.f;
-        int yv = b0 + lane < B ? labels[b0 + lane] - l0 : -1;
+        // first unit of this wave: its scores / labels are in flight during the clear as well
+        int b0 = wv * unit;
+        bool in = lane < unit && b0 + lane < B;
+        float sv = in ? scores[(long)(b0 + lane) * N + m] : 0.f;
+        int yv = in ? labels[b0 + lane] - l0 : -1;
         {
             uint4* z = reinterpret_cast<uint4*>(pos);
-            for (int i = threadIdx.x; i < CAVG_WAVES * lch * 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (int l = threadIdx.x; l < nl; l += 256) cnt[l] = 0u;
+            for (int i = threadIdx.x; i < lch * 16; i += 1024) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int l = threadIdx.x; l < nl; l += 1024) cnt[l] = 0u;
         }
         __syncthreads();
-        unsigned* mine = pos + wv * lch * 64 + lane;
-        for (; b0 < B; b0 += CAVG_WAVES * 64) {
-            const int b1 = b0 + CAVG_WAVES * 64;                      // the wave's next block: loaded before this one is walked
-            const float sv1 = b1 + lane < B ? scores[(long)(b1 + lane) * N + m] : 0.f;
-            const int yv1 = b1 + lane < B ? labels[b1 + lane] - l0 : -1;
+        unsigned* mine = pos + lane;
+        for (; b0 < B; b0 += CAVG_WAVES * unit) {
+            const int b1 = b0 + CAVG_WAVES * unit;                     // the wave's next unit: loaded before this one is walked
+            in = lane < unit && b1 + lane < B;
+            const float sv1 = in ? scores[(long)(b1 + lane) * N + m] : 0.f;
+            const int yv1 = in ? labels[b1 + lane] - l0 : -1;
             if (yv < 0 || yv >= nl) yv = -1;
             if (yv >= 0) atomicAdd(&cnt[yv], 1u);                     // examples per label (all thresholds share it)
             // branch-free walk: an example that does not count (label outside the chunk, score below the threshold, lane past the
             // batch: yv = -1) adds 0 to row 0 -- with branches an iteration cost ~145 cycles of exec-mask and scalar-branch traffic
 #pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
+            for (int j = 0; j < unit; ++j) {
                 const int y = __builtin_amdgcn_readlane(yv, j);       // wave-uniform
                 const float sj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), j));
                 const unsigned one = (y >= 0 && sj >= thr) ? 1u : 0u;  // metrics.py:60
@@ -833,9 +837,7 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
             for (int u = 0; u < CAVG_BATCH; ++u) {
                 const int l = wv + u * CAVG_WAVES;
                 if (l < nl) {
-                    unsigned pu = 0u;
-#pragma unroll
-                    for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
+                    const unsigned pu = pos[l * 64 + lane];
                     va[u] += (float)pu;
                     vb[u] += (float)(cnt[l] - pu);                                     // s < thr  (:61)
                 }
@@ -849,15 +851,6 @@ __global__ __launch_bounds__(256) void cavg_update_kernel(const float* __restric
                     *pa = va[u];
                     *pb = vb[u];
                 }
-            }
-            for (int l = wv + CAVG_BATCH * CAVG_WAVES; l < nl; l += CAVG_WAVES) {       // label chunks past 100: one by one
-                unsigned pu = 0u;
-#pragma unroll
-                for (int w = 0; w < CAVG_WAVES; ++w) pu += pos[(w * lch + l) * 64 + lane];
-                float *pa, *pb;
-                cells(l0 + l, pa, pb);
-                *pa += (float)pu;
-                *pb += (float)(cnt[l] - pu);
             }
         }
         __syncthreads();
@@ -1314,19 +1307,24 @@ extern "C" int lidbox_cavg_update(const float* scores, const int32_t* labels, in
     LBX_ARG(scores && labels && thresholds && tp && fn && fp_pairs && tn_pairs, "pointers != NULL");
     LBX_ARG(N >= 2 && Th >= 1, "N >= 2 (metrics.py:20), Th >= 1");
     if (B == 0) return LIDBOX_OK;
-    const int lch = N < 128 ? N : 128;                       // label chunk held in LDS: four 64-column copies (128 labels: 129 KB)
-    const size_t lds = ((size_t)CAVG_WAVES * lch * 64 + lch) * sizeof(float);
-    if (lds > 65536) {
-        static std::atomic<unsigned long long> attr_devs{0};
-        int dev = 0;
-        LBX_HIP(hipGetDevice(&dev));
-        if (dev >= 64 || !(attr_devs.load() >> dev & 1ull)) {
-            LBX_HIP(hipFuncSetAttribute((const void*)cavg_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            if (dev < 64) attr_devs.fetch_or(1ull << dev);
-        }
-    }
-    hipLaunchKernelGGL(cavg_update_kernel, dim3(N, (unsigned)lbx_cdiv(Th, 64)), dim3(256), lds,
-                       (hipStream_t)stream, scores, labels, B, N, thresholds, Th, lch, tp, fn, fp_pairs,
+    // label chunk held in LDS (128 labels: 32.5 KB).  A chunk per workgroup along grid.z while the grid stays within one workgroup
+    // of 16 waves per CU; every workgroup still walks the whole batch (examples outside its chunk add 0).  tools/cavg_time.py, 512
+    // examples x 100 thresholds: 50 classes 13.1 (round 5) -> 7.2 (one chunk) -> 6.8 us (two); 100 classes 18.9 -> 10.5 (one) / 11.8 (two)
+    const int thb = (int)lbx_cdiv(Th, 64);
+    int nz = (int)(256 / ((long)N * thb));
+    if (const char* e = getenv("LIDBOX_CAVG_NZ")) { const int v = atoi(e); if (v >= 1) nz = v; }      // tuning aid
+    int lch = (int)lbx_cdiv(N, nz < 1 ? 1 : nz);
+    lch = (lch + CAVG_WAVES - 1) / CAVG_WAVES * CAVG_WAVES;
+    if (lch > CAVG_LCH) lch = CAVG_LCH;
+    nz = (int)lbx_cdiv(N, lch);
+    if (nz > 64) nz = 64;
+    // examples per unit of the walk: 16 waves x unit covers the batch in one pass up to 1 024 examples
+    int unit = 16;
+    while (unit < 64 && (long)CAVG_WAVES * unit < B) unit <<= 1;
+    if (const char* e = getenv("LIDBOX_CAVG_UNIT")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) unit = v; }
+    const size_t lds = ((size_t)lch * 64 + lch) * sizeof(unsigned);
+    hipLaunchKernelGGL(cavg_update_kernel, dim3(N, (unsigned)thb, (unsigned)nz), dim3(1024), lds,
+                       (hipStream_t)stream, scores, labels, B, N, thresholds, Th, lch, unit, tp, fn, fp_pairs,
                        tn_pairs);
     LBX_LAUNCH_OK();
     return LIDBOX_OK;

@@ -684,7 +684,7 @@ def test_refresh_bf16_weights_one_launch():
     row-padded, and blocks side by side in one destination"""
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(5)
-    shapes = [(200, 512), (1536, 512), (37, 5), (512, 1500)]
+    shapes = [(200, 512), (1536, 512), (37, 5), (512, 1500), (132, 68)]       # the last: vector path with partial 64 x 64 tiles
     offs, off = [], 3 * 4                                       # matrices start on 4-float boundaries inside the flat vector
     for r, c in shapes:
         offs.append(off)
@@ -699,10 +699,16 @@ def test_refresh_bf16_weights_one_launch():
     items.append((offs[3], 512, 1500, padded.data_ptr(), 1504, 0))
     items.append((offs[0], 200, 512, stacked.data_ptr() + 2 * 512, 1024, 0))
     items.append((offs[0], 200, 512, stacked.data_ptr(), 1024, 0))
+    odd = torch.zeros((6, 7), dtype=torch.bfloat16, device="cuda")                      # source off the 4-float grid, odd row pitch
+    items.append((offs[2] + 1, 6, 5, odd.data_ptr(), 7, 0))
+    odd_t = torch.zeros((68, 134), dtype=torch.bfloat16, device="cuda")                 # transposed at a row pitch that is no multiple of 4
+    items.append((offs[4], 132, 68, odd_t.data_ptr(), 134, 1))
     mats = (nv.WeightShadow * len(items))(*[nv.WeightShadow(*it) for it in items])
     st = nv.current_stream()
     nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, mats, len(items), st))
     assert torch.equal(flat16, flat.bfloat16())
+    assert torch.equal(odd[:, :5], flat[offs[2] + 1:offs[2] + 31].reshape(6, 5).bfloat16()) and not odd[:, 5:].any()
+    assert torch.equal(odd_t[:, :132], flat[offs[4]:offs[4] + 132 * 68].reshape(132, 68).t().bfloat16()) and not odd_t[:, 132:].any()
     for (r, c), o, d in zip(shapes, offs, dsts):
         assert torch.equal(d, flat[o:o + r * c].reshape(r, c).t().bfloat16())
     w3 = flat[offs[3]:offs[3] + 512 * 1500].reshape(512, 1500).bfloat16()
@@ -710,7 +716,7 @@ def test_refresh_bf16_weights_one_launch():
     w0 = flat[offs[0]:offs[0] + 200 * 512].reshape(200, 512).bfloat16()
     assert torch.equal(stacked[:, :512], w0) and torch.equal(stacked[:, 512:], w0)
     # more matrices than one launch's table holds
-    many = (nv.WeightShadow * 100)(*[nv.WeightShadow(*items[i % 4]) for i in range(100)])
+    many = (nv.WeightShadow * 100)(*[nv.WeightShadow(*items[i % 5]) for i in range(100)])
     for d in dsts:
         d.zero_()
     nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), nv.ptr(flat16), n, many, 100, st))
@@ -721,7 +727,7 @@ def test_refresh_bf16_weights_one_launch():
     part16 = torch.full((n,), 3.0, dtype=torch.bfloat16, device="cuda")
     for d in dsts:
         d.zero_()
-    some = items[:4] + [(offs[1], shapes[1][0], shapes[1][1], part16.data_ptr() + 2 * offs[1], shapes[1][1], 0)]
+    some = items[:5] + [(offs[1], shapes[1][0], shapes[1][1], part16.data_ptr() + 2 * offs[1], shapes[1][1], 0)]
     some_c = (nv.WeightShadow * len(some))(*[nv.WeightShadow(*it) for it in some])
     nv.check(nv.lib.lidbox_refresh_bf16_weights(nv.ptr(flat), None, n, some_c, len(some), st))
     for (r, c), o, d in zip(shapes, offs, dsts):
