@@ -410,6 +410,31 @@ def test_cavg_demo_and_random():
         AverageDetectionCost(1, th)
 
 
+@pytest.mark.parametrize("B,N,Th", [(1, 2, 1), (17, 3, 5), (1100, 130, 65), (2048, 14, 100), (33, 257, 130), (512, 50, 100)])
+@pytest.mark.parametrize("nz,unit", [(None, None), ("3", "16"), ("1", "64"), ("7", "32")])
+def test_cavg_counters_exact_at_edge_shapes(B, N, Th, nz, unit, monkeypatch):
+    """lidbox_cavg_update (sixteen waves, one shared LDS copy, label chunks along grid.z): the four counter arrays are the oracle's
+    integers exactly -- one example, more classes than one LDS chunk holds (> 128), threshold counts off the 64-lane grid, batches past
+    one pass of 16 waves x 64 examples, two updates on top of each other, and every forced chunk count / walk unit"""
+    from lidbox_amd.metrics import SparseAverageDetectionCost
+    for k, v in (("LIDBOX_CAVG_NZ", nz), ("LIDBOX_CAVG_UNIT", unit)):
+        if v is not None:
+            monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(B * 7 + N)
+    thr = np.sort(rng.uniform(-5, 0, Th)).astype(np.float32)
+    g = SparseAverageDetectionCost(N, thr)
+    o = mo.SparseAverageDetectionCost(N, thr)
+    for _ in range(2):
+        s = mo.log_softmax(rng.standard_normal((B, N)) * 2).astype(np.float32)
+        s[rng.integers(0, B), rng.integers(0, N)] = thr[rng.integers(0, Th)]          # a score exactly on a threshold (>= counts)
+        y = rng.integers(0, N, size=B)
+        g.update_state(_dev(y, np.int64), _dev(s))
+        o.update_state(y, s)
+    for name in ("tp", "fn", "fp_pairs", "tn_pairs"):
+        assert torch.equal(getattr(g, name).cpu(), torch.from_numpy(getattr(o, name))), name
+    assert abs(float(g.result()) - o.result()) < 1e-6
+
+
 def test_adam_matches_keras_formula():
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(16)
