@@ -242,14 +242,14 @@ def test_stats_and_avg_pool():
     assert np.allclose(out[:, 5:].cpu().numpy(), 1e-5, rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,T,C", [(3, 33, 1500), (2, 1, 8), (5, 40, 64), (4, 12, 260)])
-def test_stats_pool_over_a_bf16_shadow(B, T, C):
+@pytest.mark.parametrize("B,T,C,Cp", [(3, 33, 1500, 1504), (2, 1, 8, 8), (5, 40, 64, 64), (4, 12, 260, 264), (3, 20, 36, 36), (2, 33, 1500, 1500),
+                                      (7, 36, 520, 528)])
+def test_stats_pool_over_a_bf16_shadow(B, T, C, Cp):
     """lidbox_stats_pool_fwd_bf16 / _bwd_bf16 (the bf16 policy's all-shadow mode: the pooling reads the last frame layer's bfloat16
-    shadow, rows padded to 8 channels): bit-identical to the fp32 kernels fed the shadow's values, hence within the fp32 kernels'
-    tolerance of the oracle on those values; shapes the register kernels do not cover are refused"""
+    shadow, row pitch Cp >= C a multiple of 4 channels): bit-identical to the fp32 kernels fed the shadow's values, hence within the fp32
+    kernels' tolerance of the oracle on those values; shapes the register kernels do not cover are refused"""
     from lidbox_amd import _native as nv
     rng = np.random.default_rng(B * 100 + T)
-    Cp = (C + 7) // 8 * 8
     x16 = torch.zeros((B, T, Cp), dtype=torch.bfloat16, device="cuda")
     x16[:, :, :C] = _dev(rng.standard_normal((B, T, C)) * 2 + 0.3).bfloat16()
     x32 = x16[:, :, :C].float().contiguous()
