@@ -126,7 +126,8 @@ class KernelTimer:
              "lidbox_extract_features_fwd_shadow": -1, "lidbox_extract_features_fwd_ex": -2,
              "lidbox_gemm_tn_partial": 4, "lidbox_gemm_nt_carry": 5, "lidbox_gemm_nt_tn_carry": 6,
              "lidbox_gemm_bf16_nn": 10, "lidbox_gemm_bf16_nt": 11, "lidbox_gemm_bf16_tn": 12, "lidbox_gemm_bf16s_nt": 13,
-             "lidbox_gemm_bf16s_tn": 14, "lidbox_gemm_bf16s_nt_carry": 15, "lidbox_gemm_bf16s_tn_partial": 16}
+             "lidbox_gemm_bf16s_tn": 14, "lidbox_gemm_bf16s_nt_carry": 15, "lidbox_gemm_bf16s_tn_partial": 16,
+             "lidbox_gemm_bf16s_nt_pair_carry": 17}
 
     def __init__(self, nv, feature_bytes=BYTES_PER_UTT_FEATURE):
         self.nv = nv
@@ -160,6 +161,10 @@ class KernelTimer:
             kind = 13
         elif kind == 16:       # lidbox_gemm_bf16s_tn's arguments + job
             kind = 14
+        if kind == 17:         # two lidbox_gemm_bf16s_nt argument lists (9 each) + ws, ws_bytes, jobs, njobs, stream
+            A0, A1 = args[0], args[9]
+            return ("gemm16s_rows_pp2_kernel<256, 2>",
+                    2.0 * A0.batch * A0.rows_per_batch * args[5] * args[6] + 2.0 * A1.batch * A1.rows_per_batch * args[14] * args[15])
         if kind < 0:          # (plan, kind, signals, [src_format,] B, ...): the streaming feature kernel of round 6
             return FEATURE_KERNEL, float(args[3 if kind == -1 else 4]) * self.feature_bytes
         if kind == 13:                                        # bf16-storage kernel: (A16, B16, ldb, C, C16, K, N, ...)
@@ -244,6 +249,9 @@ class KernelTimer:
                         key = "gemm16s_rows_kres_kernel"
                     elif out3[0]:
                         key = "gemm16s_rows_dma_kernel<%d, %d, %d>" % (out3[0], out3[1], out3[2])
+                elif self.ENTRY[_n] == 17:
+                    if self.nv.lib.lidbox_gemm_bf16s_last_pair() != 1:     # ran as two launches: not one kernel's bracket
+                        key = "gemm16s_rows (two launches of a pair call)"
                 elif self.ENTRY[_n] in (14, 16):
                     if self.nv.lib.lidbox_gemm_bf16s_tn_last_pp() > 0:     # the ping-pong wgrad tile (gemm16_pp_tn.h)
                         key = "gemm16s_tn_pp_kernel"

@@ -366,6 +366,19 @@ int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, long ldb, lid
                                int epilogue, const float* aux, void* workspace, size_t workspace_bytes,
                                const lidbox_reduce_job_t* jobs, int njobs, lidbox_stream_t stream);
 int lidbox_gemm_bf16s_last_carried(void);
+/* Two independent lidbox_gemm_bf16s_nt problems as ONE launch (round 6).  Reference: the input gradient of a strided Conv1D
+ * (xvector.py:40, kernel 3 / stride 2: tf.keras computes it as one conv_backprop_input); here it is one GEMM per row residue of the
+ * output-stationary form -- 492 tiles 1 024 deep and 396 tiles 512 deep at 512 utterances: 1.92 + 1.55 rounds of 256 CUs as two
+ * launches, 3.47 as one grid.  Both problems must be launches lidbox_gemm_bf16s_nt would run on the 256 x 256 ping-pong tile without a
+ * K split (gemm16_pp.h); anything else, or LIDBOX_GEMM16S_NO_PAIR=1, runs the two calls one after the other (the jobs ride with the
+ * first): same bits either way.  The outputs must not overlap; the operands may.  lidbox_gemm_bf16s_last_pair(): 1 if the calling
+ * thread's most recent call ran as one grid. */
+int lidbox_gemm_bf16s_nt_pair_carry(lidbox_rows_t A16_0, const void* B16_0, long ldb0, lidbox_rows_out_t C0, void* C16_0, int K0, int N0,
+                                    int epilogue0, const float* aux0, lidbox_rows_t A16_1, const void* B16_1, long ldb1,
+                                    lidbox_rows_out_t C1, void* C16_1, int K1, int N1, int epilogue1, const float* aux1,
+                                    void* workspace, size_t workspace_bytes, const lidbox_reduce_job_t* jobs, int njobs,
+                                    lidbox_stream_t stream);
+int lidbox_gemm_bf16s_last_pair(void);
 /* Kernel variant of the calling thread's most recent lidbox_gemm_bf16s_tn / _tn_partial (tests, profiling tools): the number of M
  * slices of the 256 x 256 eight-wave ping-pong tile (gemm16_pp_tn.h) if that ran, 0 for the four-wave 128 x 128 kernel.  The tile
  * is chosen for long slices of big layers (K1, N multiples of 256, >= 8 tiles, >= 2048 rows per slice: frame2's wgrad at 512

@@ -163,6 +163,9 @@ _SIGS = {
     "lidbox_gemm_bf16s_tn_partial": (_i, [Rows, Rows, _vp, _l, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),
     "lidbox_gemm_bf16s_nt_carry": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, _vp, _sz, C.POINTER(ReduceJob), _i, _vp]),
     "lidbox_gemm_bf16s_last_carried": (_i, []),
+    "lidbox_gemm_bf16s_nt_pair_carry": (_i, [Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp, Rows, _vp, _l, Rows, _vp, _i, _i, _i, _vp,
+                                             _vp, _sz, C.POINTER(ReduceJob), _i, _vp]),
+    "lidbox_gemm_bf16s_last_pair": (_i, []),
     "lidbox_gemm_bf16s_tn_last_pp": (_i, []),
     "lidbox_gemm_bf16s_tn_last_kres": (_i, []),
     "lidbox_f32_to_bf16": (_i, [_vp, _vp, _l, _vp]),

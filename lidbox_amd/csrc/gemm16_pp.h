@@ -382,15 +382,12 @@ constexpr int pp_lds_bytes() {
     return 3 * 256 * D16_ROW_BYTES + 2 * BN * D16_ROW_BYTES;
 }
 
+// one tile (index `tile` of `ntiles`, K range of split blockIdx.y) of one problem: the body of both kernels below
 template <int BN, int SUB>
-__global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
-                                                                  float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
-                                                                  const float* __restrict__ aux, int tiles_n, unsigned ntiles,
-                                                                  int k_per_split, const unsigned short* __restrict__ mask16, ReduceJobs rj) {
-    if (blockIdx.x < rj.total) {
-        if (blockIdx.y == 0 && threadIdx.x < 256) reduce_jobs_run(rj, blockIdx.x);
-        return;
-    }
+__device__ __forceinline__ void pp_tile(const RowsH& A, const RowsH& Bw, const RowsOutD& Cd, unsigned short* __restrict__ C16,
+                                        float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
+                                        const float* __restrict__ aux, int tiles_n, unsigned ntiles, int k_per_split,
+                                        const unsigned short* __restrict__ mask16, unsigned tile) {
     constexpr int BM = 256;
     constexpr int WN = BN / 64, WM = 8 / WN;                  // waves along N / M
     constexpr int MI = BM / WM / 32, NJ = 2;                  // 32 x 32 blocks per wave
@@ -405,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
     const int grp = wv >> 2;
     const int wm = wv / WN, wn = wv % WN;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem16p);
-    const unsigned chunk = xcd_chunk_id(blockIdx.x - rj.total, ntiles);
+    const unsigned chunk = xcd_chunk_id(tile, ntiles);
     const int tn = chunk % tiles_n;
     const long m0 = m_beg + (long)(chunk / tiles_n) * BM;
     const int n0 = tn * BN;
@@ -566,6 +563,46 @@ __global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH 
     }
     pp_store_tile<MI, NJ>(acc, reinterpret_cast<float*>(smem16p + wv * PP_EPI_BYTES), m0 + rowA, n0 + rowB, lane, m_beg, M, N, epi, aux, Cd, P,
                           split, C16, mask16, mp.bits, mp.complete());
+}
+
+template <int BN, int SUB>
+__global__ __launch_bounds__(512, 2) void gemm16s_rows_pp_kernel(RowsH A, RowsH Bw, RowsOutD Cd, unsigned short* __restrict__ C16,
+                                                                  float* __restrict__ P, long m_beg, long M, int K, int N, int epi,
+                                                                  const float* __restrict__ aux, int tiles_n, unsigned ntiles,
+                                                                  int k_per_split, const unsigned short* __restrict__ mask16, ReduceJobs rj) {
+    if (blockIdx.x < rj.total) {
+        if (blockIdx.y == 0 && threadIdx.x < 256) reduce_jobs_run(rj, blockIdx.x);
+        return;
+    }
+    pp_tile<BN, SUB>(A, Bw, Cd, C16, P, m_beg, M, K, N, epi, aux, tiles_n, ntiles, k_per_split, mask16, blockIdx.x - rj.total);
+}
+
+// Two independent problems in ONE grid (round 6: the two row residues of frame2's output-stationary dgrad, 492 tiles 1 024 deep and
+// 396 tiles 512 deep -- 1.92 + 1.55 rounds of 256 CUs as two launches, 3.47 as one): the first problem's tiles take the leading
+// workgroups (the caller passes the deeper contraction first: long tiles first packs best), no K splits, no slice workspace.
+struct PpProblem {
+    RowsH A, Bw;
+    RowsOutD Cd;
+    unsigned short* C16;
+    float* P;                            // NULL (no K splits); a kernel argument rather than a literal: hipcc 7.2's SimplifyCFG crashes on the latter
+    const unsigned short* mask16;
+    const float* aux;
+    long M;
+    int K, N, epi, tiles_n;
+    unsigned ntiles;
+};
+template <int BN, int SUB>
+__global__ __launch_bounds__(512, 2) void gemm16s_rows_pp2_kernel(PpProblem p0, PpProblem p1, ReduceJobs rj) {
+    if (blockIdx.x < rj.total) {
+        if (threadIdx.x < 256) reduce_jobs_run(rj, blockIdx.x);
+        return;
+    }
+    const unsigned t = blockIdx.x - rj.total;
+    if (t < p0.ntiles)
+        pp_tile<BN, SUB>(p0.A, p0.Bw, p0.Cd, p0.C16, p0.P, 0L, p0.M, p0.K, p0.N, p0.epi, p0.aux, p0.tiles_n, p0.ntiles, p0.K + D16_BK, p0.mask16, t);
+    else
+        pp_tile<BN, SUB>(p1.A, p1.Bw, p1.Cd, p1.C16, p1.P, 0L, p1.M, p1.K, p1.N, p1.epi, p1.aux, p1.tiles_n, p1.ntiles, p1.K + D16_BK, p1.mask16,
+                         t - p0.ntiles);
 }
 
 }  // namespace

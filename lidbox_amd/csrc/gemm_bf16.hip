@@ -1148,7 +1148,23 @@ int launch_rows16s_pp_t(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh,
 thread_local int g16_last_carried = 0;                 // jobs the calling thread's last lidbox_gemm_bf16s_nt_carry ran inside its GEMM launch
 thread_local int g16_tn_last_kres = 0;                 // slices of the calling thread's last storage wgrad if the K1-resident kernel ran it, else 0
 thread_local int g16_tn_last_pp = 0;                   // slices of the calling thread's last storage wgrad if the ping-pong tile ran it, else 0
+thread_local int g16_last_pair = 0;                    // 1 if the calling thread's last lidbox_gemm_bf16s_nt_pair_carry ran both problems in one grid
 thread_local int g16_last_variant[3] = {0, 0, 0};     // {bm, bn, stages} of the calling thread's last lidbox_gemm_bf16s_nt (0: register-staged)
+
+// two problems in one grid of the 256 x 256 ping-pong tile (gemm16_pp.h: gemm16s_rows_pp2_kernel); p0's tiles lead
+int launch_rows16s_pp2(const PpProblem& p0, const PpProblem& p1, hipStream_t st, const ReduceJobs& rj) {
+    constexpr size_t lds_bytes = (size_t)pp_lds_bytes<256>();
+    static std::atomic<unsigned long long> attr_devs{0};
+    int dev = 0;
+    LBX_HIP(hipGetDevice(&dev));
+    if (dev >= 64 || !(attr_devs.load() >> dev & 1ull)) {
+        LBX_HIP(hipFuncSetAttribute((const void*)gemm16s_rows_pp2_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (dev < 64) attr_devs.fetch_or(1ull << dev);
+    }
+    hipLaunchKernelGGL((gemm16s_rows_pp2_kernel<256, 2>), dim3(p0.ntiles + p1.ntiles + rj.total), dim3(512), lds_bytes, st, p0, p1, rj);
+    LBX_LAUNCH_OK();
+    return LIDBOX_OK;
+}
 
 int launch_rows16s_dma(const Dma16Choice& dc, const RowsH& Ah, const RowsH& Bh, const RowsOutD& Co, unsigned short* S, float* P, long M, int K,
                        int N, int epi, const float* aux, const unsigned short* mask16, hipStream_t st, const ReduceJobs& rj) {
@@ -1357,6 +1373,89 @@ extern "C" int lidbox_gemm_bf16s_nt_carry(lidbox_rows_t A16, const void* B16, lo
 }
 
 extern "C" int lidbox_gemm_bf16s_last_carried(void) { return g16_last_carried; }
+
+// Two independent lidbox_gemm_bf16s_nt problems (they may share A; their outputs must not overlap) as ONE launch when both would run on
+// the 256 x 256 ping-pong tile without a K split -- the two row residues of a strided convolution's output-stationary dgrad, whose tile
+// counts (1.92 + 1.55 rounds of 256 CUs at 512 utterances) pack better as one grid of 3.47 rounds; the deeper contraction leads.
+// Otherwise: the two calls one after the other (the jobs ride with the first).  Same bits either way (the same tile code).
+namespace {
+struct Nt16Call {
+    lidbox_rows_t A; const void* B; long ldb; lidbox_rows_out_t C; void* C16; int K, N, epilogue; const float* aux;
+};
+// the checks of lidbox_gemm_bf16s_nt_carry / launch_rows16s that decide whether a call may join a two-problem grid
+bool pp2_problem(const Nt16Call& c, size_t ws_bytes, PpProblem* out) {
+    const bool mask16 = (c.epilogue & LIDBOX_EPI_MASK_BF16) != 0;
+    const int epi = c.epilogue & ~LIDBOX_EPI_MASK_BF16;
+    const long M = (long)c.A.batch * c.A.rows_per_batch;
+    if (M <= 0 || c.N <= 0 || c.K <= 0) return false;
+    if (!c.C.base && (!c.C16 || epi == LIDBOX_EPI_ACCUM || epi == LIDBOX_EPI_ACCUM_RELU || epi == LIDBOX_EPI_ACCUM_RELU_MASK)) return false;
+    if (mask16 && epi != LIDBOX_EPI_RELU_MASK && epi != LIDBOX_EPI_ACCUM_RELU_MASK) return false;
+    lidbox_rows_out_t Cv = c.C;
+    if (!c.C.base) Cv.base = (float*)c.C16;
+    if (validate_rows_call("lidbox_gemm_bf16s_nt_pair_carry", c.A, (const float*)c.B, c.ldb, Cv, c.K, c.N, epi, c.aux, c.K)) return false;
+    const lidbox_rows_t Cin{c.C.base, c.C.batch_stride, c.C.row_stride, c.C.batch, c.C.rows_per_batch};
+    const bool a_ok = aligned16(c.A.base) && c.A.row_stride % 8 == 0 && (c.A.batch == 1 || c.A.batch_stride % 8 == 0);
+    if (!(a_ok && rows_aligned(Cin) && c.K % 8 == 0 && aligned16(c.B) && c.ldb % 8 == 0 && (c.C16 == nullptr || (((uintptr_t)c.C16) & 1) == 0)))
+        return false;
+    if (!mask16 && kres_applies(c.A, c.K, c.N)) return false;                  // the K-resident forward kernel may take it
+    const Dma16Choice dc = choose_dma16(M, c.N, c.K, ws_bytes, c.C.base != nullptr);
+    if (!(dc.bm == 256 && dc.bn == 256 && dc.stages == 2 && dc.splits == 1)) return false;
+    const double a_ext = ((double)(c.A.batch - 1) * (double)c.A.batch_stride + (double)c.A.rows_per_batch * (double)c.A.row_stride + c.K) * 2.0;
+    const double b_ext = ((double)c.N * (double)c.ldb + c.K) * 2.0;
+    if (!(a_ext < 4.0e9 && b_ext < 4.0e9)) return false;
+    out->A = RowsH{(const __bf16*)c.A.base, c.A.batch_stride, c.A.row_stride, c.A.batch, c.A.rows_per_batch};
+    out->Bw = RowsH{(const __bf16*)c.B, 0, c.ldb, 1, 0};
+    out->Cd = RowsOutD{c.C.base, c.C.batch_stride, c.C.row_stride, c.C.batch, c.C.rows_per_batch};
+    out->C16 = (unsigned short*)c.C16;
+    out->P = nullptr;
+    out->mask16 = mask16 ? (const unsigned short*)c.aux : nullptr;
+    out->aux = mask16 ? nullptr : c.aux;
+    out->M = M; out->K = c.K; out->N = c.N; out->epi = epi;
+    out->tiles_n = (int)lbx_cdiv((long)c.N, 256L);
+    out->ntiles = (unsigned)(lbx_cdiv(M, 256L) * out->tiles_n);
+    return true;
+}
+}  // namespace
+
+extern "C" int lidbox_gemm_bf16s_nt_pair_carry(lidbox_rows_t A0, const void* B0, long ldb0, lidbox_rows_out_t C0, void* C16_0, int K0, int N0,
+                                               int epilogue0, const float* aux0, lidbox_rows_t A1, const void* B1, long ldb1,
+                                               lidbox_rows_out_t C1, void* C16_1, int K1, int N1, int epilogue1, const float* aux1,
+                                               void* workspace, size_t workspace_bytes, const lidbox_reduce_job_t* jobs, int njobs,
+                                               lidbox_stream_t stream) {
+    g16_last_pair = 0;
+    const Nt16Call c0{A0, B0, ldb0, C0, C16_0, K0, N0, epilogue0, aux0}, c1{A1, B1, ldb1, C1, C16_1, K1, N1, epilogue1, aux1};
+    static const bool off = getenv("LIDBOX_GEMM16S_NO_PAIR") != nullptr;                       // A/B aid
+    PpProblem p0, p1;
+    ReduceJob js[MAX_CARRY];
+    int m = 0;
+    bool jobs_ok = true;
+    for (int i = 0; jobs && i < njobs; ++i) {
+        if (jobs[i].nblocks == 0) continue;
+        if (m >= MAX_CARRY) { jobs_ok = false; break; }
+        memcpy(&js[m], jobs + i, sizeof(ReduceJob));
+        if ((const void*)js[m].P == workspace || js[m].splits < 0) { jobs_ok = false; break; }
+        ++m;
+    }
+    if (!off && jobs_ok && getenv("LIDBOX_GEMM_NO_CARRY") == nullptr && aligned16(workspace) &&
+        pp2_problem(c0, workspace ? workspace_bytes : 0, &p0) && pp2_problem(c1, workspace ? workspace_bytes : 0, &p1)) {
+        ReduceJobs rj;
+        if (m > 0) rj = pack_carry(js, m, carry_cap16());
+        const bool swap = p1.K > p0.K;                                           // long tiles first
+        int rc = launch_rows16s_pp2(swap ? p1 : p0, swap ? p0 : p1, (hipStream_t)stream, rj);
+        if (rc) return rc;
+        g16_last_pair = 1;
+        g16_last_carried = m;
+        g16_last_variant[0] = 256; g16_last_variant[1] = 256; g16_last_variant[2] = 2;
+        return LIDBOX_OK;
+    }
+    int rc = lidbox_gemm_bf16s_nt_carry(A0, B0, ldb0, C0, C16_0, K0, N0, epilogue0, aux0, workspace, workspace_bytes, jobs, njobs, stream);
+    if (rc) return rc;
+    const int carried = g16_last_carried;
+    rc = lidbox_gemm_bf16s_nt_carry(A1, B1, ldb1, C1, C16_1, K1, N1, epilogue1, aux1, workspace, workspace_bytes, nullptr, 0, stream);
+    g16_last_carried = carried;
+    return rc;
+}
+extern "C" int lidbox_gemm_bf16s_last_pair(void) { return g16_last_pair; }
 extern "C" int lidbox_gemm_bf16s_tn_last_pp(void) { return g16_tn_last_pp; }
 extern "C" int lidbox_gemm_bf16s_tn_last_kres(void) { return g16_tn_last_kres; }
 

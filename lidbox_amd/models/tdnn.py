@@ -1041,6 +1041,7 @@ class SequentialTDNN:
             # k > s, output-stationary (_dgrad_residues): one GEMM per row residue, every row of dact[i] behind the pad written
             # exactly once; windows running past an utterance's last gradient row read the zero trail rows of dact16[i+1]
             Tp2, cp = dy16.shape[1], dy16.shape[2]
+            calls = []
             for rho, Q, u_min, u_max in self._dgrad_residues(i, ws.Ts[i]):
                 nu, p0 = u_max - u_min + 1, u_min * c.s + rho
                 A16 = nv.Rows(dy16.data_ptr() + 2 * (ws.pads[i + 1] + u_min - Q + 1) * cp, Tp2 * cp, cp, B, nu)
@@ -1051,9 +1052,16 @@ class SequentialTDNN:
                 elif relu_prev:
                     epi, mask = nv.EPI_RELU_MASK, ctypes.c_void_p(aprev.data_ptr() + 4 * p0 * cin)
                 sh = None if d16 is None else ctypes.c_void_p(d16.data_ptr() + 2 * p0 * cin)
+                calls.append((A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin, epi, mask))
+            if len(calls) == 2:
+                # the two row residues of a stride-2 layer (frame2: taps {0, 2} and {1}) write disjoint rows: ONE grid when both run
+                # on the ping-pong tile (lidbox_gemm_bf16s_nt_pair_carry; otherwise the library issues the two launches itself)
                 jobs, nj = self._take_jobs(ws, 2)
-                nv.check(lib.lidbox_gemm_bf16s_nt_carry(A16, nv.ptr(self.wd16[i][rho]), Q * cp, Cd, sh, Q * cp, cin, epi, mask, gws, gws_n,
-                                                        jobs, nj, st))
+                nv.check(lib.lidbox_gemm_bf16s_nt_pair_carry(*calls[0], *calls[1], gws, gws_n, jobs, nj, st))
+            else:
+                for call in calls:
+                    jobs, nj = self._take_jobs(ws, 2)
+                    nv.check(lib.lidbox_gemm_bf16s_nt_carry(*call, gws, gws_n, jobs, nj, st))
             if d16 is not None:
                 ws.d16_fresh.add(i)
             return

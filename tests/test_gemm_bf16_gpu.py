@@ -314,6 +314,86 @@ def test_bf16_pingpong_tile_carries_reduce_jobs_and_splits_k(variant, monkeypatc
     assert float((db.double() - dy16.double().sum(0)).abs().max()) <= 2e-5 * float(dy16.double().sum(0).abs().max())
 
 
+@pytest.mark.parametrize("forced", [True, False])
+def test_bf16_two_problems_in_one_grid_equal_two_launches(forced, monkeypatch):
+    """lidbox_gemm_bf16s_nt_pair_carry: the two row residues of a stride-2 convolution's output-stationary dgrad (windows of Q = 2 / 1
+    output-gradient rows against the stacked taps, interleaved output rows, ReLU mask from bf16 data, shadow-only output) as ONE grid of
+    the ping-pong tile == the two launches one after the other, bit for bit; the carried wgrad reduce runs in the same launch; a pair
+    the policy keeps off the tile falls back to the two calls.  forced: small ragged shapes on the forced tile;
+    otherwise frame2's own shapes at 256 utterances, where the policy picks the tile by itself."""
+    from lidbox_amd import _native as nv
+    if forced:
+        monkeypatch.setenv("LIDBOX_GEMM16S_DMA", "256,256,2,1")           # the tile, no K split (small problems get one otherwise)
+        Bn, To, Co, cin = 7, 45, 264, 520
+    else:
+        Bn, To, Co, cin = 256, 99, 512, 512
+    rng = np.random.default_rng(23)
+    s_, pad = 2, 2
+    Tin = To * s_
+    # dY shadow with one zero row ahead of every utterance (the window of residue 0 starts one row early) and one behind
+    dy16 = torch.zeros((Bn, To + 2, Co), dtype=torch.bfloat16, device="cuda")
+    dy16[:, 1:To + 1] = _dev(rng.standard_normal((Bn, To, Co))).bfloat16()
+    w_even = (_dev(rng.standard_normal((cin, 2 * Co))) * 0.05).bfloat16()       # taps {2, 0} side by side
+    w_odd = (_dev(rng.standard_normal((cin, Co))) * 0.05).bfloat16()            # tap {1}
+    act16 = _dev(rng.standard_normal((Bn, pad + Tin, cin))).bfloat16()
+    K1 = 200
+    x16 = _dev(rng.standard_normal((Bn * To, K1))).bfloat16()
+    st = nv.current_stream()
+    M = Bn * To
+    wsb = max(16, nv.lib.lidbox_gemm_bf16_rows_workspace(M, cin, 2 * Co))
+    ws1 = _ws(wsb)
+    ws2 = _ws(max(16, nv.lib.lidbox_gemm_bf16s_tn_workspace(M, K1, Co)))
+    epi = nv.EPI_RELU_MASK | nv.EPI_MASK_BF16
+
+    def problems(dx16):
+        out = []
+        for rho, Q, w in ((0, 2, w_even), (1, 1, w_odd)):
+            A = nv.Rows(dy16.data_ptr() + 2 * (1 - (Q - 1)) * Co, (To + 2) * Co, Co, Bn, To)
+            p0 = pad + rho
+            Cd = nv.Rows(None, (pad + Tin) * cin, s_ * cin, Bn, To)
+            out.append((A, nv.ptr(w), Q * Co, Cd, nv.C.c_void_p(dx16.data_ptr() + 2 * p0 * cin), Q * Co, cin, epi,
+                        nv.C.c_void_p(act16.data_ptr() + 2 * p0 * cin)))
+        return out
+
+    def run(pair):
+        dx16 = torch.full((Bn, pad + Tin, cin), 5.0, dtype=torch.bfloat16, device="cuda")
+        dw, db = torch.full((K1, Co), 3.0, device="cuda"), torch.full((Co,), 3.0, device="cuda")
+        job = nv.ReduceJob()
+        ra = nv.Rows(x16.data_ptr(), 0, K1, 1, M)
+        rb = nv.Rows(dy16.data_ptr() + 2 * Co, (To + 2) * Co, Co, Bn, To)
+        nv.check(nv.lib.lidbox_gemm_bf16s_tn_partial(ra, rb, nv.ptr(dw), Co, K1, Co, 0, nv.ptr(db), nv.ptr(ws2), ws2.numel(), nv.C.byref(job), st))
+        c0, c1 = problems(dx16)
+        if pair:
+            nv.check(nv.lib.lidbox_gemm_bf16s_nt_pair_carry(*c0, *c1, nv.ptr(ws1), ws1.numel(), nv.C.byref(job), 1, st))
+            took = nv.lib.lidbox_gemm_bf16s_last_pair()
+            assert nv.lib.lidbox_gemm_bf16s_last_carried() == 1
+        else:
+            nv.check(nv.lib.lidbox_gemm_bf16s_nt_carry(*c0, nv.ptr(ws1), ws1.numel(), nv.C.byref(job), 1, st))
+            nv.check(nv.lib.lidbox_gemm_bf16s_nt(*c1, nv.ptr(ws1), ws1.numel(), st))
+            took = 0
+        torch.cuda.synchronize()
+        return dx16, dw, db, took
+    a, b = run(True), run(False)
+    assert a[3] == 1
+    for u, v in zip(a[:3], b[:3]):
+        assert torch.equal(u, v)
+    dx16 = a[0]
+    assert bool((dx16[:, :pad] == 5.0).all())                            # the causal pad rows are nobody's output
+    # against the float64 product of the stored values: even rows = dY[u-1] W2^T + dY[u] W0^T (stacked), odd rows = dY[u] W1^T
+    dyd = dy16.double()
+    win = torch.cat([dyd[:, 0:To], dyd[:, 1:To + 1]], dim=2)             # rows u-1 | u
+    even = (win @ w_even.double().T) * (act16[:, pad::2].double() > 0)
+    odd = (dyd[:, 1:To + 1] @ w_odd.double().T) * (act16[:, pad + 1::2].double() > 0)
+    for got, ref in ((dx16[:, pad::2], even), (dx16[:, pad + 1::2], odd)):
+        assert float((got.double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    if forced:
+        monkeypatch.delenv("LIDBOX_GEMM16S_DMA")                         # the policy's own choice at this size: four-wave tiles
+        c, d = run(True), run(False)
+        assert c[3] == 0                                                 # fell back to two launches
+        for u, v in zip(c[:3], d[:3]):
+            assert torch.equal(u, v)
+
+
 def test_bf16_storage_gemm_implicit_rows_and_errors():
     """strided causal windows over a bf16 shadow [B, pad + T, C] (Conv1D k = 3, stride 2) and the alignment rules"""
     from lidbox_amd import _native as nv

@@ -23,7 +23,8 @@ def wrap(name, orig):
         e0.record(); rc = orig(*a); e1.record()
         A = a[0]
         M = A.batch * A.rows_per_batch
-        if name.endswith("bf16s_nt"): K, N = a[5], a[6]
+        if "bf16s_nt_pair" in name: K, N = a[5] + a[14], a[6]      # two problems in one grid: their contractions side by side
+        elif "bf16s_nt" in name: K, N = a[5], a[6]
         else: K, N = a[4], a[5]
         recs.append((name, M, K, N, e0, e1))
         return rc
